@@ -1,0 +1,161 @@
+"""TEST INFRASTRUCTURE (oracle) -- second, independent evaluation of the same model.
+
+The C oracle (ppc_oracle.c) is pinned against this file, which is written from the Stan
+program (inst/stan/negBinomial_MPI.stan:180-258) with *library* densities only:
+scipy.stats.nbinom / skewnorm / laplace / norm for the value, torch-CPU fp64 autograd for the
+gradient, mpmath for extreme arguments. Stan's `~` statements drop additive constants while the
+`target += neg_binomial_2_log_lpmf` keeps them, so the dropped constants are
+subtracted here explicitly.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def offsets(G, C, K):
+    a1 = 3 + G
+    a2 = a1 + K
+    sr = a2 + max(C - 2, 0) * K
+    return dict(lambda_mu=0, lambda_sigma=1, lambda_skew=2, intercept=3, alpha1=a1, alpha2=a2, sigma_raw=sr,
+                sigma_slope=sr + G, sigma_intercept=sr + G + 1, sigma_sigma=sr + G + 2, D=sr + G + 3)
+
+
+def unpack(u, G, C, K, lambda_mu_mu):
+    o = offsets(G, C, K)
+    p = dict(
+        lambda_mu=u[0] + lambda_mu_mu, lambda_sigma=math.exp(u[1]), lambda_skew=u[2],
+        intercept=u[o["intercept"]:o["intercept"] + G], alpha1=u[o["alpha1"]:o["alpha1"] + K],
+        alpha2=u[o["alpha2"]:o["sigma_raw"]].reshape(K, max(C - 2, 0)).T if C > 2 else np.zeros((0, K)),
+        sigma_raw=u[o["sigma_raw"]:o["sigma_raw"] + G], sigma_slope=-math.exp(u[o["sigma_slope"]]),
+        sigma_intercept=u[o["sigma_intercept"]], sigma_sigma=math.exp(u[o["sigma_sigma"]]))
+    return p
+
+
+def log_prob_scipy(u, counts, X, exposure, K, lambda_mu_mu=5.612671, excl=None):
+    """Value only, via scipy.stats library densities."""
+    from scipy import stats
+    counts = np.asarray(counts)
+    G, S = counts.shape
+    X = np.asarray(X, float).reshape(S, -1)
+    C = X.shape[1]
+    p = unpack(np.asarray(u, float), G, C, K, lambda_mu_mu)
+    half_log_2pi = 0.5 * math.log(2 * math.pi)
+    lp = u[1] + u[offsets(G, C, K)["sigma_slope"]] + u[offsets(G, C, K)["sigma_sigma"]]  # Jacobians
+    # `~ normal` with constants (and log sd of the fixed-scale hyper priors) dropped
+    def n_drop(x, m, s):
+        return stats.norm.logpdf(x, m, s) + half_log_2pi + math.log(s)
+    lp += n_drop(p["lambda_mu"], lambda_mu_mu, 2) + n_drop(p["lambda_sigma"], 0, 2) + n_drop(p["lambda_skew"], 0, 1)
+    lp += n_drop(p["sigma_intercept"], 0, 2) + n_drop(p["sigma_slope"], 0, 2) + n_drop(p["sigma_sigma"], 0, 2)
+    # skew_normal: scipy's pdf = 2/w phi(z) Phi(az); Stan keeps -log w - z^2/2 + log erfc(-az/sqrt2),
+    # i.e. drops -0.5 log(2 pi) only (log 2 + log Phi = log erfc).
+    lp += np.sum(stats.skewnorm.logpdf(p["intercept"], p["lambda_skew"], loc=p["lambda_mu"] + lambda_mu_mu,
+                                       scale=p["lambda_sigma"]) + half_log_2pi)
+    if C >= 2:
+        lp += np.sum(stats.laplace.logpdf(p["alpha1"], 0, 1) + math.log(2.0))
+    if C >= 3:
+        lp += np.sum(stats.norm.logpdf(p["alpha2"], 0, 2.5) + half_log_2pi + math.log(2.5))
+    lp += np.sum(stats.norm.logpdf(p["sigma_raw"], p["sigma_slope"] * p["intercept"] + p["sigma_intercept"],
+                                   p["sigma_sigma"]) + half_log_2pi)
+    alpha = np.zeros((C, G))
+    alpha[0] = p["intercept"]
+    if C >= 2:
+        alpha[1, :K] = p["alpha1"]
+    if C >= 3:
+        alpha[2:, :K] = p["alpha2"]
+    eta = (X @ alpha).T + np.asarray(exposure)[None, :]           # G x S
+    phi = np.exp(-p["sigma_raw"])[:, None]
+    mu = np.exp(eta)
+    ll = stats.nbinom.logpmf(counts, phi, phi / (phi + mu))
+    total = ll.sum()
+    if excl is not None and len(excl):
+        total -= ll.reshape(-1)[np.asarray(excl)].sum()
+    return float(lp + total)
+
+
+def log_prob_grad_torch(u, counts, X, exposure, K, lambda_mu_mu=5.612671, excl=None):
+    """Value and gradient by torch-CPU fp64 autograd over a direct transcription of the Stan model."""
+    import torch
+    counts_t = torch.as_tensor(np.asarray(counts), dtype=torch.float64)
+    G, S = counts_t.shape
+    Xt = torch.as_tensor(np.asarray(X, float).reshape(S, -1), dtype=torch.float64)
+    C = Xt.shape[1]
+    o = offsets(G, C, K)
+    ut = torch.tensor(np.asarray(u, float), dtype=torch.float64, requires_grad=True)
+    lambda_mu = ut[0] + lambda_mu_mu
+    lambda_sigma = torch.exp(ut[1])
+    lambda_skew = ut[2]
+    intercept = ut[o["intercept"]:o["intercept"] + G]
+    alpha1 = ut[o["alpha1"]:o["alpha1"] + K]
+    sigma_raw = ut[o["sigma_raw"]:o["sigma_raw"] + G]
+    sigma_slope = -torch.exp(ut[o["sigma_slope"]])
+    sigma_intercept = ut[o["sigma_intercept"]]
+    sigma_sigma = torch.exp(ut[o["sigma_sigma"]])
+    lp = ut[1] + ut[o["sigma_slope"]] + ut[o["sigma_sigma"]]
+    lp = lp - (lambda_mu - lambda_mu_mu) ** 2 / 8 - lambda_sigma ** 2 / 8 - lambda_skew ** 2 / 2
+    lp = lp - sigma_intercept ** 2 / 8 - sigma_slope ** 2 / 8 - sigma_sigma ** 2 / 8
+    z = (intercept - (lambda_mu + lambda_mu_mu)) / lambda_sigma
+    lp = lp + torch.sum(-torch.log(lambda_sigma) - 0.5 * z * z + torch.log(torch.special.erfc(-lambda_skew * z / math.sqrt(2))))
+    rows = [intercept]
+    if C >= 2:
+        lp = lp - torch.sum(torch.abs(alpha1))
+        rows.append(torch.cat([alpha1, torch.zeros(G - K, dtype=torch.float64)]))
+    if C >= 3:
+        alpha2 = ut[o["alpha2"]:o["sigma_raw"]].reshape(K, C - 2).T
+        lp = lp - torch.sum(alpha2 ** 2) / (2 * 2.5 ** 2)
+        for c in range(C - 2):
+            rows.append(torch.cat([alpha2[c], torch.zeros(G - K, dtype=torch.float64)]))
+    r = sigma_raw - (sigma_slope * intercept + sigma_intercept)
+    lp = lp + torch.sum(-torch.log(sigma_sigma) - 0.5 * r * r / sigma_sigma ** 2)
+    alpha = torch.stack(rows)                                        # C x G
+    eta = (Xt @ alpha).T + torch.as_tensor(np.asarray(exposure), dtype=torch.float64)[None, :]
+    phi = torch.exp(-sigma_raw)[:, None]
+    lse = torch.logaddexp(eta, torch.log(phi))
+    ll = (torch.lgamma(counts_t + phi) - torch.lgamma(phi) - torch.lgamma(counts_t + 1) + counts_t * eta
+          + phi * torch.log(phi) - (counts_t + phi) * lse)
+    total = ll.sum()
+    if excl is not None and len(excl):
+        total = total - ll.reshape(-1)[torch.as_tensor(np.asarray(excl), dtype=torch.long)].sum()
+    lp = lp + total
+    lp.backward()
+    return float(lp.detach()), ut.grad.numpy().copy()
+
+
+def synth(G, S, K=None, seed=20250, C=2, outliers=True):
+    """Synthetic generator of SURVEY.md 8(d) (cfg2-5). Returns dict(counts, X, exposure, K, truth)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    from scipy import stats
+    K = int(round(0.05 * G)) if K is None else K
+    group = np.zeros(S)
+    group[(S + 1) // 2:] = 1.0
+    cols = [np.ones(S), group]
+    for c in range(2, C):
+        cols.append(rng.normal(size=S))
+    X = np.stack(cols[:C], axis=1)
+    exposure = rng.normal(0, 0.2, S)
+    exposure -= exposure.mean()
+    intercept = stats.skewnorm.rvs(-1.0, loc=6.5, scale=1.8, size=G, random_state=rng)
+    sigma_raw = rng.normal(-0.3 * intercept, 0.4)
+    phi = np.exp(-sigma_raw)
+    alpha = np.zeros((C, G))
+    alpha[0] = intercept
+    if C >= 2:
+        alpha[1, :K] = rng.laplace(0, 1, K)
+    for c in range(2, C):
+        alpha[c, :K] = rng.normal(0, 0.5, K)
+    mu = np.exp((X @ alpha).T + exposure[None, :])
+    lam = rng.gamma(phi[:, None], mu / phi[:, None])
+    counts = rng.poisson(np.minimum(lam, 1e9)).astype(np.int64)
+    injected = []
+    if outliers and K > 0:
+        n_out = max(1, K // 10)
+        for g in rng.choice(K, n_out, replace=False):
+            s = int(rng.integers(S))
+            f = int(rng.integers(10, 51))
+            up = (alpha[1, g] > 0) == (group[s] > 0.5) if C >= 2 else True
+            counts[g, s] = counts[g, s] * f + f if up else counts[g, s] // f
+            injected.append((int(g), s))
+    counts = np.minimum(counts, 2**31 - 2).astype(np.int32)
+    return dict(counts=counts, X=X, exposure=exposure, K=K, injected=injected,
+                truth=dict(intercept=intercept, sigma_raw=sigma_raw, alpha=alpha))
