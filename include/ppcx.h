@@ -1,0 +1,113 @@
+/* ppcx.h -- C ABI of the MI355X-native posterior-predictive-check engine for ppcseq's
+ * negative-binomial hierarchical model.
+ *
+ * This is the drop-in boundary for the ONE hot path of stemangiola/ppcseq: what
+ * `do_inference()` (R/utilities.R:1321-1547) obtains today from
+ *     rstan::sampling(stanmodels$negBinomial_MPI, ...)            R/utilities.R:1497-1512
+ *     rstan::summary(fit, "counts_rng", prob = c(p, 1-p))         R/utilities.R:685-703
+ *     rstan::extract(fit, "lambda_log_param" / "sigma_raw")       R/utilities.R:738,743
+ *     rstan::summary(fit, "alpha_sub_1") (slope)                  R/utilities.R:1531,1250-1263
+ * whose model object is registered by src/RcppExports.cpp:15-25 / R/stanmodels.R:7-25.
+ * The Stan data block (inst/stan/negBinomial_MPI.stan:142-173) carries CPU-threading packing
+ * (counts_package, G_ind, symbol_end ...); this ABI takes the LOGICAL inputs instead and the
+ * R shim in INTEGRATION.md undoes the packing.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types; every function returns a status
+ * (0 = ok, < 0 = error class, message via ppcx_last_error()); the caller owns every buffer it
+ * passes, the library never keeps a caller pointer after return; device memory is internal.
+ * One call at a time per handle; different handles may be used from different threads.
+ */
+#ifndef PPCX_H
+#define PPCX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define PPCX_API __attribute__((visibility("default")))
+#else
+#define PPCX_API
+#endif
+
+#define PPCX_OK 0
+#define PPCX_ERR_ARG (-1)       /* invalid argument                                   */
+#define PPCX_ERR_HIP (-2)       /* HIP runtime error (message has hipGetErrorString)  */
+#define PPCX_ERR_INIT (-3)      /* no finite initial point after 100 attempts (Stan)  */
+#define PPCX_ERR_STEPSIZE (-4)  /* step-size heuristic left (0, 1e7) (Stan)           */
+#define PPCX_ERR_STALL (-5)     /* launch budget exhausted (internal guard)           */
+#define PPCX_ERR_LIMIT (-6)     /* size limit of this build                           */
+
+typedef struct ppcx_model ppcx_model;
+typedef struct ppcx_fit ppcx_fit;
+
+PPCX_API int ppcx_version(void);
+PPCX_API int ppcx_device_count(void);
+PPCX_API const char* ppcx_last_error(void);
+
+/* --- model = Stan data block (inst/stan/negBinomial_MPI.stan:142-173), logical form -------------
+ * counts : G x S int32, gene-major (sample index fastest); genes 0..K-1 are the checked ones
+ *          (how_many_to_check, R/utilities.R:1364-1368; G order R/utilities.R:949-952)
+ * X      : S x C doubles, column-major (R model.matrix, R/utilities.R:887-900)
+ * exposure_rate : S (R/utilities.R:1466-1473);  lambda_mu_mu = 5.612671 (R/methods.R:218)
+ * excl   : n_excl cell ids g*S+s, 0-based (to_exclude, R/utilities.R:321-359 / .stan:105-115)      */
+PPCX_API int ppcx_model_create(int device, int G, int S, int C, int K, const int32_t* counts, const double* X,
+                      const double* exposure_rate, double lambda_mu_mu, int n_excl, const int32_t* excl,
+                      ppcx_model** out);
+PPCX_API int ppcx_model_set_exclusions(ppcx_model* m, int n_excl, const int32_t* excl);   /* pass 2 of R/methods.R:320-342 */
+PPCX_API int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int groups_per_wave); /* 0 = automatic */
+PPCX_API int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int* nblocks);
+PPCX_API int ppcx_model_dim(const ppcx_model* m);          /* D = 2G + K*max(C-1,1) + 6 */
+PPCX_API void ppcx_model_destroy(ppcx_model* m);
+
+/* log_prob + gradient on the unconstrained scale, Stan parameter order (.stan:183-197), Jacobians
+ * included, `~` constants dropped, neg_binomial_2_log_lpmf constants kept (what NUTS integrates).
+ * u, grad: n_points x D ; lp: n_points.                                                             */
+PPCX_API int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, double* lp, double* grad);
+
+/* --- NUTS = rstan::sampling call of R/utilities.R:1497-1512 ------------------------------------- */
+typedef struct {
+  int chains, iter, warmup;          /* iter includes warmup (Stan convention)                     */
+  unsigned long long seed;
+  double adapt_delta;                /* 0.8  */
+  int max_treedepth;                 /* 10   */
+  double init_radius;                /* 2    (init = "random")                                     */
+  double stepsize0;                  /* 1    */
+  int init_buffer, term_buffer, window;   /* 75, 50, 25                                            */
+  int chain_id_offset;               /* global id of chain 0 of this call (multi-GPU: rank*chains)  */
+} ppcx_nuts_config;
+PPCX_API void ppcx_nuts_config_default(ppcx_nuts_config* cfg);
+
+PPCX_API int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fit** out);
+PPCX_API int ppcx_fit_info(const ppcx_fit* f, int* chains, int* n_keep, int* D, int* iter);
+/* kept draws, unconstrained, [chains][n_keep][D] */
+PPCX_API int ppcx_fit_get_draws(ppcx_fit* f, double* out);
+/* selected columns of the kept draws, [chains*n_keep][n_cols] */
+PPCX_API int ppcx_fit_get_columns(ppcx_fit* f, int n_cols, const int32_t* cols, double* out);
+/* lp: [chains][n_keep]; the rest [chains][iter] (warmup included); any pointer may be NULL */
+PPCX_API int ppcx_fit_get_diagnostics(ppcx_fit* f, double* lp, double* stepsize, int32_t* treedepth,
+                             int32_t* n_leapfrog, int32_t* divergent, double* accept);
+/* wall seconds of the sampling loop, gradient evaluations summed over chains, and the mean duration
+ * (ms) / count of the HIP-event-timed gene-kernel launches with the chain-launches they covered    */
+PPCX_API int ppcx_fit_get_timing(ppcx_fit* f, double* seconds, long long* grad_evals, double* gene_kernel_ms_mean,
+                        long long* gene_kernel_samples, double* gene_kernel_chain_launches_mean);
+
+/* generated quantities + credible intervals (.stan:259-266; R/utilities.R:685-703 full analysis,
+ * :733-784 approximated analysis when resample != 0 and n_gen = how_many_posterior_draws).
+ * ci: [K][S][4] = mean, sd, lower, upper.  counts_rng: NULL or [n_gen][K][S] int32.
+ * n_gen = 0 means one predictive draw per kept posterior draw.                                      */
+PPCX_API int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double p_lo, double p_hi,
+                 unsigned long long seed, int n_gen, int resample, double* ci, int32_t* counts_rng);
+PPCX_API void ppcx_fit_free(ppcx_fit* f);
+
+/* R .C() convention (all pointers, void): one do_inference() pass end to end.
+ * dims = {device, G, S, C, K, n_excl, chains, iter, warmup, n_gen, resample}; reals = {lambda_mu_mu,
+ * truncation_compensation, p_lo, p_hi, seed}. Outputs: ci [K*S*4], slope [K] (posterior mean of
+ * alpha_sub_1), status[1].                                                                          */
+PPCX_API void ppcx_do_inference_C(const int* dims, const int* counts, const double* X, const double* exposure_rate,
+                         const int* excl, const double* reals, double* ci, double* slope, int* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -454,12 +454,12 @@ static void transition(chain_t* c, uint32_t iter, int max_depth, trans_info* inf
     int valid; double lsw_sub = -INFINITY;
     if (scalar_uniform(c, t.rng_j++, iter) > 0.5) {
       ps_load(&z_fwd, c);
-      memcpy(rho_bck, rho, sizeof(double) * D); memcpy(p_bck_fwd, p_fwd_bck, sizeof(double) * D); memcpy(psh_bck_fwd, psh_fwd_bck, sizeof(double) * D);
+      memcpy(rho_bck, rho, sizeof(double) * D); memcpy(p_bck_fwd, p_fwd_fwd, sizeof(double) * D); memcpy(psh_bck_fwd, psh_fwd_fwd, sizeof(double) * D);
       valid = build_tree(&t, depth, &z_propose, psh_fwd_bck, psh_fwd_fwd, rho_fwd, p_fwd_bck, p_fwd_fwd, 1, &lsw_sub);
       ps_save(&z_fwd, c);
     } else {
       ps_load(&z_bck, c);
-      memcpy(rho_fwd, rho, sizeof(double) * D); memcpy(p_fwd_bck, p_bck_fwd, sizeof(double) * D); memcpy(psh_fwd_bck, psh_bck_fwd, sizeof(double) * D);
+      memcpy(rho_fwd, rho, sizeof(double) * D); memcpy(p_fwd_bck, p_bck_bck, sizeof(double) * D); memcpy(psh_fwd_bck, psh_bck_bck, sizeof(double) * D);
       valid = build_tree(&t, depth, &z_propose, psh_bck_fwd, psh_bck_bck, rho_bck, p_bck_fwd, p_bck_bck, -1, &lsw_sub);
       ps_save(&z_bck, c);
     }
@@ -666,6 +666,7 @@ static int64_t poisson_rng(double lam, ppco_stream* st) {
   }
 }
 PPCO_EXPORT int32_t ppco_nb2_log_rng(double eta, double phi, uint64_t seed, uint32_t cell, uint32_t draw) {
+  if (!(phi > 0.0) || !isfinite(phi) || !isfinite(eta)) return 2147483647;
   ppco_stream st; ppco_stream_init(&st, seed32(seed), 0x50504331u, cell, draw, 4u);
   double lam = gamma_rng(phi, &st) * (exp(eta) / phi);
   if (!(lam < 1073741824.0)) return 1073741823;          /* Stan errors above 2^30; we saturate */

@@ -1,0 +1,216 @@
+"""ctypes binding of the C ABI in include/ppcx.h (libppcx.so, built by ppcseq_amd/build.py).
+
+There is deliberately no CPU fallback: if the HIP library is missing or no MI355X is visible the
+calls raise. The library is loaded from the package directory (in-tree build).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libppcx.so")
+
+EXPORTS = [
+    "ppcx_version", "ppcx_device_count", "ppcx_last_error", "ppcx_model_create", "ppcx_model_set_exclusions",
+    "ppcx_model_set_launch", "ppcx_model_get_launch", "ppcx_model_dim", "ppcx_model_destroy", "ppcx_log_prob_grad",
+    "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
+    "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C",
+]
+
+
+class PpcxError(RuntimeError):
+    pass
+
+
+class NutsConfig(C.Structure):
+    _fields_ = [("chains", C.c_int), ("iter", C.c_int), ("warmup", C.c_int), ("seed", C.c_ulonglong),
+                ("adapt_delta", C.c_double), ("max_treedepth", C.c_int), ("init_radius", C.c_double),
+                ("stepsize0", C.c_double), ("init_buffer", C.c_int), ("term_buffer", C.c_int), ("window", C.c_int),
+                ("chain_id_offset", C.c_int)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libppcx.so (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PpcxError(f"{LIB_PATH} not found: run `python -m ppcseq_amd.build` (hipcc, gfx950) first; "
+                        "there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    lib.ppcx_last_error.restype = C.c_char_p
+    lib.ppcx_model_create.argtypes = [C.c_int] * 5 + [ip, dp, dp, C.c_double, C.c_int, ip, C.POINTER(C.c_void_p)]
+    lib.ppcx_model_set_exclusions.argtypes = [C.c_void_p, C.c_int, ip]
+    lib.ppcx_model_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.ppcx_model_get_launch.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.ppcx_model_dim.argtypes = [C.c_void_p]
+    lib.ppcx_model_destroy.argtypes = [C.c_void_p]
+    lib.ppcx_model_destroy.restype = None
+    lib.ppcx_log_prob_grad.argtypes = [C.c_void_p, C.c_int, dp, dp, dp]
+    lib.ppcx_nuts_config_default.argtypes = [C.POINTER(NutsConfig)]
+    lib.ppcx_nuts_config_default.restype = None
+    lib.ppcx_fit_nuts.argtypes = [C.c_void_p, C.POINTER(NutsConfig), C.POINTER(C.c_void_p)]
+    lib.ppcx_fit_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+    lib.ppcx_fit_get_draws.argtypes = [C.c_void_p, dp]
+    lib.ppcx_fit_get_columns.argtypes = [C.c_void_p, C.c_int, ip, dp]
+    lib.ppcx_fit_get_diagnostics.argtypes = [C.c_void_p, dp, dp, ip, ip, ip, dp]
+    lib.ppcx_fit_get_timing.argtypes = [C.c_void_p, dp, C.POINTER(C.c_longlong), dp, C.POINTER(C.c_longlong), dp]
+    lib.ppcx_fit_ppc.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_ulonglong, C.c_int, C.c_int, dp, ip]
+    lib.ppcx_fit_free.argtypes = [C.c_void_p]
+    lib.ppcx_fit_free.restype = None
+    _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise PpcxError(f"ppcx error {rc}: {load().ppcx_last_error().decode()}")
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def device_count() -> int:
+    return int(load().ppcx_device_count())
+
+
+class Model:
+    """Device-resident model inputs (Stan data block in logical form, include/ppcx.h)."""
+
+    def __init__(self, counts, X, exposure_rate, K, lambda_mu_mu=5.612671, excl=None, device=0):
+        lib = load()
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        if counts.ndim != 2:
+            raise ValueError("counts must be G x S")
+        self.G, self.S = counts.shape
+        X = np.asfortranarray(np.asarray(X, dtype=np.float64).reshape(self.S, -1))
+        self.C = X.shape[1]
+        self.K = int(K)
+        exposure_rate = np.ascontiguousarray(exposure_rate, dtype=np.float64)
+        if exposure_rate.shape != (self.S,):
+            raise ValueError("exposure_rate must have length S")
+        excl = np.ascontiguousarray(excl if excl is not None else np.zeros(0), dtype=np.int32)
+        self.X, self.exposure_rate = X, exposure_rate
+        h = C.c_void_p()
+        _check(lib.ppcx_model_create(int(device), self.G, self.S, self.C, self.K, _p(counts, C.c_int32),
+                                     _p(X, C.c_double), _p(exposure_rate, C.c_double), float(lambda_mu_mu),
+                                     int(excl.size), _p(excl, C.c_int32), C.byref(h)))
+        self._h = h
+        self.D = int(lib.ppcx_model_dim(h))
+
+    def set_exclusions(self, excl):
+        excl = np.ascontiguousarray(excl if excl is not None else np.zeros(0), dtype=np.int32)
+        _check(load().ppcx_model_set_exclusions(self._h, int(excl.size), _p(excl, C.c_int32)))
+
+    def set_launch(self, lanes_per_gene=0, groups_per_wave=0):
+        _check(load().ppcx_model_set_launch(self._h, int(lanes_per_gene), int(groups_per_wave)))
+
+    def get_launch(self):
+        a, b = C.c_int(), C.c_int()
+        _check(load().ppcx_model_get_launch(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def log_prob_grad(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        one = u.ndim == 1
+        u2 = u.reshape(-1, self.D)
+        lp = np.zeros(u2.shape[0])
+        g = np.zeros_like(u2)
+        _check(load().ppcx_log_prob_grad(self._h, u2.shape[0], _p(u2, C.c_double), _p(lp, C.c_double), _p(g, C.c_double)))
+        return (float(lp[0]), g[0]) if one else (lp, g)
+
+    def fit_nuts(self, chains=3, iter=300, warmup=150, seed=1, adapt_delta=0.8, max_treedepth=10, init_radius=2.0,
+                 stepsize0=1.0, init_buffer=75, term_buffer=50, window=25, chain_id_offset=0) -> "Fit":
+        cfg = NutsConfig(chains, iter, warmup, seed, adapt_delta, max_treedepth, init_radius, stepsize0,
+                         init_buffer, term_buffer, window, chain_id_offset)
+        h = C.c_void_p()
+        _check(load().ppcx_fit_nuts(self._h, C.byref(cfg), C.byref(h)))
+        return Fit(self, h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().ppcx_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class Timing:
+    seconds: float
+    grad_evals: int
+    gene_kernel_ms_mean: float
+    gene_kernel_samples: int
+    gene_kernel_chain_launches_mean: float
+
+
+class Fit:
+    """Kept draws + diagnostics of one NUTS run, resident on the device."""
+
+    def __init__(self, model: Model, handle):
+        self.model, self._h = model, handle
+        c, k, d, it = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(load().ppcx_fit_info(handle, C.byref(c), C.byref(k), C.byref(d), C.byref(it)))
+        self.chains, self.n_keep, self.D, self.iter = c.value, k.value, d.value, it.value
+
+    def draws(self):
+        out = np.zeros((self.chains, self.n_keep, self.D))
+        _check(load().ppcx_fit_get_draws(self._h, _p(out, C.c_double)))
+        return out
+
+    def columns(self, cols):
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        out = np.zeros((self.chains, self.n_keep, cols.size))
+        _check(load().ppcx_fit_get_columns(self._h, int(cols.size), _p(cols, C.c_int32), _p(out, C.c_double)))
+        return out
+
+    def diagnostics(self):
+        lp = np.zeros((self.chains, self.n_keep))
+        ss = np.zeros((self.chains, self.iter))
+        acc = np.zeros((self.chains, self.iter))
+        td = np.zeros((self.chains, self.iter), np.int32)
+        nl = np.zeros((self.chains, self.iter), np.int32)
+        dv = np.zeros((self.chains, self.iter), np.int32)
+        _check(load().ppcx_fit_get_diagnostics(self._h, _p(lp, C.c_double), _p(ss, C.c_double), _p(td, C.c_int32),
+                                                _p(nl, C.c_int32), _p(dv, C.c_int32), _p(acc, C.c_double)))
+        return dict(lp=lp, stepsize=ss, treedepth=td, n_leapfrog=nl, divergent=dv, accept=acc)
+
+    def timing(self) -> Timing:
+        s, ms, cl = C.c_double(), C.c_double(), C.c_double()
+        ge, ns = C.c_longlong(), C.c_longlong()
+        _check(load().ppcx_fit_get_timing(self._h, C.byref(s), C.byref(ge), C.byref(ms), C.byref(ns), C.byref(cl)))
+        return Timing(s.value, ge.value, ms.value, ns.value, cl.value)
+
+    def ppc(self, truncation_compensation=1.0, p_lo=0.025, p_hi=0.975, seed=1, n_gen=0, resample=False,
+            return_counts_rng=False):
+        K, S = self.model.K, self.model.S
+        ci = np.zeros((K, S, 4))
+        n = n_gen if n_gen > 0 else self.chains * self.n_keep
+        rng = np.zeros((n, K, S), np.int32) if return_counts_rng else None
+        _check(load().ppcx_fit_ppc(self._h, float(truncation_compensation), float(p_lo), float(p_hi), int(seed),
+                                   int(n_gen), int(bool(resample)), _p(ci, C.c_double), _p(rng, C.c_int32)))
+        return (ci, rng) if return_counts_rng else ci
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().ppcx_fit_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

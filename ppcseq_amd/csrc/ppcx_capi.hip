@@ -1,0 +1,508 @@
+// ppcx_capi.hip -- host side of the C ABI declared in include/ppcx.h.
+// Owns device memory, chooses the launch geometry, pumps the (gene kernel, chain kernel) launch pairs
+// and copies results back. No torch types, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <chrono>
+#include <string>
+#include <vector>
+#include "../../include/ppcx.h"
+#include "ppcx_kernels.h"
+
+using namespace ppcx;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+struct ppcx_model {
+  int device;
+  Dims d;
+  int CM, L, groups_per_wave, nblocks;
+  int L_override, gpw_override;
+  std::vector<int32_t> counts_host;            // original counts (exclusions are re-applied on a copy)
+  std::vector<double> X_host, expo_host;
+  int* d_counts = nullptr;
+  double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_ncell = nullptr;
+  hipStream_t stream = nullptr;
+};
+
+struct ppcx_fit {
+  ppcx_model* m;
+  NutsConfig cfg;
+  int chains, n_keep, iter;
+  double* d_draws = nullptr;                   // [chains][n_keep][D]
+  double *d_lp = nullptr, *d_stepsize = nullptr, *d_accept = nullptr;
+  int *d_treedepth = nullptr, *d_nleap = nullptr, *d_div = nullptr;
+  double seconds = 0; long long grad_evals = 0;
+  double kA_ms_mean = 0; long long kA_samples = 0; double kA_chain_launches_mean = 0;
+};
+
+extern "C" int ppcx_version(void) { return 100; }
+extern "C" int ppcx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" const char* ppcx_last_error(void) { return g_err.c_str(); }
+
+// choose lanes-per-gene L and blocks per chain: maximise (lane utilisation) x (SIMD balance)
+static void choose_launch(ppcx_model* m, int nchains) {
+  const int G = m->d.G, S = m->d.S;
+  const double slots = 1024.0 * 2.0;           // SIMDs x resident waves per SIMD (VGPR-limited)
+  int bestL = 64; double best = -1.0;
+  for (int L = 1; L <= 64; L <<= 1) {
+    const int iters = (S + L - 1) / L;
+    const double util = (double)S / ((double)iters * L);
+    const double waves = ceil((double)G * L / 64.0) * nchains;
+    const double bal = waves / (ceil(waves / slots) * slots);
+    const double coal = 1.0 + 0.01 * log2((double)L);    // mild preference for wider contiguous reads
+    const double score = util * bal * coal;
+    if (score > best) { best = score; bestL = L; }
+  }
+  m->L = m->L_override > 0 ? m->L_override : bestL;
+  const int gpw = 64 / m->L;
+  const int ngroups = (G + gpw - 1) / gpw;
+  int r = m->gpw_override > 0 ? m->gpw_override : 1;
+  const int cap = 640;
+  int nb = (ngroups + 4 * r - 1) / (4 * r);
+  while (nb > cap) { ++r; nb = (ngroups + 4 * r - 1) / (4 * r); }
+  m->groups_per_wave = r;
+  m->nblocks = nb < 1 ? 1 : nb;
+}
+
+static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
+  const int G = m->d.G, S = m->d.S, C = m->d.C;
+  std::vector<int32_t> cnt(m->counts_host);
+  for (int e = 0; e < n_excl; ++e) {
+    if (excl[e] < 0 || excl[e] >= G * S) return fail(PPCX_ERR_ARG, "excluded cell id out of range");
+    cnt[excl[e]] = -1;
+  }
+  std::vector<double> Sy(G, 0.0), SyE(G, 0.0), SyX((size_t)C * G, 0.0), ncell(G, 0.0);
+  double lg1 = 0.0;
+  for (int g = 0; g < G; ++g) {
+    double sy = 0, sye = 0, nc = 0;
+    for (int s = 0; s < S; ++s) {
+      const int y = cnt[(size_t)g * S + s];
+      if (y < 0) continue;
+      sy += y; sye += (double)y * m->expo_host[s]; nc += 1.0; lg1 += lgamma((double)y + 1.0);
+      for (int c = 0; c < C; ++c) SyX[(size_t)c * G + g] += (double)y * m->X_host[(size_t)c * S + s];
+    }
+    Sy[g] = sy; SyE[g] = sye; ncell[g] = nc;
+  }
+  m->d.lgamma_y1_total = lg1;
+  HIPCHK(hipMemcpy(m->d_counts, cnt.data(), sizeof(int32_t) * cnt.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->d_Sy, Sy.data(), sizeof(double) * G, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->d_SyE, SyE.data(), sizeof(double) * G, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->d_SyX, SyX.data(), sizeof(double) * SyX.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->d_ncell, ncell.data(), sizeof(double) * G, hipMemcpyHostToDevice));
+  return PPCX_OK;
+}
+
+extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const int32_t* counts, const double* X,
+                                 const double* exposure, double lambda_mu_mu, int n_excl, const int32_t* excl,
+                                 ppcx_model** out) {
+  if (!out) return fail(PPCX_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (G < 1 || S < 1 || C < 1 || K < 0 || K > G) return fail(PPCX_ERR_ARG, "need G>=1, S>=1, C>=1, 0<=K<=G");
+  if (C > kMaxC) return fail(PPCX_ERR_LIMIT, "C exceeds the 8 design columns this build supports");
+  if ((long long)G * S > 2000000000LL) return fail(PPCX_ERR_LIMIT, "G*S exceeds int32 cell ids");
+  if (!counts || !X || !exposure || (n_excl > 0 && !excl)) return fail(PPCX_ERR_ARG, "NULL input buffer");
+  for (long long i = 0; i < (long long)G * S; ++i) if (counts[i] < 0) return fail(PPCX_ERR_ARG, "negative count");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(PPCX_ERR_ARG, "no such HIP device");
+  HIPCHK(hipSetDevice(device));
+  ppcx_model* m = new ppcx_model();
+  m->device = device;
+  m->d = make_dims(G, S, C, K, lambda_mu_mu);
+  m->CM = C <= 2 ? 2 : (C <= 4 ? 4 : 8);
+  m->L_override = 0; m->gpw_override = 0;
+  m->counts_host.assign(counts, counts + (size_t)G * S);
+  m->X_host.assign(X, X + (size_t)S * C);
+  m->expo_host.assign(exposure, exposure + S);
+  int x0 = 1;
+  for (int s = 0; s < S; ++s) if (X[s] != 1.0) x0 = 0;
+  m->d.x0_is_one = x0;
+  std::vector<double> E(S);
+  for (int s = 0; s < S; ++s) E[s] = exp(exposure[s]);
+#define MCHK(expr) do { int rc_ = (expr); if (rc_ != PPCX_OK) { ppcx_model_destroy(m); return rc_; } } while (0)
+#define MHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ppcx_model_destroy(m); return fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+  MHIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  MHIP(hipMalloc(&m->d_counts, sizeof(int32_t) * (size_t)G * S));
+  MHIP(hipMalloc(&m->d_E, sizeof(double) * S));
+  MHIP(hipMalloc(&m->d_expo, sizeof(double) * S));
+  MHIP(hipMalloc(&m->d_X, sizeof(double) * (size_t)S * C));
+  MHIP(hipMalloc(&m->d_Sy, sizeof(double) * G));
+  MHIP(hipMalloc(&m->d_SyE, sizeof(double) * G));
+  MHIP(hipMalloc(&m->d_SyX, sizeof(double) * (size_t)C * G));
+  MHIP(hipMalloc(&m->d_ncell, sizeof(double) * G));
+  MHIP(hipMemcpy(m->d_E, E.data(), sizeof(double) * S, hipMemcpyHostToDevice));
+  MHIP(hipMemcpy(m->d_expo, exposure, sizeof(double) * S, hipMemcpyHostToDevice));
+  MHIP(hipMemcpy(m->d_X, X, sizeof(double) * (size_t)S * C, hipMemcpyHostToDevice));
+  MCHK(upload_counts(m, n_excl, excl));
+  choose_launch(m, 1);
+  *out = m;
+  return PPCX_OK;
+}
+
+extern "C" int ppcx_model_set_exclusions(ppcx_model* m, int n_excl, const int32_t* excl) {
+  if (!m || (n_excl > 0 && !excl) || n_excl < 0) return fail(PPCX_ERR_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(m->device));
+  return upload_counts(m, n_excl, excl);
+}
+extern "C" int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int groups_per_wave) {
+  if (!m) return fail(PPCX_ERR_ARG, "model is NULL");
+  if (lanes_per_gene != 0 && (lanes_per_gene < 1 || lanes_per_gene > 64 || (lanes_per_gene & (lanes_per_gene - 1))))
+    return fail(PPCX_ERR_ARG, "lanes_per_gene must be 0 or a power of two <= 64");
+  m->L_override = lanes_per_gene; m->gpw_override = groups_per_wave > 0 ? groups_per_wave : 0;
+  choose_launch(m, 1);
+  return PPCX_OK;
+}
+extern "C" int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int* nblocks) {
+  if (!m) return fail(PPCX_ERR_ARG, "model is NULL");
+  if (lanes_per_gene) *lanes_per_gene = m->L;
+  if (nblocks) *nblocks = m->nblocks;
+  return PPCX_OK;
+}
+extern "C" int ppcx_model_dim(const ppcx_model* m) { return m ? m->d.D : PPCX_ERR_ARG; }
+extern "C" void ppcx_model_destroy(ppcx_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  (void)hipFree(m->d_counts); (void)hipFree(m->d_E); (void)hipFree(m->d_expo); (void)hipFree(m->d_X);
+  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_ncell);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+extern "C" void ppcx_nuts_config_default(ppcx_nuts_config* c) {
+  if (!c) return;
+  c->chains = 3; c->iter = 300; c->warmup = 150; c->seed = 1; c->adapt_delta = 0.8; c->max_treedepth = 10;
+  c->init_radius = 2.0; c->stepsize0 = 1.0; c->init_buffer = 75; c->term_buffer = 50; c->window = 25;
+  c->chain_id_offset = 0;
+}
+
+// device scratch of one run of the launch pump
+struct Work {
+  double *vecs = nullptr, *hyper_vecs = nullptr, *partials = nullptr;
+  Cmd* cmds = nullptr; ChainState* states = nullptr; int* done = nullptr;
+  int* done_host = nullptr;
+  long Dpad = 0;
+  ~Work() {
+    (void)hipFree(vecs); (void)hipFree(hyper_vecs); (void)hipFree(partials); (void)hipFree(cmds);
+    (void)hipFree(states); (void)hipFree(done);
+    if (done_host) (void)hipHostFree(done_host);
+  }
+};
+
+static int work_alloc(Work& w, ppcx_model* m, int nchains) {
+  const int D = m->d.D;
+  w.Dpad = ((long)D + 31) / 32 * 32;
+  HIPCHK(hipMalloc(&w.vecs, sizeof(double) * (size_t)nchains * V_COUNT * w.Dpad));
+  HIPCHK(hipMalloc(&w.hyper_vecs, sizeof(double) * (size_t)nchains * V_COUNT * 8));
+  HIPCHK(hipMalloc(&w.partials, sizeof(double) * (size_t)nchains * m->nblocks * PT_COUNT));
+  HIPCHK(hipMalloc(&w.cmds, sizeof(Cmd) * nchains));
+  HIPCHK(hipMalloc(&w.states, sizeof(ChainState) * nchains));
+  HIPCHK(hipMalloc(&w.done, sizeof(int) * nchains));
+  HIPCHK(hipHostMalloc(&w.done_host, sizeof(int) * nchains));
+  HIPCHK(hipMemsetAsync(w.vecs, 0, sizeof(double) * (size_t)nchains * V_COUNT * w.Dpad, m->stream));
+  HIPCHK(hipMemsetAsync(w.hyper_vecs, 0, sizeof(double) * (size_t)nchains * V_COUNT * 8, m->stream));
+  HIPCHK(hipMemsetAsync(w.partials, 0, sizeof(double) * (size_t)nchains * m->nblocks * PT_COUNT, m->stream));
+  HIPCHK(hipMemsetAsync(w.cmds, 0, sizeof(Cmd) * nchains, m->stream));
+  HIPCHK(hipMemsetAsync(w.done, 0, sizeof(int) * nchains, m->stream));
+  for (int c = 0; c < nchains; ++c) {          // inverse metric starts at identity
+    HIPCHK(launch_fill_kernel(w.vecs + ((size_t)c * V_COUNT + V_MINV) * w.Dpad, w.Dpad, 1.0, m->stream));
+    HIPCHK(launch_fill_kernel(w.hyper_vecs + ((size_t)c * V_COUNT + V_MINV) * 8, 8, 1.0, m->stream));
+  }
+  return PPCX_OK;
+}
+
+struct PumpStats { double kA_ms_sum = 0; long long kA_samples = 0; double chain_launches = 0; long long pairs = 0; };
+
+// Launch (A,B) pairs until every chain reports done. `max_pairs` bounds the loop.
+static int pump(ppcx_model* m, Work& w, int nchains, const GeneArgs& ga, const ChainArgs& ca, long long max_pairs,
+                bool time_kernels, PumpStats* stats) {
+  hipStream_t st = m->stream;
+  HIPCHK(launch_chain_kernel(ca, nchains, st));                 // PH_START -> first command
+  const int batch = 32, sample_every = 16;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (time_kernels) { HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1)); }
+  long long pairs = 0; int n_done = 0;
+  int rc = PPCX_OK;
+  while (true) {
+    bool sampled = false;
+    for (int i = 0; i < batch; ++i, ++pairs) {
+      const bool smp = time_kernels && !sampled && (pairs / batch) % sample_every == 0 && i == batch / 2;
+      if (smp) HIPCHK(hipEventRecord(ev0, st));
+      HIPCHK(launch_gene_kernel(m->L, m->CM, ga, m->nblocks, nchains, st));
+      if (smp) { HIPCHK(hipEventRecord(ev1, st)); sampled = true; }
+      HIPCHK(launch_chain_kernel(ca, nchains, st));
+    }
+    HIPCHK(hipMemcpyAsync(w.done_host, w.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (sampled && n_done == 0) {               // only launches in which every chain was still active
+      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+      stats->kA_ms_sum += ms; stats->kA_samples++; stats->chain_launches += nchains;
+    }
+    n_done = 0;
+    for (int c = 0; c < nchains; ++c) {
+      if (w.done_host[c]) ++n_done;
+      if (w.done_host[c] == 2) rc = fail(PPCX_ERR_INIT, "no finite initial point after 100 attempts");
+      if (w.done_host[c] == 3) rc = fail(PPCX_ERR_STEPSIZE, "step-size heuristic diverged");
+    }
+    if (n_done == nchains) break;
+    if (pairs > max_pairs) { rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished"); break; }
+  }
+  if (ev0) (void)hipEventDestroy(ev0);
+  if (ev1) (void)hipEventDestroy(ev1);
+  stats->pairs = pairs;
+  return rc;
+}
+
+static GeneArgs gene_args(ppcx_model* m, Work& w, double* draws, long draws_stride) {
+  GeneArgs ga;
+  ga.d = m->d; ga.counts = m->d_counts; ga.sampleE = m->d_E; ga.exposure = m->d_expo; ga.X = m->d_X;
+  ga.Sy = m->d_Sy; ga.SyE = m->d_SyE; ga.SyX = m->d_SyX; ga.ncell = m->d_ncell;
+  ga.vecs = w.vecs; ga.Dpad = w.Dpad; ga.cmds = w.cmds; ga.partials = w.partials;
+  ga.draws = draws; ga.draws_chain_stride = draws_stride;
+  return ga;
+}
+
+extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, double* lp, double* grad) {
+  if (!m || n_points < 1 || !u || !lp) return fail(PPCX_ERR_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(m->device));
+  const int D = m->d.D;
+  const int maxb = 256;                         // points per batch (grid.y)
+  for (int p0 = 0; p0 < n_points; p0 += maxb) {
+    const int nb = n_points - p0 < maxb ? n_points - p0 : maxb;
+    choose_launch(m, nb);
+    Work w;
+    int rc = work_alloc(w, m, nb);
+    if (rc != PPCX_OK) return rc;
+    std::vector<ChainState> states(nb);
+    NutsConfig cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.chains = nb; cfg.iter = 0; cfg.warmup = 0; cfg.seed = 0; cfg.adapt_delta = 0.8; cfg.max_treedepth = 10;
+    cfg.init_radius = 2; cfg.stepsize0 = 1; cfg.init_buffer = 75; cfg.term_buffer = 50; cfg.window = 25; cfg.chain_id_offset = 0;
+    for (int c = 0; c < nb; ++c) state_init(states[c], cfg, c, 1);
+    HIPCHK(hipMemcpyAsync(w.states, states.data(), sizeof(ChainState) * nb, hipMemcpyHostToDevice, m->stream));
+    std::vector<double> hq((size_t)nb * V_COUNT * 8, 0.0);
+    for (int c = 0; c < nb; ++c) {
+      const double* uc = u + (size_t)(p0 + c) * D;
+      HIPCHK(hipMemcpyAsync(w.vecs + ((size_t)c * V_COUNT + V_Q1) * w.Dpad, uc, sizeof(double) * D, hipMemcpyHostToDevice, m->stream));
+      for (int k = 0; k < 6; ++k) hq[((size_t)c * V_COUNT + V_Q1) * 8 + k] = uc[hyper_index(m->d, k)];
+      for (int k = 0; k < 8; ++k) hq[((size_t)c * V_COUNT + V_MINV) * 8 + k] = 1.0;
+    }
+    HIPCHK(hipMemcpyAsync(w.hyper_vecs, hq.data(), sizeof(double) * hq.size(), hipMemcpyHostToDevice, m->stream));
+    GeneArgs ga = gene_args(m, w, nullptr, 0);
+    ChainArgs ca; memset(&ca, 0, sizeof ca);
+    ca.d = m->d; ca.states = w.states; ca.cmds = w.cmds; ca.partials = w.partials; ca.nblocks = m->nblocks;
+    ca.hyper_vecs = w.hyper_vecs; ca.done = w.done;
+    PumpStats ps;
+    rc = pump(m, w, nb, ga, ca, 64, false, &ps);
+    if (rc != PPCX_OK) return rc;
+    HIPCHK(hipMemcpy(states.data(), w.states, sizeof(ChainState) * nb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hq.data(), w.hyper_vecs, sizeof(double) * hq.size(), hipMemcpyDeviceToHost));
+    for (int c = 0; c < nb; ++c) {
+      lp[p0 + c] = states[c].lp_eval;
+      if (grad) {
+        double* gc = grad + (size_t)(p0 + c) * D;
+        HIPCHK(hipMemcpy(gc, w.vecs + ((size_t)c * V_COUNT + V_G1) * w.Dpad, sizeof(double) * D, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 6; ++k) gc[hyper_index(m->d, k)] = hq[((size_t)c * V_COUNT + V_G1) * 8 + k];
+      }
+    }
+  }
+  return PPCX_OK;
+}
+
+extern "C" void ppcx_fit_free(ppcx_fit* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->m->device);
+  (void)hipFree(f->d_draws); (void)hipFree(f->d_lp); (void)hipFree(f->d_stepsize); (void)hipFree(f->d_accept);
+  (void)hipFree(f->d_treedepth); (void)hipFree(f->d_nleap); (void)hipFree(f->d_div);
+  delete f;
+}
+
+extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fit** out) {
+  if (!m || !cfg || !out) return fail(PPCX_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  if (cfg->chains < 1 || cfg->chains > 1024 || cfg->iter < 1 || cfg->warmup < 0 || cfg->warmup > cfg->iter)
+    return fail(PPCX_ERR_ARG, "need 1<=chains<=1024, iter>=1, 0<=warmup<=iter");
+  if (cfg->max_treedepth < 1 || cfg->max_treedepth > kMaxDepth) return fail(PPCX_ERR_LIMIT, "max_treedepth must be in 1..10");
+  HIPCHK(hipSetDevice(m->device));
+  const int nch = cfg->chains, D = m->d.D, iter = cfg->iter, n_keep = cfg->iter - cfg->warmup;
+  choose_launch(m, nch);
+  ppcx_fit* f = new ppcx_fit();
+  f->m = m; f->chains = nch; f->n_keep = n_keep; f->iter = iter;
+  NutsConfig nc;
+  nc.chains = nch; nc.iter = iter; nc.warmup = cfg->warmup; nc.seed = cfg->seed; nc.adapt_delta = cfg->adapt_delta;
+  nc.max_treedepth = cfg->max_treedepth; nc.init_radius = cfg->init_radius; nc.stepsize0 = cfg->stepsize0;
+  nc.init_buffer = cfg->init_buffer; nc.term_buffer = cfg->term_buffer; nc.window = cfg->window;
+  nc.chain_id_offset = cfg->chain_id_offset;
+  f->cfg = nc;
+#define FHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ppcx_fit_free(f); return fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+  if (n_keep > 0) FHIP(hipMalloc(&f->d_draws, sizeof(double) * (size_t)nch * n_keep * D));
+  if (n_keep > 0) FHIP(hipMalloc(&f->d_lp, sizeof(double) * (size_t)nch * n_keep));
+  FHIP(hipMalloc(&f->d_stepsize, sizeof(double) * (size_t)nch * iter));
+  FHIP(hipMalloc(&f->d_accept, sizeof(double) * (size_t)nch * iter));
+  FHIP(hipMalloc(&f->d_treedepth, sizeof(int) * (size_t)nch * iter));
+  FHIP(hipMalloc(&f->d_nleap, sizeof(int) * (size_t)nch * iter));
+  FHIP(hipMalloc(&f->d_div, sizeof(int) * (size_t)nch * iter));
+  FHIP(hipMemsetAsync(f->d_stepsize, 0, sizeof(double) * (size_t)nch * iter, m->stream));
+  FHIP(hipMemsetAsync(f->d_accept, 0, sizeof(double) * (size_t)nch * iter, m->stream));
+  FHIP(hipMemsetAsync(f->d_treedepth, 0, sizeof(int) * (size_t)nch * iter, m->stream));
+  FHIP(hipMemsetAsync(f->d_nleap, 0, sizeof(int) * (size_t)nch * iter, m->stream));
+  FHIP(hipMemsetAsync(f->d_div, 0, sizeof(int) * (size_t)nch * iter, m->stream));
+  Work w;
+  int rc = work_alloc(w, m, nch);
+  if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }
+  std::vector<ChainState> states(nch);
+  for (int c = 0; c < nch; ++c) state_init(states[c], nc, c, 0);
+  FHIP(hipMemcpyAsync(w.states, states.data(), sizeof(ChainState) * nch, hipMemcpyHostToDevice, m->stream));
+  GeneArgs ga = gene_args(m, w, f->d_draws, (long)n_keep * D);
+  ChainArgs ca; memset(&ca, 0, sizeof ca);
+  ca.d = m->d; ca.states = w.states; ca.cmds = w.cmds; ca.partials = w.partials; ca.nblocks = m->nblocks;
+  ca.hyper_vecs = w.hyper_vecs; ca.draws = f->d_draws; ca.draws_chain_stride = (long)n_keep * D;
+  ca.n_keep = n_keep; ca.iter = iter;
+  ca.out_lp = f->d_lp; ca.out_stepsize = f->d_stepsize; ca.out_treedepth = f->d_treedepth;
+  ca.out_n_leapfrog = f->d_nleap; ca.out_divergent = f->d_div; ca.out_accept = f->d_accept; ca.done = w.done;
+  FHIP(hipStreamSynchronize(m->stream));
+  const long long max_pairs = (long long)iter * ((1LL << cfg->max_treedepth) + 8) + 100000;
+  PumpStats ps;
+  const auto t0 = std::chrono::steady_clock::now();
+  rc = pump(m, w, nch, ga, ca, max_pairs, true, &ps);
+  const auto t1 = std::chrono::steady_clock::now();
+  if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }
+  f->seconds = std::chrono::duration<double>(t1 - t0).count();
+  FHIP(hipMemcpy(states.data(), w.states, sizeof(ChainState) * nch, hipMemcpyDeviceToHost));
+  f->grad_evals = 0;
+  for (int c = 0; c < nch; ++c) f->grad_evals += states[c].total_leapfrogs;
+  f->kA_samples = ps.kA_samples;
+  f->kA_ms_mean = ps.kA_samples ? ps.kA_ms_sum / (double)ps.kA_samples : 0.0;
+  f->kA_chain_launches_mean = ps.kA_samples ? ps.chain_launches / (double)ps.kA_samples : 0.0;
+  *out = f;
+  return PPCX_OK;
+}
+
+extern "C" int ppcx_fit_info(const ppcx_fit* f, int* chains, int* n_keep, int* D, int* iter) {
+  if (!f) return fail(PPCX_ERR_ARG, "fit is NULL");
+  if (chains) *chains = f->chains;
+  if (n_keep) *n_keep = f->n_keep;
+  if (D) *D = f->m->d.D;
+  if (iter) *iter = f->iter;
+  return PPCX_OK;
+}
+extern "C" int ppcx_fit_get_draws(ppcx_fit* f, double* out) {
+  if (!f || !out) return fail(PPCX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(f->m->device));
+  if (f->n_keep > 0) HIPCHK(hipMemcpy(out, f->d_draws, sizeof(double) * (size_t)f->chains * f->n_keep * f->m->d.D, hipMemcpyDeviceToHost));
+  return PPCX_OK;
+}
+extern "C" int ppcx_fit_get_columns(ppcx_fit* f, int n_cols, const int32_t* cols, double* out) {
+  if (!f || !cols || !out || n_cols < 1) return fail(PPCX_ERR_ARG, "bad arguments");
+  const int D = f->m->d.D;
+  for (int i = 0; i < n_cols; ++i) if (cols[i] < 0 || cols[i] >= D) return fail(PPCX_ERR_ARG, "column out of range");
+  HIPCHK(hipSetDevice(f->m->device));
+  const long rows = (long)f->chains * f->n_keep;
+  if (rows == 0) return PPCX_OK;
+  int* d_cols = nullptr; double* d_out = nullptr;
+  HIPCHK(hipMalloc(&d_cols, sizeof(int) * n_cols));
+  hipError_t e = hipMalloc(&d_out, sizeof(double) * (size_t)rows * n_cols);
+  if (e != hipSuccess) { (void)hipFree(d_cols); return fail(PPCX_ERR_HIP, hipGetErrorString(e)); }
+  int rc = PPCX_OK;
+  do {
+    if ((e = hipMemcpy(d_cols, cols, sizeof(int) * n_cols, hipMemcpyHostToDevice)) != hipSuccess) break;
+    if ((e = launch_gather_kernel(f->d_draws, rows, D, d_cols, n_cols, d_out, f->m->stream)) != hipSuccess) break;
+    if ((e = hipStreamSynchronize(f->m->stream)) != hipSuccess) break;
+    e = hipMemcpy(out, d_out, sizeof(double) * (size_t)rows * n_cols, hipMemcpyDeviceToHost);
+  } while (0);
+  if (e != hipSuccess) rc = fail(PPCX_ERR_HIP, hipGetErrorString(e));
+  (void)hipFree(d_cols); (void)hipFree(d_out);
+  return rc;
+}
+extern "C" int ppcx_fit_get_diagnostics(ppcx_fit* f, double* lp, double* stepsize, int32_t* treedepth,
+                                        int32_t* n_leapfrog, int32_t* divergent, double* accept) {
+  if (!f) return fail(PPCX_ERR_ARG, "fit is NULL");
+  HIPCHK(hipSetDevice(f->m->device));
+  const size_t ni = (size_t)f->chains * f->iter, nk = (size_t)f->chains * f->n_keep;
+  if (lp && nk) HIPCHK(hipMemcpy(lp, f->d_lp, sizeof(double) * nk, hipMemcpyDeviceToHost));
+  if (stepsize) HIPCHK(hipMemcpy(stepsize, f->d_stepsize, sizeof(double) * ni, hipMemcpyDeviceToHost));
+  if (treedepth) HIPCHK(hipMemcpy(treedepth, f->d_treedepth, sizeof(int) * ni, hipMemcpyDeviceToHost));
+  if (n_leapfrog) HIPCHK(hipMemcpy(n_leapfrog, f->d_nleap, sizeof(int) * ni, hipMemcpyDeviceToHost));
+  if (divergent) HIPCHK(hipMemcpy(divergent, f->d_div, sizeof(int) * ni, hipMemcpyDeviceToHost));
+  if (accept) HIPCHK(hipMemcpy(accept, f->d_accept, sizeof(double) * ni, hipMemcpyDeviceToHost));
+  return PPCX_OK;
+}
+extern "C" int ppcx_fit_get_timing(ppcx_fit* f, double* seconds, long long* grad_evals, double* gene_kernel_ms_mean,
+                                   long long* gene_kernel_samples, double* gene_kernel_chain_launches_mean) {
+  if (!f) return fail(PPCX_ERR_ARG, "fit is NULL");
+  if (seconds) *seconds = f->seconds;
+  if (grad_evals) *grad_evals = f->grad_evals;
+  if (gene_kernel_ms_mean) *gene_kernel_ms_mean = f->kA_ms_mean;
+  if (gene_kernel_samples) *gene_kernel_samples = f->kA_samples;
+  if (gene_kernel_chain_launches_mean) *gene_kernel_chain_launches_mean = f->kA_chain_launches_mean;
+  return PPCX_OK;
+}
+
+extern "C" int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double p_lo, double p_hi,
+                            unsigned long long seed, int n_gen, int resample, double* ci, int32_t* counts_rng) {
+  if (!f || !ci) return fail(PPCX_ERR_ARG, "NULL argument");
+  ppcx_model* m = f->m;
+  const long n_draws = (long)f->chains * f->n_keep;
+  if (n_draws < 1) return fail(PPCX_ERR_ARG, "fit holds no kept draws");
+  if (m->d.K < 1) return PPCX_OK;
+  if (n_gen <= 0) n_gen = (int)n_draws;
+  if (!resample && n_gen > n_draws) return fail(PPCX_ERR_ARG, "n_gen exceeds the kept draws (use resample)");
+  int n_pad = 2; while (n_pad < n_gen) n_pad <<= 1;
+  if (n_pad > 32768) return fail(PPCX_ERR_LIMIT, "more than 32768 predictive draws per cell: use the approximated analysis with fewer draws");
+  if (!(p_lo >= 0.0 && p_hi <= 1.0 && p_lo <= p_hi)) return fail(PPCX_ERR_ARG, "need 0 <= p_lo <= p_hi <= 1");
+  HIPCHK(hipSetDevice(m->device));
+  const int n_cells = m->d.K * m->d.S;
+  double* d_ci = nullptr; int* d_rng = nullptr;
+  HIPCHK(hipMalloc(&d_ci, sizeof(double) * (size_t)n_cells * 4));
+  if (counts_rng) {
+    hipError_t e = hipMalloc(&d_rng, sizeof(int) * (size_t)n_gen * n_cells);
+    if (e != hipSuccess) { (void)hipFree(d_ci); return fail(PPCX_ERR_HIP, hipGetErrorString(e)); }
+  }
+  PpcArgs pa;
+  pa.d = m->d; pa.draws = f->d_draws; pa.n_draws = n_draws; pa.exposure = m->d_expo; pa.X = m->d_X;
+  pa.truncation_compensation = truncation_compensation; pa.p_lo = p_lo; pa.p_hi = p_hi; pa.k0 = seed32(seed);
+  pa.n_gen = n_gen; pa.n_pad = n_pad; pa.resample = resample ? 1 : 0; pa.n_cells = n_cells; pa.ci = d_ci; pa.counts_rng = d_rng;
+  hipError_t e = launch_ppc_kernel(pa, m->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+  if (e == hipSuccess) e = hipMemcpy(ci, d_ci, sizeof(double) * (size_t)n_cells * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && counts_rng) e = hipMemcpy(counts_rng, d_rng, sizeof(int) * (size_t)n_gen * n_cells, hipMemcpyDeviceToHost);
+  (void)hipFree(d_ci); (void)hipFree(d_rng);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, hipGetErrorString(e));
+  return PPCX_OK;
+}
+
+extern "C" void ppcx_do_inference_C(const int* dims, const int* counts, const double* X, const double* exposure,
+                                    const int* excl, const double* reals, double* ci, double* slope, int* status) {
+  if (!status) return;
+  if (!dims || !reals) { *status = PPCX_ERR_ARG; return; }
+  const int device = dims[0], G = dims[1], S = dims[2], C = dims[3], K = dims[4], n_excl = dims[5];
+  ppcx_model* m = nullptr; ppcx_fit* f = nullptr;
+  int rc = ppcx_model_create(device, G, S, C, K, counts, X, exposure, reals[0], n_excl, excl, &m);
+  if (rc == PPCX_OK) {
+    ppcx_nuts_config cfg; ppcx_nuts_config_default(&cfg);
+    cfg.chains = dims[6]; cfg.iter = dims[7]; cfg.warmup = dims[8]; cfg.seed = (unsigned long long)reals[4];
+    rc = ppcx_fit_nuts(m, &cfg, &f);
+  }
+  if (rc == PPCX_OK) rc = ppcx_fit_ppc(f, reals[1], reals[2], reals[3], (unsigned long long)reals[4], dims[9], dims[10], ci, nullptr);
+  if (rc == PPCX_OK && slope && K > 0) {
+    std::vector<int32_t> cols(K);
+    for (int k = 0; k < K; ++k) cols[k] = m->d.off_alpha1 + k;
+    int chains, n_keep; ppcx_fit_info(f, &chains, &n_keep, nullptr, nullptr);
+    std::vector<double> a((size_t)chains * n_keep * K);
+    rc = ppcx_fit_get_columns(f, K, cols.data(), a.data());
+    if (rc == PPCX_OK) for (int k = 0; k < K; ++k) {
+      double s = 0; for (long r = 0; r < (long)chains * n_keep; ++r) s += a[(size_t)r * K + k];
+      slope[k] = s / ((double)chains * n_keep);
+    }
+  }
+  ppcx_fit_free(f); ppcx_model_destroy(m);
+  *status = rc;
+}

@@ -1,0 +1,174 @@
+// ppcx_gene.h -- the per-gene body of kernel A, split into the three phases between which the
+// wavefront combines partial sums:  gene_begin  ->  gene_cells (per lane)  ->  [L-lane butterfly]
+// ->  gene_end  ->  tree bookkeeping (coord_merge_dots / coord_store_slot / coord_top_dots).
+// Shared by the gfx950 kernel (ppcx_kernels.hip) and the CPU emulation harness in tests/emul.
+#pragma once
+#include "ppcx_nuts.h"
+
+namespace ppcx {
+
+template <int CM>
+struct GeneCtx {
+  static constexpr int NCM = CM + 1;          // coordinates a gene can own: intercept, sigma_raw, CM-1 slopes
+  int gg, ncoord;
+  bool active, writer, has_slopes, fast;
+  int idx[NCM];
+  double minv[NCM], ph[NCM], qn[NCM];
+  GeneParams<CM> gp;
+  double T0;
+};
+
+// pre-operations, half kick + drift of the gene's coordinates, per-gene constants
+template <int CM>
+PPCX_HD void gene_begin(const Dims& d, const Cmd& c, const VecRef& v, int g, bool lane_is_writer, double* draws,
+                        GeneCtx<CM>& x) {
+  constexpr int NCM = CM + 1;
+  x.active = g < d.G;
+  x.writer = x.active && lane_is_writer;
+  x.gg = x.active ? g : 0;
+  const int C = d.C;
+  const int nslope = x.gg < d.K ? (C - 1 > 1 ? C - 1 : 1) : 0;   // alpha_sub_1 exists even for C == 1 (.stan:189)
+  x.ncoord = x.active ? 2 + nslope : 0;
+  x.T0 = 0.0;
+  const double eps = c.eps;
+#pragma unroll
+  for (int j = 0; j < NCM; ++j) {
+    x.idx[j] = j == 0 ? d.off_intercept + x.gg : (j == 1 ? d.off_sigma_raw + x.gg : coef_index(d, j - 1, x.gg));
+    CoordVals cv{0.0, 0.0, 0.0, 1.0};
+    if (j < x.ncoord) cv = coord_pre(c, v, x.idx[j], x.idx[j], x.writer, draws, d.D, c.k0, c.k1, &x.T0);
+    x.minv[j] = cv.minv;
+    x.ph[j] = cv.p + 0.5 * eps * cv.g;         // half kick
+    x.qn[j] = cv.q + eps * cv.minv * x.ph[j];  // drift
+  }
+  x.has_slopes = x.active && x.gg < d.K && C >= 2;
+  x.fast = d.x0_is_one && !x.has_slopes;
+  x.gp.coef[0] = x.qn[0];
+#pragma unroll
+  for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < C) ? x.qn[cc + 1] : 0.0;
+  x.gp.sigma_raw = x.qn[1];
+  x.gp.phi = exp(-x.gp.sigma_raw);             // sigma = 1 ./ exp(sigma_raw)   (.stan:203)
+  lgamma_digamma(x.gp.phi, &x.gp.lgphi, &x.gp.dgphi);
+  x.gp.A = exp(x.gp.coef[0] + x.gp.sigma_raw);
+}
+
+// the cells s = sub, sub+L, ... of the gene's row of counts
+template <int CM>
+PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, const double* sE, const double* sExpo,
+                        const double* sX, int sub, int L, CellAcc<CM>& acc) {
+  const int S = d.S, C = d.C;
+  const GeneParams<CM>& gp = x.gp;
+  if (x.fast) {
+    for (int s = sub; s < S; s += L) {
+      const int y = x.active ? row[s] : -1;
+      if (y >= 0) {
+        double xsig;
+        cell_core(y, sE[s] * gp.A, gp.phi, gp.lgphi, gp.dgphi, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
+        acc.T2u += xsig;
+      }
+    }
+  } else {
+    for (int s = sub; s < S; s += L) {
+      const int y = x.active ? row[s] : -1;
+      if (y >= 0) {
+        double t = sExpo[s] + gp.sigma_raw;
+#pragma unroll
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) t += sX[cc * S + s] * gp.coef[cc];
+        double xsig;
+        cell_core(y, exp(t), gp.phi, gp.lgphi, gp.dgphi, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
+        acc.T2u += xsig;
+#pragma unroll
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.T2x[cc] += sX[cc * S + s] * xsig;
+      }
+    }
+  }
+}
+
+// close the gene with the reduced sums: gradient, second half kick, stores, partial sums part[0..9]
+template <int CM>
+PPCX_HD void gene_end(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, CellAcc<CM>& acc,
+                      const double* Sy, const double* SyE, const double* SyXg, const double* ncell,
+                      double* part, double* pn) {
+  constexpr int NCM = CM + 1;
+  if (x.fast) acc.T2x[0] = acc.T2u;
+  double SyX[CM];
+#pragma unroll
+  for (int cc = 0; cc < CM; ++cc) SyX[cc] = (cc < d.C) ? SyXg[(long)cc * d.G + x.gg] : 0.0;
+  GeneOut<CM> go;
+  gene_close<CM>(d, c.hy, x.gg, x.has_slopes, x.gp, acc, Sy[x.gg], SyE[x.gg], SyX, ncell[x.gg], &go);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) part[k] = 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NCM; ++j) {
+    const double gnew = j == 0 ? go.g_coef[0] : (j == 1 ? go.g_sigma_raw : go.g_coef[j >= 2 ? j - 1 : 0]);
+    pn[j] = x.ph[j] + 0.5 * c.eps * gnew;      // half kick
+    if (j < x.ncoord && x.writer) {
+      v.at(V_Q0 + 3 * c.dir, x.idx[j]) = x.qn[j];
+      v.at(V_P0 + 3 * c.dir, x.idx[j]) = pn[j];
+      v.at(V_G0 + 3 * c.dir, x.idx[j]) = gnew;
+      part[PT_T1] += pn[j] * pn[j] * x.minv[j];
+      bad = bad || !isfinite(gnew);
+    }
+  }
+  if (x.writer) {
+    part[PT_LP] = go.lp;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) part[PT_H0 + k] = go.h[k];
+    part[PT_T0] = x.T0;
+    part[PT_NONFINITE] = bad ? 1.0 : 0.0;
+  }
+}
+
+// Kernel B, serial part (one thread per chain): finish the hyper coordinates of the executed command,
+// advance the state machine, run the hyper pre-operations + half kick + drift of the next command.
+// `red` are the block partials reduced in a fixed order; `hv` the chain's hyper-coordinate vectors.
+struct ChainIO {
+  double* draws;                 // this chain's [n_keep][D] or null
+  ChainOut out;
+};
+PPCX_HD void chain_step(const Dims& d, ChainState& st, const Cmd& ex, const double* red, bool have_parts,
+                        const VecRef& hv, const ChainIO& io, Cmd& nc) {
+  Reduced rd;
+  double lp = 0.0; bool finite = true;
+  if (have_parts && ex.type != CMD_FLUSH) {
+    rd.lp_genes = red[PT_LP];
+    for (int k = 0; k < 6; ++k) rd.hsum[k] = red[PT_H0 + k];
+    rd.T0 = red[PT_T0] + st.T0h; rd.T1 = red[PT_T1]; rd.nonfinite = red[PT_NONFINITE];
+    for (int l = 0; l < kLev; ++l) for (int k = 0; k < 6; ++k) rd.dots[l][k] = red[PT_DOTS + 6 * l + k];
+    for (int k = 0; k < 6; ++k) rd.top[k] = red[PT_TOP + k];
+    double g6[6];
+    lp = hyper_close(d, ex.hy, ex.hyp_q, rd.lp_genes, rd.hsum, g6);
+    finite = rd.nonfinite == 0.0;
+    for (int k = 0; k < 6; ++k) {              // second half kick of the hyper coordinates + tree terms
+      finite = finite && isfinite(g6[k]);
+      const double minv = hv.at(V_MINV, k);
+      const double pn = hv.at(V_P0 + 3 * ex.dir, k) + 0.5 * ex.eps * g6[k];
+      hv.at(V_P0 + 3 * ex.dir, k) = pn; hv.at(V_G0 + 3 * ex.dir, k) = g6[k];
+      rd.T1 += pn * pn * minv;
+      if (ex.type == CMD_LEAF) {
+        NodeVals nv{pn, pn};
+        for (int l = 0; l < ex.n_merge; ++l) coord_merge_dots(hv, k, l, pn, minv, &nv, rd.dots[l]);
+        if (!ex.subtree_complete) coord_store_slot(hv, k, ex.n_merge, pn, nv);
+        else coord_top_dots(hv, k, ex.dir, pn, minv, nv, rd.top);
+      }
+    }
+  }
+  chain_advance(st, ex, rd, lp, finite, io.out, nc);
+  nc.k0 = st.k0; nc.k1 = st.k1;
+  if (nc.type != CMD_DONE) {
+    double T0h = 0.0;
+    for (int k = 0; k < 6; ++k) {
+      const CoordVals cv = coord_pre(nc, hv, k, hyper_index(d, k), true, io.draws, d.D, st.k0, st.k1, &T0h);
+      if (nc.type != CMD_FLUSH) {
+        const double ph = cv.p + 0.5 * nc.eps * cv.g;
+        const double qn = cv.q + nc.eps * cv.minv * ph;
+        hv.at(V_Q0 + 3 * nc.dir, k) = qn; hv.at(V_P0 + 3 * nc.dir, k) = ph;
+        nc.hyp_q[k] = qn;
+      }
+    }
+    st.T0h = T0h;
+    nc.hy = make_hyper(nc.hyp_q, d.lambda_mu_mu);
+  }
+}
+
+}  // namespace ppcx

@@ -1,0 +1,57 @@
+// ppcx_kernels.h -- argument blocks and launchers of the gfx950 kernels (ppcx_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ppcx_nuts.h"
+
+namespace ppcx {
+
+struct GeneArgs {
+  Dims d;
+  const int* counts;            // G x S gene-major, excluded cells = -1
+  const double* sampleE;        // exp(exposure_s)
+  const double* exposure;       // S
+  const double* X;              // S x C column-major
+  const double* Sy;             // per-gene sufficient statistics over non-excluded cells
+  const double* SyE;
+  const double* SyX;            // [C][G]
+  const double* ncell;
+  double* vecs;                 // [chains][V_COUNT][Dpad]
+  long Dpad;
+  const Cmd* cmds;              // [chains]
+  double* partials;             // [chains][nblocks][PT_COUNT]
+  double* draws;                // [chains][n_keep][D] or null
+  long draws_chain_stride;
+};
+
+struct ChainArgs {
+  Dims d;
+  ChainState* states;
+  Cmd* cmds;
+  const double* partials;
+  int nblocks;
+  double* hyper_vecs;           // [chains][V_COUNT][8]
+  double* draws; long draws_chain_stride;
+  int n_keep, iter;
+  double* out_lp; double* out_stepsize; int* out_treedepth; int* out_n_leapfrog; int* out_divergent; double* out_accept;
+  int* done;                    // [chains]
+};
+
+struct PpcArgs {
+  Dims d;
+  const double* draws;          // [n_draws][D]
+  long n_draws;
+  const double* exposure; const double* X;
+  double truncation_compensation, p_lo, p_hi;
+  uint32_t k0;
+  int n_gen, n_pad, resample, n_cells;
+  double* ci;                   // [K*S][4] mean, sd, lower, upper
+  int* counts_rng;              // [n_gen][K*S] or null
+};
+
+hipError_t launch_gene_kernel(int L, int CM, const GeneArgs& a, int nblocks, int nchains, hipStream_t st);
+hipError_t launch_chain_kernel(const ChainArgs& a, int nchains, hipStream_t st);
+hipError_t launch_ppc_kernel(const PpcArgs& a, hipStream_t st);
+hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st);
+hipError_t launch_fill_kernel(double* p, long n, double val, hipStream_t st);
+
+}  // namespace ppcx

@@ -1,0 +1,208 @@
+// ppcx_math.h -- scalar building blocks of the MI355X NB hierarchical engine.
+//
+// Everything here is `__host__ __device__` so the *same* arithmetic is compiled into the gfx950
+// kernels (ppcx_kernels.hip) and into the CPU emulation harness that tests/ uses to check the host
+// logic without a GPU (tests/emul). Nothing here comes from the reference: Stan Math (third party,
+// not vendored) is where the reference's arithmetic lives; the formulas below are written from the
+// published definitions cited at each function.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PPCX_HD __host__ __device__ __forceinline__
+#else
+#define PPCX_HD inline
+#endif
+
+namespace ppcx {
+
+// ---------------------------------------------------------------------------------------------
+// log-gamma and digamma for x > 0 with ONE shared logarithm and ONE reciprocal.
+//   x >= 8 : Stirling series  lgamma(x) = (x-1/2)ln x - x + ln(2pi)/2 + sum B2k/(2k(2k-1)x^(2k-1))
+//            digamma(x) = ln x - 1/(2x) - sum B2k/(2k x^2k)          (Abramowitz & Stegun 6.1.40, 6.3.18)
+//   x <  8 : shift by 8 with the recurrences lgamma(x) = lgamma(x+8) - ln prod_{k<8}(x+k),
+//            digamma(x) = digamma(x+8) - P'(x)/P(x).
+// Truncation error of the 7-term tails at x = 8 is < 2e-15 (next Bernoulli term).
+// ---------------------------------------------------------------------------------------------
+PPCX_HD void lgamma_digamma_stirling(double x, double lx, double rx, double* lg, double* dg) {
+  const double r2 = rx * rx;
+  // lgamma tail: rx * (1/12 - r2*(1/360 - r2*(1/1260 - r2*(1/1680 - r2*(1/1188 - r2*(691/360360 - r2/156))))))
+  double t = 691.0 / 360360.0 - r2 * (1.0 / 156.0);
+  t = 1.0 / 1188.0 - r2 * t;
+  t = 1.0 / 1680.0 - r2 * t;
+  t = 1.0 / 1260.0 - r2 * t;
+  t = 1.0 / 360.0 - r2 * t;
+  t = 1.0 / 12.0 - r2 * t;
+  *lg = (x - 0.5) * lx - x + 0.91893853320467274178 + rx * t;
+  // digamma tail: r2 * (1/12 - r2*(1/120 - r2*(1/252 - r2*(1/240 - r2*(1/132 - r2*(691/32760 - r2/12))))))
+  double d = 691.0 / 32760.0 - r2 * (1.0 / 12.0);
+  d = 1.0 / 132.0 - r2 * d;
+  d = 1.0 / 240.0 - r2 * d;
+  d = 1.0 / 252.0 - r2 * d;
+  d = 1.0 / 120.0 - r2 * d;
+  d = 1.0 / 12.0 - r2 * d;
+  *dg = lx - 0.5 * rx - r2 * d;
+}
+
+PPCX_HD void lgamma_digamma(double x, double* lg, double* dg) {
+  if (x >= 8.0) {
+    lgamma_digamma_stirling(x, log(x), 1.0 / x, lg, dg);
+  } else {
+    // P = prod_{k=0..7}(x+k), P' by the product rule, both in one pass
+    double P = x, dP = 1.0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const double f = x + (double)k;
+      dP = dP * f + P;
+      P = P * f;
+    }
+    const double xs = x + 8.0;
+    double l8, d8;
+    lgamma_digamma_stirling(xs, log(xs), 1.0 / xs, &l8, &d8);
+    *lg = l8 - log(P);
+    *dg = d8 - dP / P;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// log erfc(x) and  R(x) = exp(-x^2)/erfc(x)  (the inverse Mills-type ratio the skew-normal
+// gradient needs). For x > 25 erfc underflows, so the asymptotic expansion
+// erfc(x) ~ exp(-x^2)/(x sqrt(pi)) * (1 - 1/(2x^2) + 3/(4x^4) - 15/(8x^6) + 105/(16x^8)) is used.
+// ---------------------------------------------------------------------------------------------
+PPCX_HD void log_erfc_and_ratio(double x, double* log_erfc, double* ratio) {
+  if (x < 25.0) {
+    const double e = erfc(x);
+    *log_erfc = log(e);
+    *ratio = exp(-x * x) / e;
+  } else {
+    const double i2 = 1.0 / (x * x);
+    const double s = 1.0 + i2 * (-0.5 + i2 * (0.75 + i2 * (-1.875 + i2 * 6.5625)));
+    const double xs = x * 1.77245385090551602730;  // x sqrt(pi)
+    *log_erfc = -x * x - log(xs) + log(s);
+    *ratio = xs / s;
+  }
+}
+
+PPCX_HD double log_sum_exp(double a, double b) {
+  if (a == -INFINITY) return b;
+  if (b == -INFINITY) return a;
+  const double m = a > b ? a : b;
+  return m + log1p(exp(-fabs(a - b)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11).
+// Counter-based, so every coordinate / cell / draw addresses its own stream without state.
+// Stream addressing is documented in DESIGN.md ("RNG").
+// ---------------------------------------------------------------------------------------------
+struct u4 { uint32_t x, y, z, w; };
+
+PPCX_HD u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return u4{c0, c1, c2, c3};
+}
+// 53 random bits -> (0,1), never 0 or 1
+PPCX_HD double u01(uint32_t a, uint32_t b) {
+  const uint64_t v = (((uint64_t)a << 32) | b) >> 11;
+  return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+PPCX_HD uint32_t seed32(uint64_t s) { return (uint32_t)s ^ (uint32_t)((s >> 32) * 0x9E3779B9u); }
+
+// standard normal for coordinate i: Box-Muller on block (i>>1); cosine branch for even i
+PPCX_HD double coord_normal(uint32_t i, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  const u4 r = philox4x32_10(i >> 1, c1, c2, c3, k0, k1);
+  const double u1 = u01(r.x, r.y), u2 = u01(r.z, r.w);
+  const double rad = sqrt(-2.0 * log(u1)), t = 6.283185307179586476925 * u2;
+  return (i & 1u) ? rad * sin(t) : rad * cos(t);
+}
+PPCX_HD double coord_uniform(uint32_t i, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  const u4 r = philox4x32_10(i, c1, c2, c3, k0, k1);
+  return u01(r.x, r.y);
+}
+
+// sequential stream over a fixed (key, c1, c2, c3): c0 is the block index. 2 uniforms per block.
+struct Stream {
+  uint32_t k0, k1, c1, c2, c3, blk;
+  int have; double b0, b1;
+  int have_n; double spare;
+  PPCX_HD void init(uint32_t k0_, uint32_t k1_, uint32_t c1_, uint32_t c2_, uint32_t c3_) {
+    k0 = k0_; k1 = k1_; c1 = c1_; c2 = c2_; c3 = c3_; blk = 0; have = 0; have_n = 0; b0 = b1 = spare = 0.0;
+  }
+  PPCX_HD double uniform() {
+    if (have == 0) {
+      const u4 r = philox4x32_10(blk++, c1, c2, c3, k0, k1);
+      b1 = u01(r.x, r.y); b0 = u01(r.z, r.w); have = 2;
+    }
+    --have;
+    return have == 1 ? b1 : b0;
+  }
+  PPCX_HD double normal() {
+    if (have_n) { have_n = 0; return spare; }
+    const double u1 = uniform(), u2 = uniform();
+    const double rad = sqrt(-2.0 * log(u1)), t = 6.283185307179586476925 * u2;
+    spare = rad * sin(t); have_n = 1;
+    return rad * cos(t);
+  }
+};
+
+// Gamma(shape a, scale 1): Marsaglia & Tsang, "A simple method for generating gamma variables" (2000)
+PPCX_HD double gamma_rng(double a, Stream& st) {
+  double boost = 1.0;
+  if (a < 1.0) { boost = pow(st.uniform(), 1.0 / a); a += 1.0; }
+  const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+  for (int it = 0; it < 4096; ++it) {          // bounded: every wave must be able to leave the loop
+    const double x = st.normal();
+    double v = 1.0 + c * x;
+    if (v <= 0.0) continue;
+    v = v * v * v;
+    const double u = st.uniform();
+    const double x2 = x * x;
+    if (u < 1.0 - 0.0331 * x2 * x2) return d * v * boost;
+    if (log(u) < 0.5 * x2 + d * (1.0 - v + log(v))) return d * v * boost;
+  }
+  return d * boost;                            // unreachable for finite a > 0 (acceptance > 95 %)
+}
+// Poisson(lam): Knuth multiplication below 10, Hoermann's PTRS (1993) above
+PPCX_HD long long poisson_rng(double lam, Stream& st) {
+  if (lam < 10.0) {
+    const double L = exp(-lam);
+    double p = st.uniform();
+    long long k = 0;
+    while (p > L && k < 4096) { ++k; p *= st.uniform(); }
+    return k;
+  }
+  const double slam = sqrt(lam), loglam = log(lam);
+  const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+  const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+  for (int it = 0; it < 4096; ++it) {
+    const double U = st.uniform() - 0.5, V = st.uniform();
+    const double us = 0.5 - fabs(U);
+    const double kf = floor((2.0 * a / us + b) * U + lam + 0.43);
+    if (us >= 0.07 && V <= vr) return (long long)kf;
+    if (kf < 0 || (us < 0.013 && V > us)) continue;
+    if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + kf * loglam - lgamma(kf + 1.0)) return (long long)kf;
+  }
+  return (long long)lam;                       // unreachable for finite lam (acceptance > 85 %)
+}
+// neg_binomial_2_log_rng(eta, phi) as a gamma-Poisson mixture (inst/stan/negBinomial_MPI.stan:264);
+// stream = (seed, 'PPC1') x (cell, draw). Stan raises above 2^30; we saturate.
+PPCX_HD int32_t nb2_log_rng(double eta, double phi, uint32_t k0, uint32_t cell, uint32_t draw) {
+  if (!(phi > 0.0) || !isfinite(phi) || !isfinite(eta)) return 2147483647;   // invalid draw: sorts last
+  Stream st; st.init(k0, 0x50504331u, cell, draw, 4u);
+  const double lam = gamma_rng(phi, st) * (exp(eta) / phi);
+  if (!(lam < 1073741824.0)) return 1073741823;
+  const long long k = poisson_rng(lam, st);
+  return k > 2147483647LL ? 2147483647 : (int32_t)k;
+}
+
+}  // namespace ppcx

@@ -1,0 +1,135 @@
+// CPU emulation harness (TEST INFRASTRUCTURE): drives the SAME __host__ __device__ source that the
+// gfx950 kernels are built from (ppcseq_amd/csrc/ppcx_{math,model,nuts,gene}.h) with plain loops in
+// place of wavefront lanes, so the host logic -- command protocol, iterative NUTS tree, adaptation --
+// can be checked against the oracle without a GPU. It is never loaded by the product package.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../ppcseq_amd/csrc/ppcx_gene.h"
+
+using namespace ppcx;
+
+struct EmulModel {
+  Dims d; int CM;
+  std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, ncell;
+};
+
+static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, const double* X, const double* expo,
+                            double lmm, int n_excl, const int32_t* excl) {
+  EmulModel m; m.d = make_dims(G, S, C, K, lmm); m.CM = C <= 2 ? 2 : (C <= 4 ? 4 : 8);
+  m.counts.assign(counts, counts + (size_t)G * S);
+  for (int e = 0; e < n_excl; ++e) m.counts[excl[e]] = -1;
+  m.X.assign(X, X + (size_t)S * C); m.expo.assign(expo, expo + S); m.E.resize(S);
+  int x0 = 1;
+  for (int s = 0; s < S; ++s) { m.E[s] = exp(expo[s]); if (X[s] != 1.0) x0 = 0; }
+  m.d.x0_is_one = x0;
+  m.Sy.assign(G, 0); m.SyE.assign(G, 0); m.SyX.assign((size_t)C * G, 0); m.ncell.assign(G, 0);
+  double lg1 = 0;
+  for (int g = 0; g < G; ++g) for (int s = 0; s < S; ++s) {
+    int y = m.counts[(size_t)g * S + s]; if (y < 0) continue;
+    m.Sy[g] += y; m.SyE[g] += (double)y * expo[s]; m.ncell[g] += 1; lg1 += lgamma((double)y + 1.0);
+    for (int c = 0; c < C; ++c) m.SyX[(size_t)c * G + g] += (double)y * X[(size_t)c * S + s];
+  }
+  m.d.lgamma_y1_total = lg1;
+  return m;
+}
+
+template <int CM>
+static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double* draws, double* red) {
+  constexpr int NCM = CM + 1;
+  const Dims& d = m.d;
+  for (int k = 0; k < PT_COUNT; ++k) red[k] = 0.0;
+  if (c.type == CMD_DONE) return;
+  for (int g = 0; g < d.G; ++g) {
+    GeneCtx<CM> x;
+    gene_begin<CM>(d, c, v, g, true, draws, x);
+    if (c.type == CMD_FLUSH) continue;
+    CellAcc<CM> acc; acc.zero();
+    gene_cells<CM>(d, x, m.counts.data() + (size_t)g * d.S, m.E.data(), m.expo.data(), m.X.data(), 0, 1, acc);
+    double pn[NCM], part[10];
+    gene_end<CM>(d, c, v, x, acc, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.ncell.data(), part, pn);
+    for (int k = 0; k < 10; ++k) red[k] += part[k];
+    if (c.type == CMD_LEAF) {
+      NodeVals nv[NCM];
+      for (int j = 0; j < NCM; ++j) nv[j] = NodeVals{pn[j], pn[j]};
+      for (int lev = 0; lev < c.n_merge; ++lev)
+        for (int j = 0; j < x.ncoord; ++j) coord_merge_dots(v, x.idx[j], lev, pn[j], x.minv[j], &nv[j], red + PT_DOTS + 6 * lev);
+      if (!c.subtree_complete) { for (int j = 0; j < x.ncoord; ++j) coord_store_slot(v, x.idx[j], c.n_merge, pn[j], nv[j]); }
+      else for (int j = 0; j < x.ncoord; ++j) coord_top_dots(v, x.idx[j], c.dir, pn[j], x.minv[j], nv[j], red + PT_TOP);
+    }
+  }
+}
+static void gene_pass_dispatch(const EmulModel& m, const Cmd& c, const VecRef& v, double* draws, double* red) {
+  if (m.CM == 2) gene_pass<2>(m, c, v, draws, red);
+  else if (m.CM == 4) gene_pass<4>(m, c, v, draws, red);
+  else gene_pass<8>(m, c, v, draws, red);
+}
+
+struct EmulCfg { int chains, iter, warmup; unsigned long long seed; double adapt_delta; int max_treedepth;
+                 double init_radius, stepsize0; int init_buffer, term_buffer, window, chain_id_offset; };
+
+extern "C" __attribute__((visibility("default")))
+int emul_log_prob_grad(int G, int S, int C, int K, const int32_t* counts, const double* X, const double* expo,
+                       double lmm, int n_excl, const int32_t* excl, const double* u, double* lp, double* grad) {
+  EmulModel m = make_model(G, S, C, K, counts, X, expo, lmm, n_excl, excl);
+  const int D = m.d.D;
+  std::vector<double> vecs((size_t)V_COUNT * D, 0.0), hv((size_t)V_COUNT * 8, 0.0), red(PT_COUNT, 0.0);
+  for (int i = 0; i < D; ++i) { vecs[(size_t)V_Q1 * D + i] = u[i]; vecs[(size_t)V_MINV * D + i] = 1.0; }
+  for (int k = 0; k < 6; ++k) { hv[V_Q1 * 8 + k] = u[hyper_index(m.d, k)]; hv[V_MINV * 8 + k] = 1.0; }
+  NutsConfig nc; memset(&nc, 0, sizeof nc); nc.chains = 1; nc.max_treedepth = 10; nc.adapt_delta = 0.8; nc.init_radius = 2; nc.stepsize0 = 1;
+  ChainState st; state_init(st, nc, 0, 1);
+  Cmd c, n; cmd_clear(c);
+  ChainIO io; memset(&io, 0, sizeof io);
+  VecRef v{vecs.data(), D}, h{hv.data(), 8};
+  chain_step(m.d, st, c, red.data(), false, h, io, n); c = n;
+  while (c.type != CMD_DONE) {
+    gene_pass_dispatch(m, c, v, nullptr, red.data());
+    chain_step(m.d, st, c, red.data(), true, h, io, n); c = n;
+  }
+  *lp = st.lp_eval;
+  for (int i = 0; i < D; ++i) grad[i] = vecs[(size_t)V_G1 * D + i];
+  for (int k = 0; k < 6; ++k) grad[hyper_index(m.d, k)] = hv[V_G1 * 8 + k];
+  return 0;
+}
+
+// draws [chains][n_keep][D]; lp [chains][n_keep]; diagnostics [chains][iter]
+extern "C" __attribute__((visibility("default")))
+int emul_fit_nuts(int G, int S, int C, int K, const int32_t* counts, const double* X, const double* expo, double lmm,
+                  int n_excl, const int32_t* excl, const EmulCfg* cfg, double* draws, double* lp, double* stepsize,
+                  int* treedepth, int* n_leapfrog, int* divergent, double* accept) {
+  EmulModel m = make_model(G, S, C, K, counts, X, expo, lmm, n_excl, excl);
+  const int D = m.d.D, nk = cfg->iter - cfg->warmup;
+  NutsConfig nc; nc.chains = cfg->chains; nc.iter = cfg->iter; nc.warmup = cfg->warmup; nc.seed = cfg->seed;
+  nc.adapt_delta = cfg->adapt_delta; nc.max_treedepth = cfg->max_treedepth; nc.init_radius = cfg->init_radius;
+  nc.stepsize0 = cfg->stepsize0; nc.init_buffer = cfg->init_buffer; nc.term_buffer = cfg->term_buffer;
+  nc.window = cfg->window; nc.chain_id_offset = cfg->chain_id_offset;
+  int rc = 0;
+  for (int ch = 0; ch < cfg->chains; ++ch) {
+    std::vector<double> vecs((size_t)V_COUNT * D, 0.0), hv((size_t)V_COUNT * 8, 0.0), red(PT_COUNT, 0.0);
+    for (int i = 0; i < D; ++i) vecs[(size_t)V_MINV * D + i] = 1.0;
+    for (int k = 0; k < 8; ++k) hv[V_MINV * 8 + k] = 1.0;
+    ChainState st; state_init(st, nc, ch, 0);
+    Cmd c, n; cmd_clear(c);
+    ChainIO io;
+    io.draws = draws + (size_t)ch * nk * D;
+    io.out.lp = lp + (size_t)ch * nk; io.out.stepsize = stepsize + (size_t)ch * cfg->iter;
+    io.out.treedepth = treedepth + (size_t)ch * cfg->iter; io.out.n_leapfrog = n_leapfrog + (size_t)ch * cfg->iter;
+    io.out.divergent = divergent + (size_t)ch * cfg->iter; io.out.accept = accept + (size_t)ch * cfg->iter;
+    VecRef v{vecs.data(), D}, h{hv.data(), 8};
+    chain_step(m.d, st, c, red.data(), false, h, io, n); c = n;
+    long guard = 0;
+    while (c.type != CMD_DONE) {
+      gene_pass_dispatch(m, c, v, io.draws, red.data());
+      chain_step(m.d, st, c, red.data(), true, h, io, n); c = n;
+      if (++guard > 50000000L) { rc = -5; break; }
+    }
+    if (st.error) rc = -3;
+  }
+  return rc;
+}
+
+extern "C" __attribute__((visibility("default")))
+int emul_nb2_log_rng(double eta, double phi, unsigned long long seed, unsigned cell, unsigned draw) {
+  return nb2_log_rng(eta, phi, seed32(seed), cell, draw);
+}
