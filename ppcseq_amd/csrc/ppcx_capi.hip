@@ -30,7 +30,7 @@ struct ppcx_model {
   std::vector<int32_t> counts_host;            // original counts (exclusions are re-applied on a copy)
   std::vector<double> X_host, expo_host;
   int* d_counts = nullptr;
-  double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_ncell = nullptr;
+  double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_ncell = nullptr, *d_Lg1 = nullptr;
   hipStream_t stream = nullptr;
 };
 
@@ -81,24 +81,23 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
     if (excl[e] < 0 || excl[e] >= G * S) return fail(PPCX_ERR_ARG, "excluded cell id out of range");
     cnt[excl[e]] = -1;
   }
-  std::vector<double> Sy(G, 0.0), SyE(G, 0.0), SyX((size_t)C * G, 0.0), ncell(G, 0.0);
-  double lg1 = 0.0;
+  std::vector<double> Sy(G, 0.0), SyE(G, 0.0), SyX((size_t)C * G, 0.0), ncell(G, 0.0), Lg1(G, 0.0);
   for (int g = 0; g < G; ++g) {
-    double sy = 0, sye = 0, nc = 0;
+    double sy = 0, sye = 0, nc = 0, lg1 = 0;
     for (int s = 0; s < S; ++s) {
       const int y = cnt[(size_t)g * S + s];
       if (y < 0) continue;
       sy += y; sye += (double)y * m->expo_host[s]; nc += 1.0; lg1 += lgamma((double)y + 1.0);
       for (int c = 0; c < C; ++c) SyX[(size_t)c * G + g] += (double)y * m->X_host[(size_t)c * S + s];
     }
-    Sy[g] = sy; SyE[g] = sye; ncell[g] = nc;
+    Sy[g] = sy; SyE[g] = sye; ncell[g] = nc; Lg1[g] = lg1;
   }
-  m->d.lgamma_y1_total = lg1;
   HIPCHK(hipMemcpy(m->d_counts, cnt.data(), sizeof(int32_t) * cnt.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_Sy, Sy.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_SyE, SyE.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_SyX, SyX.data(), sizeof(double) * SyX.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_ncell, ncell.data(), sizeof(double) * G, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->d_Lg1, Lg1.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   return PPCX_OK;
 }
 
@@ -140,6 +139,7 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   MHIP(hipMalloc(&m->d_SyE, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_SyX, sizeof(double) * (size_t)C * G));
   MHIP(hipMalloc(&m->d_ncell, sizeof(double) * G));
+  MHIP(hipMalloc(&m->d_Lg1, sizeof(double) * G));
   MHIP(hipMemcpy(m->d_E, E.data(), sizeof(double) * S, hipMemcpyHostToDevice));
   MHIP(hipMemcpy(m->d_expo, exposure, sizeof(double) * S, hipMemcpyHostToDevice));
   MHIP(hipMemcpy(m->d_X, X, sizeof(double) * (size_t)S * C, hipMemcpyHostToDevice));
@@ -173,7 +173,7 @@ extern "C" void ppcx_model_destroy(ppcx_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipFree(m->d_counts); (void)hipFree(m->d_E); (void)hipFree(m->d_expo); (void)hipFree(m->d_X);
-  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_ncell);
+  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_Lg1);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -265,7 +265,7 @@ static int pump(ppcx_model* m, Work& w, int nchains, const GeneArgs& ga, const C
 static GeneArgs gene_args(ppcx_model* m, Work& w, double* draws, long draws_stride) {
   GeneArgs ga;
   ga.d = m->d; ga.counts = m->d_counts; ga.sampleE = m->d_E; ga.exposure = m->d_expo; ga.X = m->d_X;
-  ga.Sy = m->d_Sy; ga.SyE = m->d_SyE; ga.SyX = m->d_SyX; ga.ncell = m->d_ncell;
+  ga.Sy = m->d_Sy; ga.SyE = m->d_SyE; ga.SyX = m->d_SyX; ga.ncell = m->d_ncell; ga.Lg1 = m->d_Lg1;
   ga.vecs = w.vecs; ga.Dpad = w.Dpad; ga.cmds = w.cmds; ga.partials = w.partials;
   ga.draws = draws; ga.draws_chain_stride = draws_stride;
   return ga;

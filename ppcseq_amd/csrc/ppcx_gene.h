@@ -87,14 +87,14 @@ PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, con
 template <int CM>
 PPCX_HD void gene_end(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, CellAcc<CM>& acc,
                       const double* Sy, const double* SyE, const double* SyXg, const double* ncell,
-                      double* part, double* pn) {
+                      const double* Lg1, double* part, double* pn) {
   constexpr int NCM = CM + 1;
   if (x.fast) acc.T2x[0] = acc.T2u;
   double SyX[CM];
 #pragma unroll
   for (int cc = 0; cc < CM; ++cc) SyX[cc] = (cc < d.C) ? SyXg[(long)cc * d.G + x.gg] : 0.0;
   GeneOut<CM> go;
-  gene_close<CM>(d, c.hy, x.gg, x.has_slopes, x.gp, acc, Sy[x.gg], SyE[x.gg], SyX, ncell[x.gg], &go);
+  gene_close<CM>(d, c.hy, x.gg, x.has_slopes, x.gp, acc, Sy[x.gg], SyE[x.gg], SyX, ncell[x.gg], Lg1[x.gg], &go);
 #pragma unroll
   for (int k = 0; k < 10; ++k) part[k] = 0.0;
   bool bad = false;

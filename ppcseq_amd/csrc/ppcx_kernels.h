@@ -15,6 +15,7 @@ struct GeneArgs {
   const double* SyE;
   const double* SyX;            // [C][G]
   const double* ncell;
+  const double* Lg1;            // per-gene sum of lgamma(y+1)
   double* vecs;                 // [chains][V_COUNT][Dpad]
   long Dpad;
   const Cmd* cmds;              // [chains]

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void ppcx_gene_kernel(GeneArgs a) {
       }
     }
     double pn[NCM], part[10];
-    gene_end<CM>(d, c, v, x, acc, a.Sy, a.SyE, a.SyX, a.ncell, part, pn);
+    gene_end<CM>(d, c, v, x, acc, a.Sy, a.SyE, a.SyX, a.ncell, a.Lg1, part, pn);
 #pragma unroll
     for (int msk = L; msk < 64; msk <<= 1) {
 #pragma unroll

@@ -11,7 +11,8 @@
 //       d/deta = y - (y+phi)*u/w           d/dphi = psi(y+phi) - psi(phi) + 1 - log(w) - (y+phi)/(phi*w)
 //   * sum_s y*t and sum_s y are per-gene SUFFICIENT STATISTICS (Sy, SyE, SyX) precomputed once, so the
 //     large cancelling terms never go through the per-cell loop;
-//   * sum lgamma(y+1) is one constant of the data;
+//   * sum_s lgamma(y+1) is a per-gene constant of the data (Lg1), subtracted at gene level so the
+//     large lgamma terms cancel inside each gene instead of across the whole matrix;
 //   * for genes without slope terms (g >= K, X[,1] == 1) exp(t) factorises into E_s * A_g with
 //     E_s = exp(exposure_s) staged in LDS and A_g = exp(intercept_g + sigma_raw_g): no per-cell exp;
 //   * excluded cells (to_exclude, R/utilities.R:321-359, subtracted at .stan:105-115) are stored as
@@ -28,7 +29,6 @@ struct Dims {
   int off_intercept, off_alpha1, off_alpha2, off_sigma_raw, off_tail;  // Stan declaration order (.stan:183-197)
   int x0_is_one;                // X[,1] == 1 (model.matrix intercept column, R/utilities.R:887-900)
   double lambda_mu_mu;
-  double lgamma_y1_total;       // sum over non-excluded cells of lgamma(y+1)
 };
 
 PPCX_HD Dims make_dims(int G, int S, int C, int K, double lambda_mu_mu) {
@@ -40,7 +40,7 @@ PPCX_HD Dims make_dims(int G, int S, int C, int K, double lambda_mu_mu) {
   d.off_sigma_raw = d.off_alpha2 + (C > 2 ? C - 2 : 0) * K;
   d.off_tail = d.off_sigma_raw + G;
   d.D = d.off_tail + 3;
-  d.x0_is_one = 1; d.lambda_mu_mu = lambda_mu_mu; d.lgamma_y1_total = 0.0;
+  d.x0_is_one = 1; d.lambda_mu_mu = lambda_mu_mu;
   return d;
 }
 // flat index of the k-th hyper-parameter, k = 0..5 = lambda_mu, lambda_sigma, lambda_skew,
@@ -116,10 +116,10 @@ struct GeneOut {
 template <int CM>
 PPCX_HD void gene_close(const Dims& d, const Hyper& hy, int g, bool has_slopes, const GeneParams<CM>& gp,
                         const CellAcc<CM>& a, double Sy, double SyE, const double* SyX /*CM*/, double ncell,
-                        GeneOut<CM>* o) {
+                        double Lg1, GeneOut<CM>* o) {
   const double SQRT1_2 = 0.70710678118654752440, SQRT_2_OVER_PI = 0.79788456080286535588;
   // ----- likelihood -----
-  double lik = SyE + gp.sigma_raw * Sy - a.T1 + a.T3;
+  double lik = SyE + gp.sigma_raw * Sy - a.T1 + (a.T3 - Lg1);
 #pragma unroll
   for (int c = 0; c < CM; ++c) {
     o->g_coef[c] = 0.0;
@@ -168,7 +168,7 @@ PPCX_HD void gene_close(const Dims& d, const Hyper& hy, int g, bool has_slopes, 
 // hsum[6] = sums over genes of GeneOut::h; lp_genes = sum over genes of GeneOut::lp.
 PPCX_HD double hyper_close(const Dims& d, const Hyper& hy, const double* u6, double lp_genes, const double* hsum,
                            double* g6) {
-  double lp = lp_genes - d.lgamma_y1_total;
+  double lp = lp_genes;
   lp += u6[1] + u6[3] + u6[5];                                  // Jacobians
   const double dm = hy.lambda_mu - d.lambda_mu_mu;
   lp += -0.125 * dm * dm - 0.125 * hy.lambda_sigma * hy.lambda_sigma - 0.5 * hy.lambda_skew * hy.lambda_skew;

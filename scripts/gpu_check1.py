@@ -25,7 +25,7 @@ for (G, S, C, K, seed) in [(7, 5, 2, 3, 1), (40, 21, 2, 5, 2), (30, 11, 3, 4, 3)
             lpo, go = O.log_prob_grad(mo, u[i])
             rel = abs(lp[i] - lpo) / abs(lpo)
             ge = np.max(np.abs(g[i] - go) / (1 + np.abs(go)))
-            assert rel < 1e-12 and ge < 1e-10, (G, S, C, K, Lg, rel, ge)
+            assert rel < 1e-11 and ge < 1e-10, (G, S, C, K, Lg, rel, ge)
     print("lp/grad ok", G, S, C, K, m.get_launch(), flush=True)
     m.close()
 

@@ -12,7 +12,7 @@ using namespace ppcx;
 
 struct EmulModel {
   Dims d; int CM;
-  std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, ncell;
+  std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, ncell, Lg1;
 };
 
 static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, const double* X, const double* expo,
@@ -24,14 +24,12 @@ static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, c
   int x0 = 1;
   for (int s = 0; s < S; ++s) { m.E[s] = exp(expo[s]); if (X[s] != 1.0) x0 = 0; }
   m.d.x0_is_one = x0;
-  m.Sy.assign(G, 0); m.SyE.assign(G, 0); m.SyX.assign((size_t)C * G, 0); m.ncell.assign(G, 0);
-  double lg1 = 0;
+  m.Sy.assign(G, 0); m.SyE.assign(G, 0); m.SyX.assign((size_t)C * G, 0); m.ncell.assign(G, 0); m.Lg1.assign(G, 0);
   for (int g = 0; g < G; ++g) for (int s = 0; s < S; ++s) {
     int y = m.counts[(size_t)g * S + s]; if (y < 0) continue;
-    m.Sy[g] += y; m.SyE[g] += (double)y * expo[s]; m.ncell[g] += 1; lg1 += lgamma((double)y + 1.0);
+    m.Sy[g] += y; m.SyE[g] += (double)y * expo[s]; m.ncell[g] += 1; m.Lg1[g] += lgamma((double)y + 1.0);
     for (int c = 0; c < C; ++c) m.SyX[(size_t)c * G + g] += (double)y * X[(size_t)c * S + s];
   }
-  m.d.lgamma_y1_total = lg1;
   return m;
 }
 
@@ -48,7 +46,7 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
     CellAcc<CM> acc; acc.zero();
     gene_cells<CM>(d, x, m.counts.data() + (size_t)g * d.S, m.E.data(), m.expo.data(), m.X.data(), 0, 1, acc);
     double pn[NCM], part[10];
-    gene_end<CM>(d, c, v, x, acc, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.ncell.data(), part, pn);
+    gene_end<CM>(d, c, v, x, acc, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.ncell.data(), m.Lg1.data(), part, pn);
     for (int k = 0; k < 10; ++k) red[k] += part[k];
     if (c.type == CMD_LEAF) {
       NodeVals nv[NCM];
