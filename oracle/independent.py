@@ -122,40 +122,4 @@ def log_prob_grad_torch(u, counts, X, exposure, K, lambda_mu_mu=5.612671, excl=N
     return float(lp.detach()), ut.grad.numpy().copy()
 
 
-def synth(G, S, K=None, seed=20250, C=2, outliers=True):
-    """Synthetic generator of SURVEY.md 8(d) (cfg2-5). Returns dict(counts, X, exposure, K, truth)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    from scipy import stats
-    K = int(round(0.05 * G)) if K is None else K
-    group = np.zeros(S)
-    group[(S + 1) // 2:] = 1.0
-    cols = [np.ones(S), group]
-    for c in range(2, C):
-        cols.append(rng.normal(size=S))
-    X = np.stack(cols[:C], axis=1)
-    exposure = rng.normal(0, 0.2, S)
-    exposure -= exposure.mean()
-    intercept = stats.skewnorm.rvs(-1.0, loc=6.5, scale=1.8, size=G, random_state=rng)
-    sigma_raw = rng.normal(-0.3 * intercept, 0.4)
-    phi = np.exp(-sigma_raw)
-    alpha = np.zeros((C, G))
-    alpha[0] = intercept
-    if C >= 2:
-        alpha[1, :K] = rng.laplace(0, 1, K)
-    for c in range(2, C):
-        alpha[c, :K] = rng.normal(0, 0.5, K)
-    mu = np.exp((X @ alpha).T + exposure[None, :])
-    lam = rng.gamma(phi[:, None], mu / phi[:, None])
-    counts = rng.poisson(np.minimum(lam, 1e9)).astype(np.int64)
-    injected = []
-    if outliers and K > 0:
-        n_out = max(1, K // 10)
-        for g in rng.choice(K, n_out, replace=False):
-            s = int(rng.integers(S))
-            f = int(rng.integers(10, 51))
-            up = (alpha[1, g] > 0) == (group[s] > 0.5) if C >= 2 else True
-            counts[g, s] = counts[g, s] * f + f if up else counts[g, s] // f
-            injected.append((int(g), s))
-    counts = np.minimum(counts, 2**31 - 2).astype(np.int32)
-    return dict(counts=counts, X=X, exposure=exposure, K=K, injected=injected,
-                truth=dict(intercept=intercept, sigma_raw=sigma_raw, alpha=alpha))
+from ppcseq_amd.synth import synth  # noqa: E402,F401  (the generator itself is product code)

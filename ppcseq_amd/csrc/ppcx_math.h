@@ -68,21 +68,14 @@ PPCX_HD void lgamma_digamma(double x, double* lg, double* dg) {
 
 // ---------------------------------------------------------------------------------------------
 // log erfc(x) and  R(x) = exp(-x^2)/erfc(x)  (the inverse Mills-type ratio the skew-normal
-// gradient needs). For x > 25 erfc underflows, so the asymptotic expansion
-// erfc(x) ~ exp(-x^2)/(x sqrt(pi)) * (1 - 1/(2x^2) + 3/(4x^4) - 15/(8x^6) + 105/(16x^8)) is used.
+// gradient needs). Written as Stan Math's skew_normal_lpdf evaluates it -- log(erfc(.)) directly --
+// so that where erfc underflows (x > ~26.5) the density is log(0) = -inf exactly as in the reference:
+// such points are rejected as initial values and count as divergent proposals, the same as in Stan.
 // ---------------------------------------------------------------------------------------------
 PPCX_HD void log_erfc_and_ratio(double x, double* log_erfc, double* ratio) {
-  if (x < 25.0) {
-    const double e = erfc(x);
-    *log_erfc = log(e);
-    *ratio = exp(-x * x) / e;
-  } else {
-    const double i2 = 1.0 / (x * x);
-    const double s = 1.0 + i2 * (-0.5 + i2 * (0.75 + i2 * (-1.875 + i2 * 6.5625)));
-    const double xs = x * 1.77245385090551602730;  // x sqrt(pi)
-    *log_erfc = -x * x - log(xs) + log(s);
-    *ratio = xs / s;
-  }
+  const double e = erfc(x);
+  *log_erfc = log(e);
+  *ratio = exp(-x * x) / e;
 }
 
 PPCX_HD double log_sum_exp(double a, double b) {

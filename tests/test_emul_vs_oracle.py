@@ -1,0 +1,100 @@
+"""Host-logic tests without a GPU: the product's `__host__ __device__` arithmetic and NUTS state machine
+(ppcseq_amd/csrc/ppcx_{math,model,nuts,gene}.h), compiled for the CPU by tests/emul/ppcx_emul.cpp with
+loops in place of wavefront lanes, against the oracle. The GPU kernels themselves are checked by the
+`-m gpu` tests through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import independent as ind
+from tests.emul_util import emul_fit, emul_lp
+
+CASES = [(7, 5, 2, 3, 1), (40, 21, 2, 5, 2), (30, 11, 3, 4, 3), (12, 6, 1, 2, 4), (25, 9, 5, 6, 5), (9, 1, 2, 2, 6), (6, 3, 2, 0, 8)]
+
+
+@pytest.mark.parametrize("G,S,C,K,seed", CASES)
+def test_density_and_gradient(oracle, emul, G, S, C, K, seed):
+    d = ind.synth(G, S, K=K, seed=seed, C=C)
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(-1, 1, oracle.dim(G, C, K))
+    u[3:3 + G] += 5
+    excl = np.array(sorted({1 % (G * S), (2 * S + 3) % (G * S), (G - 1) * S}), dtype=np.int32) if seed % 2 == 0 else None
+    m = oracle.model(d["counts"], d["X"], d["exposure"], K, excl=excl)
+    lp, g = oracle.log_prob_grad(m, u)
+    lp2, g2 = emul_lp(emul, d["counts"], d["X"], d["exposure"], K, u, excl)
+    assert abs(lp2 - lp) <= 1e-11 * max(1.0, abs(lp))
+    assert np.max(np.abs(g - g2) / (1 + np.abs(g))) < 1e-10
+
+
+def test_design_without_unit_intercept_column(oracle, emul):
+    """X[,1] != 1 disables the E_s * A_g factorisation: the generic per-cell exp path must agree too."""
+    d = ind.synth(10, 6, K=3, seed=2, C=2)
+    X = d["X"].copy()
+    X[:, 0] = np.linspace(0.5, 1.5, 6)
+    u = np.random.default_rng(1).uniform(-1, 1, oracle.dim(10, 2, 3))
+    u[3:13] += 4
+    m = oracle.model(d["counts"], X, d["exposure"], 3)
+    lp, g = oracle.log_prob_grad(m, u)
+    lp2, g2 = emul_lp(emul, d["counts"], X, d["exposure"], 3, u)
+    assert abs(lp2 - lp) <= 1e-11 * abs(lp) and np.max(np.abs(g - g2) / (1 + np.abs(g))) < 1e-10
+
+
+@pytest.mark.parametrize("G,S,C,K,seed", [(30, 8, 2, 4, 3), (20, 6, 1, 3, 4), (24, 7, 3, 4, 5)])
+def test_nuts_state_machine_follows_oracle(oracle, emul, G, S, C, K, seed):
+    """Same Philox streams, same Stan-default algorithm: the iterative device tree and the oracle's
+    recursive build_tree must make identical decisions until floating-point chaos separates the chains.
+    The first iterations (before roundoff has been amplified by the long warmup trajectories) agree to
+    rounding, including trees up to depth >= 5."""
+    d = ind.synth(G, S, K=K, seed=seed, C=C)
+    m = oracle.model(d["counts"], d["X"], d["exposure"], K)
+    r = oracle.nuts_model(m, oracle.cfg(chains=2, iter=40, warmup=40, seed=11))
+    e = emul_fit(emul, d["counts"], d["X"], d["exposure"], K, 2, 40, 40, 11)
+    n = 12
+    assert np.array_equal(r.n_leapfrog[:, :n], e["n_leapfrog"][:, :n])
+    assert np.array_equal(r.treedepth[:, :n], e["treedepth"][:, :n])
+    assert np.array_equal(r.divergent[:, :n], e["divergent"][:, :n])
+    assert np.max(np.abs(r.stepsize[:, :n] - e["stepsize"][:, :n])) < 1e-9
+    assert np.max(np.abs(r.accept[:, :n] - e["accept"][:, :n])) < 1e-7
+    assert r.treedepth[:, :n].max() >= 4
+
+
+def test_nuts_sampling_draws_follow_oracle(oracle, emul):
+    """With warmup = 0 (no adaptation, unit metric) and a capped tree depth the kept draws themselves
+    can be compared for the first iterations."""
+    d = ind.synth(16, 5, K=3, seed=9, C=2)
+    m = oracle.model(d["counts"], d["X"], d["exposure"], 3)
+    cfg = oracle.cfg(chains=1, iter=8, warmup=0, seed=5, max_treedepth=6)
+    r = oracle.nuts_model(m, cfg)
+    e = emul_fit(emul, d["counts"], d["X"], d["exposure"], 3, 1, 8, 0, 5, max_treedepth=6)
+    assert np.array_equal(r.n_leapfrog, e["n_leapfrog"])
+    assert np.max(np.abs(r.draws - e["draws"])) < 1e-8
+    assert np.max(np.abs(r.lp - e["lp"])) < 1e-7
+
+
+def test_full_run_distribution_matches_oracle(oracle, emul):
+    """Over a whole run the two samplers target the same posterior: pooled means of the hyper-parameters
+    agree within Monte-Carlo error."""
+    d = ind.synth(40, 10, K=4, seed=21, C=2)
+    m = oracle.model(d["counts"], d["X"], d["exposure"], 4)
+    r = oracle.nuts_model(m, oracle.cfg(chains=4, iter=400, warmup=150, seed=3))
+    e = emul_fit(emul, d["counts"], d["X"], d["exposure"], 4, 4, 400, 150, 3)
+    D = r.draws.shape[-1]
+    cols = [0, 1, 2, D - 3, D - 2, D - 1]
+    a = r.draws[..., cols].reshape(-1, 6)
+    b = e["draws"][..., cols].reshape(-1, 6)
+    se = np.sqrt(a.var(0) / 100 + b.var(0) / 100)             # ESS >= 100 each, conservatively
+    assert np.all(np.abs(a.mean(0) - b.mean(0)) < 5 * se)
+    assert e["divergent"][:, 150:].sum() == 0
+
+
+def test_nb_rng_spec_identical(oracle, emul):
+    """The product's gamma-Poisson generator and the oracle's are two implementations of one Philox
+    stream specification: identical integers."""
+    emul.emul_nb2_log_rng.restype = C.c_int
+    emul.emul_nb2_log_rng.argtypes = [C.c_double, C.c_double, C.c_ulonglong, C.c_uint, C.c_uint]
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        eta, phi = rng.uniform(-3, 12), np.exp(rng.uniform(-4, 6))
+        cell, draw, seed = int(rng.integers(1 << 20)), int(rng.integers(1 << 16)), int(rng.integers(1 << 40))
+        assert emul.emul_nb2_log_rng(eta, phi, seed, cell, draw) == oracle.nb2_log_rng(eta, phi, seed, cell, draw)

@@ -1,0 +1,104 @@
+"""Host-side mirrors of the reference's R helpers (no GPU): chain chooser, type-7 quantiles, thresholds,
+formula / design matrix, flags, TMM, ESS, .rda reader."""
+import numpy as np
+import pytest
+
+from ppcseq_amd import inference as inf
+from ppcseq_amd import methods as meth
+from ppcseq_amd.ess import ess_bulk, rhat
+
+
+def test_find_optimal_number_of_chains():
+    # R/utilities.R:291-303; SURVEY App. C: 1000 draws -> 3 chains, 10 500 -> 8
+    assert inf.find_optimal_number_of_chains(1000) == 3
+    assert inf.find_optimal_number_of_chains(10500) == 8
+
+
+def test_quantile_type7_matches_numpy_linear():
+    x = np.random.default_rng(0).integers(0, 1000, 997)
+    for p in [0.0, 0.001, 0.025, 0.5, 0.975, 1.0]:
+        assert inf.quantile7(x, p) == pytest.approx(np.quantile(x, p, method="linear"), rel=1e-14)
+
+
+def test_parse_formula_and_design_matrix():
+    import pandas as pd
+    assert meth.parse_formula("~ Label") == ["Label"]
+    assert meth.parse_formula("~ 1") == []
+    assert meth.parse_formula("~ a + b") == ["a", "b"]
+    with pytest.raises(ValueError):
+        meth.parse_formula("y ~ a")
+    df = pd.DataFrame({"sample": ["s2", "s1", "s3", "s2"], "Label": ["B", "A", "B", "B"], "x": [1.0, 2.0, 3.0, 1.0]})
+    X, names, samples = meth.create_design_matrix(df, "~ Label + x", "sample")
+    assert samples == ["s1", "s2", "s3"] and names == ["(Intercept)", "LabelB", "x"]
+    assert np.array_equal(X, np.array([[1, 0, 2.0], [1, 1, 1.0], [1, 1, 3.0]]))
+
+
+def test_flags_follow_reference_rules():
+    # check_if_within_posterior (R/utilities.R:651-663) and add_deleterious_if_covariate_exists (:493-513)
+    counts = np.array([[10, 100, 5, 50]])
+    ci = np.zeros((1, 4, 4))
+    ci[0, :, 0] = [20, 20, 20, 20]        # mean
+    ci[0, :, 2] = [10, 10, 10, 10]        # lower (inclusive)
+    ci[0, :, 3] = [50, 50, 50, 50]        # upper (inclusive)
+    X = np.array([[1, 0], [1, 0], [1, 1], [1, 1.0]])
+    r = inf._post_process(counts, ci, np.array([0.7]), X)
+    assert r.ppc.tolist() == [[True, False, False, True]]
+    assert r.is_higher_than_mean.tolist() == [[False, True, False, False]]
+    assert r.is_group_high.tolist() == [[False, False, True, True]]
+    # outlier too high in the LOW group and too low in the HIGH group both work against a positive slope
+    assert r.deleterious_outliers.tolist() == [[False, False, False, False]]
+    r2 = inf._post_process(counts, ci, np.array([-0.7]), X)
+    assert r2.deleterious_outliers.tolist() == [[False, True, True, False]]
+
+
+def test_threshold_arithmetic_of_identify_outliers():
+    # R/methods.R:156-167 with 21 samples, pfp = 1, detrimental only
+    thr2 = 1 / 100 / 21 * 2
+    thr1 = max(0.05, 2 * thr2)
+    assert thr1 == 0.05
+    assert max(10 / thr1, 1000) == 1000 and max(10 / thr2, 1000) == pytest.approx(10500)
+
+
+def test_tmm_recovers_known_scaling():
+    rng = np.random.default_rng(3)
+    base = rng.gamma(2.0, 200.0, size=2000)
+    scale = np.array([1.0, 2.0, 0.5, 1.5])
+    mat = rng.poisson(base[:, None] * scale[None, :])
+    mult, nf = meth.get_scaled_counts_bulk(mat, ["a", "b", "c", "d"])
+    m = np.array([mult[s] for s in "abcd"])
+    # multiplier brings every library to the reference sample's scale
+    scaled = mat.sum(0) * m
+    assert np.all(np.abs(scaled / scaled[np.argmax(np.median(mat, axis=0))] - 1) < 0.03)
+    assert abs(np.exp(np.mean(np.log(list(nf.values())))) - 1) < 1e-12
+
+
+def test_ess_estimator():
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(4, 1000))
+    assert 3000 < ess_bulk(x) < 5000 and abs(rhat(x) - 1) < 0.01
+    y = np.zeros((4, 1000))
+    e = rng.normal(size=(4, 1000))
+    for t in range(1, 1000):
+        y[:, t] = 0.9 * y[:, t - 1] + e[:, t]
+    assert 120 < ess_bulk(y) < 400           # theory: 4000 * (1-0.9)/(1+0.9) = 210
+    z = x + np.arange(4)[:, None]            # chains that disagree
+    assert rhat(z) > 1.5
+
+
+def test_bundled_fixture_matches_reference_facts(bundled):
+    # man/counts.Rd:8, README.md:32-45, SURVEY App. E
+    assert bundled["value"].shape == (18801, 21)
+    genes = [str(g) for g in bundled["genes"]]
+    assert genes[:3] == ["SLC16A12", "CYP1A1", "ART3"]
+    assert bundled["value"][genes.index("CYP1A1")].tolist() == [6, 12, 0, 2, 0, 2, 3, 50, 2, 48, 26, 4, 4, 4, 10, 820, 5835, 2, 12, 0, 2]
+    assert str(bundled["samples"][16]) == "11165PP"
+    assert int((bundled["FDR"] < 0.01).sum()) == 15 and int(bundled["value"].max()) == 2580228
+
+
+def test_test_config_selection(bundled):
+    from tests.conftest import bundled_test_config
+    counts, X, genes, K = bundled_test_config(bundled)
+    assert counts.shape == (53, 21) and K == 3 and genes[:3] == ["SLC16A12", "CYP1A1", "ART3"]
+    assert genes[3:8] == ["AATF", "ABCA9", "ABT1", "BHLHE40", "C1orf174"]
+    assert int(counts.sum()) == 2080390 and int(counts.max()) == 24912
+    assert X[:, 1].sum() == 11                                               # 10 High / 11 Neoadjuvant

@@ -1,0 +1,51 @@
+"""Pins the oracle's NUTS restatement (Stan defaults) on analytic targets and checks
+its adaptation schedule. No Stan draws exist to compare against (no R/Stan in the container)."""
+import numpy as np
+
+
+def test_gaussian_target_recovered(oracle):
+    D = 40
+    mean = np.linspace(-3, 3, D)
+    sd = np.exp(np.linspace(-2, 2, D))
+    cfg = oracle.cfg(chains=4, iter=650, warmup=150, seed=7)
+    r = oracle.nuts_gauss(mean, sd, cfg)
+    x = r.draws.reshape(-1, D)
+    # 2000 draws: mean within 5 MC standard errors (ESS >= 400 conservatively), sd within 12 %
+    assert np.max(np.abs(x.mean(0) - mean) / sd) < 5 / np.sqrt(400)
+    assert np.all(np.abs(x.std(0) / sd - 1) < 0.12)
+    assert r.divergent[:, 150:].sum() == 0
+    # dual averaging targets adapt_delta = 0.8 during warmup; sampling acceptance ends up near/above it
+    assert 0.7 < r.accept[:, 150:].mean() < 0.98
+
+
+def test_adaptation_schedule(oracle):
+    """warmup = 150 => init_buffer 75, one 25-iteration window, term_buffer 50: the metric changes exactly
+    once (after iteration 99), where the step size restarts from the init_stepsize heuristic."""
+    D = 10
+    cfg = oracle.cfg(chains=1, iter=160, warmup=150, seed=3)
+    r = oracle.nuts_gauss(np.zeros(D), np.full(D, 0.01), cfg)
+    ss = r.stepsize[0]
+    # tiny-scale target: before the metric update the step is ~0.01-scale, after it ~1-scale
+    assert ss[60:99].max() < 0.1 and ss[101:150].min() > 0.1
+    assert np.all(ss[150:] == ss[150])          # frozen after warmup
+
+
+def test_model_posterior_sane(oracle):
+    from oracle import independent as ind
+    d = ind.synth(60, 12, K=6, seed=5)
+    m = oracle.model(d["counts"], d["X"], d["exposure"], d["K"])
+    r = oracle.nuts_model(m, oracle.cfg(chains=3, iter=300, warmup=150, seed=11))
+    x = r.draws.reshape(-1, r.draws.shape[-1])
+    assert np.corrcoef(x[:, 3:63].mean(0), d["truth"]["intercept"])[0, 1] > 0.98
+    assert r.divergent[:, 150:].sum() == 0
+
+
+def test_rng_is_counter_based_and_reproducible(oracle):
+    a = [oracle.nb2_log_rng(3.0, 2.0, 7, c, d) for c in range(5) for d in range(5)]
+    b = [oracle.nb2_log_rng(3.0, 2.0, 7, c, d) for c in range(5) for d in range(5)]
+    assert a == b and len(set(a)) > 5
+    x = np.array([oracle.nb2_log_rng(np.log(50.0), 4.0, 1, 0, d) for d in range(20000)], dtype=float)
+    # NB(mean 50, size 4): var = 50 + 2500/4 = 675
+    assert abs(x.mean() - 50) < 1.0 and abs(x.var() - 675) < 60
+    y = np.array([oracle.nb2_log_rng(np.log(3.0), 0.5, 1, 1, d) for d in range(20000)], dtype=float)
+    assert abs(y.mean() - 3) < 0.15 and abs(y.var() - (3 + 9 / 0.5)) < 3.0
