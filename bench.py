@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Benchmark of the one hot path: NB hierarchical NUTS fit on MI355X (BASELINE.json metric
+"effective samples/sec (whole node) for NB hierarchical fit").
+
+A "step" is one complete fit -- Stan-default warm-up (150) + kept draws for every chain of every GPU --
+on the synthetic 20,000 genes x 200 samples matrix of BASELINE config 3, inputs already resident in
+HBM. `value` = sum over steps of the pooled bulk-ESS (min over the six hyper-parameters and lp__) divided
+by the summed wall time (barrier + device synchronise on both sides, max over ranks). Chains are the
+sharded unit (weak scaling: chains/GPU fixed); there is no collective on the data path.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genes", type=int, default=20000)
+    ap.add_argument("--samples", type=int, default=200)
+    ap.add_argument("--chains-per-gpu", type=int, default=4)
+    ap.add_argument("--draws-per-chain", type=int, default=250)
+    ap.add_argument("--nuts-warmup", type=int, default=150)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per gene override (0 = automatic)")
+    ap.add_argument("--groups-per-wave", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    from ppcseq_amd import _lib, distributed as D
+    from ppcseq_amd.ess import ess_bulk
+    from ppcseq_amd.synth import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+
+    G, S, C = args.genes, args.samples, 2
+    seed_data = 20253
+    # rank 0 draws the synthetic matrix; the other ranks receive it by RCCL broadcast over xGMI
+    if rank == 0:
+        d = synth(G, S, seed=seed_data, C=C)
+        arrays = dict(counts=d["counts"], X=d["X"], exposure=d["exposure"], K=np.array([d["K"]], np.int64))
+    else:
+        arrays = None
+    if dist_on:
+        arrays = D.broadcast_arrays(arrays, device=dev)
+    K = int(arrays["K"][0])
+    model = _lib.Model(arrays["counts"], arrays["X"], arrays["exposure"], K, device=local_rank)
+    if args.lanes or args.groups_per_wave:
+        model.set_launch(args.lanes, args.groups_per_wave)
+    Dm = model.D
+    hyper_cols = [0, 1, 2, Dm - 3, Dm - 2, Dm - 1]
+    nch = args.chains_per_gpu
+    n_iter = args.nuts_warmup + args.draws_per_chain
+
+    def barrier():
+        if dist_on:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_fit(step_seed):
+        fit = model.fit_nuts(chains=nch, iter=n_iter, warmup=args.nuts_warmup, seed=step_seed,
+                             chain_id_offset=D.chain_id_offset(rank, nch))
+        return fit
+
+    for w in range(args.warmup):
+        f = one_fit(1000 + w)
+        f.close()
+
+    tot_time, tot_ess, tot_grad = 0.0, 0.0, 0
+    kA_ms, kA_n, kA_chains = 0.0, 0, 0.0
+    ess_detail, depth_mean, div_total = None, [], 0
+    for k in range(args.steps):
+        barrier()
+        t0 = time.perf_counter()
+        fit = one_fit(1 + k)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            dt = D.max_over_ranks(dt, device=dev)
+        # ---- outside the timed region: pooled ESS over every chain of the job
+        hyp = fit.columns(hyper_cols)                      # [chains, n_keep, 6]
+        dg = fit.diagnostics()
+        tm = fit.timing()
+        lp = dg["lp"]
+        ge = np.array([float(tm.grad_evals)])
+        if dist_on:
+            hyp = D.all_gather_chains(hyp, device=dev)
+            lp = D.all_gather_chains(lp, device=dev)
+            ge = D.all_gather_chains(ge, device=dev)
+        per = [ess_bulk(hyp[:, :, j]) for j in range(6)] + [ess_bulk(lp)]
+        tot_ess += float(np.nanmin(per))
+        ess_detail = per
+        tot_time += dt
+        tot_grad += int(ge.sum())
+        kA_ms += tm.gene_kernel_ms_mean * tm.gene_kernel_samples
+        kA_n += tm.gene_kernel_samples
+        kA_chains += tm.gene_kernel_chain_launches_mean * tm.gene_kernel_samples
+        depth_mean.append(float(dg["treedepth"].mean()))
+        div_total += int(dg["divergent"][:, args.nuts_warmup:].sum())
+        fit.close()
+
+    if rank == 0:
+        E = 0
+        b_grad = 4.0 * G * S + 16.0 * (C + 1) * G + 8.0 * S * (C + 1) + 4.0 * E
+        roof = None
+        if kA_n > 0:
+            ms = kA_ms / kA_n
+            chains_per_launch = kA_chains / kA_n
+            achieved = b_grad * chains_per_launch / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "ppcx_gene_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": b_grad * chains_per_launch, "avg_launch_ms": round(ms, 5),
+                    "timed_launches": int(kA_n)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(arrays, K, tot_ess, tot_grad, args)
+        out = {
+            "metric": "effective samples/sec (whole node) for NB hierarchical fit",
+            "value": round(tot_ess / tot_time, 3), "unit": "ESS/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * tot_time / max(args.steps, 1), 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE cfg3: synthetic {G} genes x {S} samples (seed {seed_data}), C=2, K={K}; "
+                                   f"NUTS (Stan defaults) warm-up {args.nuts_warmup} + {args.draws_per_chain} kept draws/chain, "
+                                   f"{nch} chains per GPU (chains are the sharded unit)",
+                       "chains_total": nch * world, "lanes_per_gene": model.get_launch()[0], "blocks_per_chain": model.get_launch()[1],
+                       "ess_estimator": "rank-normalised split-chain bulk-ESS, min over 6 hyper-parameters and lp__",
+                       "ess_last_step": [round(float(x), 1) for x in ess_detail],
+                       "grad_evals": tot_grad, "mean_treedepth": round(float(np.mean(depth_mean)), 2),
+                       "divergent_after_warmup": div_total,
+                       "us_per_grad_eval_per_chain": round(1e6 * tot_time * world * nch / max(tot_grad, 1), 2)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    model.close()
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(arrays, K, gpu_ess, gpu_grad, args):
+    """The oracle (CPU restatement, Stan-equivalent, NOT rstan: no R/Stan on this box) timed on this host on a
+    bounded sample of the same workload: the first gradient evaluations of chain 0's warm-up, OpenMP threads
+    over gene shards (mirrors map_rect / STAN_NUM_THREADS, R/utilities.R:1383-1386,1479). Converted to ESS/s
+    with the ESS per gradient evaluation measured on the GPU run of the same algorithm and seeds."""
+    from oracle.oracle import Oracle
+    try:
+        O = Oracle(native=True)
+    except Exception:
+        O = Oracle()
+    # the GPU box gives a one-GPU job a share of ~16 host cores whatever os.cpu_count() says
+    try:
+        cores = min(len(os.sched_getaffinity(0)), 16)
+    except AttributeError:
+        cores = min(os.cpu_count() or 1, 16)
+    m = O.model(arrays["counts"], arrays["X"], arrays["exposure"], K, n_threads=cores)
+    u = np.zeros(O.dim(m.G, m.C, m.K))
+    t0 = time.perf_counter()
+    O.log_prob_grad(m, u)
+    t_one = time.perf_counter() - t0
+    n_leap = max(8, int(args.cpu_seconds / max(t_one, 1e-3)))
+    cfg = O.cfg(chains=1, iter=args.nuts_warmup + args.draws_per_chain, warmup=args.nuts_warmup, seed=1,
+                max_leapfrogs_total=n_leap)
+    t0 = time.perf_counter()
+    r = O.nuts_model(m, cfg)
+    dt = time.perf_counter() - t0
+    done = int(r.iters_done[0])
+    leap = int(r.n_leapfrog[0, :done].sum()) + 2 * done + 4       # + init_stepsize / init evaluations (approx.)
+    rate = leap / dt
+    ess_per_grad = gpu_ess / max(gpu_grad, 1)
+    return {"value": round(rate * ess_per_grad, 5), "unit": "ESS/s", "cores": cores, "kind": "port",
+            "grad_evals_per_s": round(rate, 3),
+            "sample": f"first {leap} gradient evaluations ({done} NUTS warm-up iterations) of chain 0 on the same "
+                      f"{m.G}x{m.S} matrix, {cores} OpenMP threads over genes, {dt:.1f} s; ESS per gradient taken "
+                      f"from the GPU run (same algorithm, seeds and estimator). CPU restatement (Stan-equivalent), not rstan."}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,272 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (libppcx.so via ctypes), against the
+oracle on the same seeded inputs; committed golden data; size-independent properties at full size.
+
+Tolerances (fp64 path):
+  log density   : |lp - lp_oracle| <= 1e-11 |lp|   (both sum ~G*S terms of magnitude up to 1e7 in fp64)
+  gradient      : max |g - g_oracle| / (1 + |g_oracle|) <= 1e-10
+  NUTS          : identical tree sizes / divergences for the first iterations at equal seeds (same Philox
+                  streams, same algorithm), then distributional agreement within Monte-Carlo error
+  predictive draws: bit-identical integers for the same posterior draws and seed
+  credible intervals: <= 1e-9 absolute on mean/sd/quantiles of identical integer draws
+"""
+import numpy as np
+import pytest
+
+from oracle import independent as ind
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(7, 5, 2, 3, 1), (40, 21, 2, 5, 2), (30, 11, 3, 4, 3), (12, 6, 1, 2, 4), (25, 9, 5, 6, 5), (9, 1, 2, 2, 6),
+         (1, 4, 2, 1, 7), (6, 3, 2, 0, 8), (300, 50, 2, 15, 10), (257, 200, 2, 13, 9), (130, 500, 2, 7, 12)]
+
+
+@pytest.fixture(scope="module")
+def L():
+    from ppcseq_amd import _lib
+    if _lib.device_count() < 1:
+        pytest.fail("no HIP device visible: the product has no CPU fallback")
+    return _lib
+
+
+def _point(G, S, C, K, seed, oracle, n=2):
+    d = ind.synth(G, S, K=K, seed=seed, C=C)
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(-1, 1, (n, oracle.dim(G, C, K)))
+    u[:, 3:3 + G] += 5
+    excl = np.array(sorted({1 % (G * S), (2 * S + 3) % (G * S), (G - 1) * S}), dtype=np.int32) if seed % 2 == 0 else None
+    return d, u, excl
+
+
+@pytest.mark.parametrize("G,S,C,K,seed", CASES)
+def test_log_prob_grad_matches_oracle(L, oracle, G, S, C, K, seed):
+    d, u, excl = _point(G, S, C, K, seed, oracle)
+    mo = oracle.model(d["counts"], d["X"], d["exposure"], K, excl=excl)
+    m = L.Model(d["counts"], d["X"], d["exposure"], K, excl=excl)
+    try:
+        for lanes in [0, 1, 2, 8, 32, 64]:           # every lanes-per-gene instantiation reduces differently
+            m.set_launch(lanes, 0)
+            lp, g = m.log_prob_grad(u)
+            for i in range(u.shape[0]):
+                lpo, go = oracle.log_prob_grad(mo, u[i])
+                assert abs(lp[i] - lpo) <= 1e-11 * max(1.0, abs(lpo)), (lanes, lp[i], lpo)
+                assert np.max(np.abs(g[i] - go) / (1 + np.abs(go))) <= 1e-10, lanes
+    finally:
+        m.close()
+
+
+def test_extreme_counts_zero_rows_and_generic_design(L, oracle):
+    """Zeros, the bundled maximum 2,580,228, an all-zero gene, and a design whose first column is not 1
+    (no E_s*A_g factorisation)."""
+    rng = np.random.default_rng(5)
+    counts = rng.poisson(30, size=(20, 9)).astype(np.int32)
+    counts[0] = 0
+    counts[1, 3] = 2580228
+    counts[2, :] = [0, 1, 2, 3, 4, 5, 6, 7, 8]
+    X = np.stack([np.linspace(0.5, 1.5, 9), (np.arange(9) > 4).astype(float), rng.normal(size=9)], axis=1)
+    expo = rng.normal(0, 0.3, 9)
+    K = 4
+    u = rng.uniform(-1, 1, (2, oracle.dim(20, 3, K)))
+    u[:, 3:23] += 3
+    mo = oracle.model(counts, X, expo, K)
+    m = L.Model(counts, X, expo, K)
+    try:
+        lp, g = m.log_prob_grad(u)
+        for i in range(2):
+            lpo, go = oracle.log_prob_grad(mo, u[i])
+            assert abs(lp[i] - lpo) <= 1e-11 * abs(lpo)
+            assert np.max(np.abs(g[i] - go) / (1 + np.abs(go))) <= 1e-10
+    finally:
+        m.close()
+
+
+def test_exclusions_equal_subtracted_cells(L, oracle):
+    """to_exclude semantics of .stan:105-115: excluding cells == full sum minus those cells; and
+    set_exclusions() (pass 2 re-use of the resident model) == a model created with the exclusions."""
+    d, u, _ = _point(50, 12, 2, 5, 3, oracle, n=1)
+    excl = np.array([0, 13, 27, 599], dtype=np.int32)
+    m = L.Model(d["counts"], d["X"], d["exposure"], 5)
+    m2 = L.Model(d["counts"], d["X"], d["exposure"], 5, excl=excl)
+    try:
+        lp_full, _ = m.log_prob_grad(u[0])
+        m.set_exclusions(excl)
+        lp_a, g_a = m.log_prob_grad(u[0])
+        lp_b, g_b = m2.log_prob_grad(u[0])
+        assert lp_a == lp_b and np.array_equal(g_a, g_b)
+        mo = oracle.model(d["counts"], d["X"], d["exposure"], 5, excl=excl)
+        lpo, _ = oracle.log_prob_grad(mo, u[0])
+        assert abs(lp_a - lpo) <= 1e-11 * abs(lpo) and lp_a != lp_full
+        m.set_exclusions(None)
+        assert m.log_prob_grad(u[0])[0] == lp_full
+    finally:
+        m.close(); m2.close()
+
+
+def test_error_reporting(L):
+    with pytest.raises(L.PpcxError):
+        L.Model(np.zeros((3, 4), np.int32) - 1, np.ones((4, 1)), np.zeros(4), 0)      # negative count
+    with pytest.raises(L.PpcxError):
+        L.Model(np.ones((3, 4), np.int32), np.ones((4, 9)), np.zeros(4), 0)           # C > 8
+    m = L.Model(np.ones((3, 4), np.int32), np.ones((4, 1)), np.zeros(4), 1)
+    try:
+        with pytest.raises(L.PpcxError):
+            m.fit_nuts(chains=0)
+        with pytest.raises(L.PpcxError):
+            m.set_exclusions(np.array([99], np.int32))
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("G,S,C,K,seed", [(30, 8, 2, 4, 3), (20, 6, 1, 3, 4), (24, 7, 3, 4, 5)])
+def test_nuts_follows_oracle_at_equal_seed(L, oracle, G, S, C, K, seed):
+    d = ind.synth(G, S, K=K, seed=seed, C=C)
+    mo = oracle.model(d["counts"], d["X"], d["exposure"], K)
+    r = oracle.nuts_model(mo, oracle.cfg(chains=3, iter=40, warmup=40, seed=11))
+    m = L.Model(d["counts"], d["X"], d["exposure"], K)
+    try:
+        f = m.fit_nuts(chains=3, iter=40, warmup=40, seed=11)
+        dg = f.diagnostics()
+        f.close()
+    finally:
+        m.close()
+    n = 10
+    assert np.array_equal(dg["n_leapfrog"][:, :n], r.n_leapfrog[:, :n])
+    assert np.array_equal(dg["treedepth"][:, :n], r.treedepth[:, :n])
+    assert np.array_equal(dg["divergent"][:, :n], r.divergent[:, :n])
+    assert np.max(np.abs(dg["stepsize"][:, :n] - r.stepsize[:, :n])) < 1e-8
+    assert np.max(np.abs(dg["accept"][:, :n] - r.accept[:, :n])) < 1e-6
+
+
+def test_nuts_draws_follow_oracle_without_adaptation(L, oracle):
+    d = ind.synth(16, 5, K=3, seed=9, C=2)
+    mo = oracle.model(d["counts"], d["X"], d["exposure"], 3)
+    r = oracle.nuts_model(mo, oracle.cfg(chains=2, iter=8, warmup=0, seed=5, max_treedepth=6))
+    m = L.Model(d["counts"], d["X"], d["exposure"], 3)
+    try:
+        f = m.fit_nuts(chains=2, iter=8, warmup=0, seed=5, max_treedepth=6)
+        dr, dg = f.draws(), f.diagnostics()
+        f.close()
+    finally:
+        m.close()
+    assert np.array_equal(dg["n_leapfrog"], r.n_leapfrog)
+    assert np.max(np.abs(dr - r.draws)) < 1e-7
+    assert np.max(np.abs(dg["lp"] - r.lp)) < 1e-6
+
+
+def test_nuts_posterior_matches_oracle_distribution(L, oracle):
+    d = ind.synth(40, 10, K=4, seed=21, C=2)
+    mo = oracle.model(d["counts"], d["X"], d["exposure"], 4, n_threads=4)
+    r = oracle.nuts_model(mo, oracle.cfg(chains=4, iter=400, warmup=150, seed=3))
+    m = L.Model(d["counts"], d["X"], d["exposure"], 4)
+    try:
+        f = m.fit_nuts(chains=4, iter=400, warmup=150, seed=3)
+        D = f.D
+        cols = [0, 1, 2, D - 3, D - 2, D - 1]
+        b = f.columns(cols).reshape(-1, 6)
+        dg = f.diagnostics()
+        f.close()
+    finally:
+        m.close()
+    a = r.draws[..., cols].reshape(-1, 6)
+    se = np.sqrt(a.var(0) / 100 + b.var(0) / 100)
+    assert np.all(np.abs(a.mean(0) - b.mean(0)) < 5 * se)
+    assert np.all(np.abs(np.log(a.std(0) / b.std(0))) < 0.35)
+    assert dg["divergent"][:, 150:].mean() <= 0.02      # small hierarchical model: rare divergences are expected
+    assert dg["stepsize"][:, -1].min() > 0
+
+
+def test_chain_id_offset_gives_distinct_streams(L):
+    d = ind.synth(20, 6, K=2, seed=1)
+    m = L.Model(d["counts"], d["X"], d["exposure"], 2)
+    try:
+        f0 = m.fit_nuts(chains=2, iter=30, warmup=20, seed=4, chain_id_offset=0)
+        f1 = m.fit_nuts(chains=2, iter=30, warmup=20, seed=4, chain_id_offset=1)
+        a, b = f0.draws(), f1.draws()
+        f0.close(); f1.close()
+    finally:
+        m.close()
+    assert np.array_equal(a[1], b[0])            # global chain 1 is the same wherever it runs
+    assert not np.array_equal(a[0], a[1])
+
+
+def test_generated_quantities_and_intervals_match_oracle(L, oracle):
+    d = ind.synth(30, 8, K=4, seed=3)
+    mo = oracle.model(d["counts"], d["X"], d["exposure"], 4)
+    m = L.Model(d["counts"], d["X"], d["exposure"], 4)
+    try:
+        f = m.fit_nuts(chains=3, iter=250, warmup=150, seed=2)
+        dr = f.draws().reshape(-1, f.D)
+        for tc, p in [(1.0, 0.05), (0.7352941, 0.002)]:
+            ci, rng = f.ppc(tc, p, 1 - p, seed=5, return_counts_rng=True)
+            gq = oracle.generated_quantities(mo, dr, tc, seed=5)
+            assert np.array_equal(gq, rng)                                   # bit-exact integer draws
+            assert np.max(np.abs(oracle.summarise(gq, p, 1 - p) - ci)) < 1e-9
+        # approximated analysis (R/utilities.R:733-784): resample the posterior, more draws than kept
+        ci2 = f.ppc(0.7352941, 0.01, 0.99, seed=8, n_gen=2000, resample=True)
+        ci_full = f.ppc(0.7352941, 0.01, 0.99, seed=8)
+        assert np.all(np.abs(ci2[..., 0] / ci_full[..., 0] - 1) < 0.2)       # same predictive mean, MC error
+        f.close()
+    finally:
+        m.close()
+
+
+def test_reference_known_answer_bundled_counts(L, bundled):
+    """The reference's only pinned result (tests/testthat/test-ppcSeq.R:11-30, :36-55): on the bundled
+    `counts`, checked genes SLC16A12 / CYP1A1 / ART3 + 50 negative controls, ~ Label, pfp = 1:
+    tot_deleterious_outliers == c(0, 1, 0); the CYP1A1 outlier is sample 11165PP (count 5835)."""
+    import pandas as pd
+    from ppcseq_amd.methods import identify_outliers
+    genes = [str(g) for g in bundled["genes"]]
+    samples = [str(s) for s in bundled["samples"]]
+    G, S = len(genes), len(samples)
+    df = pd.DataFrame({
+        "symbol": np.repeat(genes, S), "sample": np.tile(samples, G), "value": bundled["value"].reshape(-1),
+        "PValue": np.repeat(bundled["PValue"], S), "Label": np.tile(bundled["Label"].astype(str), G)})
+    df["is_significant"] = df["symbol"].isin(["SLC16A12", "CYP1A1", "ART3"])
+    res = identify_outliers(df, formula="~ Label", sample="sample", transcript="symbol", abundance="value",
+                            significance="PValue", do_check="is_significant", percent_false_positive_genes=1,
+                            how_many_negative_controls=50, cores=1, seed=42)
+    assert res["symbol"].tolist() == ["SLC16A12", "CYP1A1", "ART3"]
+    assert res["tot_deleterious_outliers"].tolist() == [0, 1, 0]
+    sw = res.loc[1, "sample_wise_data"]
+    bad = sw[sw["deleterious_outliers"]]
+    assert bad["sample"].tolist() == ["11165PP"] and bad["value"].tolist() == [5835]
+    assert list(sw.columns[:5]) == ["S", "G", "value", "sample", "slope_before_outlier_filtering"]
+
+
+def test_full_size_properties_20k_by_200(L):
+    """BASELINE config 3 size. The oracle needs ~0.15 s per gradient here, so instead of a dense comparison:
+    (1) directional derivative of lp equals grad.v (central differences); (2) every lanes-per-gene
+    instantiation gives the same lp to 1e-12 relative; (3) excluding cells changes lp by exactly the
+    re-included difference (additivity); (4) a short NUTS run keeps the energy error bounded."""
+    d = ind.synth(20000, 200, seed=20253)
+    K = d["K"]
+    m = L.Model(d["counts"], d["X"], d["exposure"], K)
+    try:
+        rng = np.random.default_rng(0)
+        u = rng.uniform(-0.3, 0.3, m.D)
+        u[3:20003] = d["truth"]["intercept"] + rng.normal(0, 0.05, 20000)
+        u[3 + 20000 + K:3 + 20000 + K + 20000] = d["truth"]["sigma_raw"]
+        lp0, g0 = m.log_prob_grad(u)
+        v = rng.normal(size=m.D); v /= np.linalg.norm(v)
+        # central difference; at |lp| ~ 3e7 the fp64 rounding noise of lp (~1e-6) divided by 2h bounds what a
+        # finite difference can resolve, so h is large and the tolerance is 1e-5 relative
+        h = 8e-4
+        fd = (m.log_prob_grad(u + h * v)[0] - m.log_prob_grad(u - h * v)[0]) / (2 * h)
+        assert abs(fd - g0 @ v) <= 1e-5 * max(1.0, abs(fd))
+        for lanes in [4, 8, 16, 32, 64]:
+            m.set_launch(lanes, 0)
+            lp, g = m.log_prob_grad(u)
+            assert abs(lp - lp0) <= 1e-12 * abs(lp0) and np.max(np.abs(g - g0) / (1 + np.abs(g0))) < 1e-11
+        m.set_launch(0, 0)
+        ex1, ex2 = np.array([5, 777, 123456], np.int32), np.array([5, 777, 123456, 3999999], np.int32)
+        m.set_exclusions(ex1); a = m.log_prob_grad(u)[0]
+        m.set_exclusions(ex2); b = m.log_prob_grad(u)[0]
+        m.set_exclusions(np.array([3999999], np.int32)); c = m.log_prob_grad(u)[0]
+        assert abs((lp0 - c) - (a - b)) <= 1e-9 * abs(lp0) * 1e-3
+        m.set_exclusions(None)
+        f = m.fit_nuts(chains=2, iter=30, warmup=30, seed=1)
+        dg = f.diagnostics()
+        f.close()
+        assert dg["n_leapfrog"].min() >= 1 and np.isfinite(dg["stepsize"]).all()
+    finally:
+        m.close()
