@@ -107,6 +107,11 @@ PPCX_API void ppcx_fit_free(ppcx_fit* f);
 PPCX_API void ppcx_do_inference_C(const int* dims, const int* counts, const double* X, const double* exposure_rate,
                          const int* excl, const double* reals, double* ci, double* slope, int* status);
 
+/* Development aid, not part of the reference boundary: mean duration (ms) of `reps` back-to-back launches of
+ * the gene kernel on the command the chains hold after `warm_pairs` launch pairs (n_merge < 0: as is).       */
+PPCX_API int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs, int reps, int n_merge,
+                           double* ms_per_launch, int* cmd_type);
+
 #ifdef __cplusplus
 }
 #endif

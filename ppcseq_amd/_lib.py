@@ -18,7 +18,7 @@ EXPORTS = [
     "ppcx_version", "ppcx_device_count", "ppcx_last_error", "ppcx_model_create", "ppcx_model_set_exclusions",
     "ppcx_model_set_launch", "ppcx_model_get_launch", "ppcx_model_dim", "ppcx_model_destroy", "ppcx_log_prob_grad",
     "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
-    "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C",
+    "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_bench_gene_kernel",
 ]
 
 
@@ -65,6 +65,7 @@ def load() -> C.CDLL:
     lib.ppcx_fit_get_timing.argtypes = [C.c_void_p, dp, C.POINTER(C.c_longlong), dp, C.POINTER(C.c_longlong), dp]
     lib.ppcx_fit_ppc.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_ulonglong, C.c_int, C.c_int, dp, ip]
     lib.ppcx_fit_free.argtypes = [C.c_void_p]
+    lib.ppcx_bench_gene_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.POINTER(C.c_int)]
     lib.ppcx_fit_free.restype = None
     _lib = lib
     return lib
@@ -135,6 +136,11 @@ class Model:
         h = C.c_void_p()
         _check(load().ppcx_fit_nuts(self._h, C.byref(cfg), C.byref(h)))
         return Fit(self, h)
+
+    def bench_gene_kernel(self, nchains=1, warm_pairs=40, reps=50, n_merge=1):
+        ms, t = C.c_double(), C.c_int()
+        _check(load().ppcx_bench_gene_kernel(self._h, nchains, warm_pairs, reps, n_merge, C.byref(ms), C.byref(t)))
+        return ms.value, t.value
 
     def close(self):
         if getattr(self, "_h", None):

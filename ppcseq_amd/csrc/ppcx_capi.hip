@@ -317,6 +317,56 @@ extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, 
   return PPCX_OK;
 }
 
+// Development aid (not part of the reference boundary): time `reps` back-to-back launches of the gene kernel
+// on the command the chains hold after `warm_pairs` launch pairs of a real run. n_merge >= 0 overrides the
+// tree position of that command (number of subtree merges the leaf closes), so every variant is timed on the
+// same work.
+extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs, int reps, int n_merge,
+                                      double* ms_per_launch, int* cmd_type) {
+  if (!m || nchains < 1 || reps < 1 || !ms_per_launch) return fail(PPCX_ERR_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(m->device));
+  choose_launch(m, nchains);
+  Work w;
+  int rc = work_alloc(w, m, nchains);
+  if (rc != PPCX_OK) return rc;
+  NutsConfig nc; memset(&nc, 0, sizeof nc);
+  nc.chains = nchains; nc.iter = 1000000; nc.warmup = 1000000; nc.seed = 1; nc.adapt_delta = 0.8; nc.max_treedepth = 10;
+  nc.init_radius = 2; nc.stepsize0 = 1; nc.init_buffer = 75; nc.term_buffer = 50; nc.window = 25;
+  std::vector<ChainState> states(nchains);
+  for (int c = 0; c < nchains; ++c) state_init(states[c], nc, c, 0);
+  HIPCHK(hipMemcpyAsync(w.states, states.data(), sizeof(ChainState) * nchains, hipMemcpyHostToDevice, m->stream));
+  GeneArgs ga = gene_args(m, w, nullptr, 0);
+  ChainArgs ca; memset(&ca, 0, sizeof ca);
+  ca.d = m->d; ca.states = w.states; ca.cmds = w.cmds; ca.partials = w.partials; ca.nblocks = m->nblocks;
+  ca.hyper_vecs = w.hyper_vecs; ca.done = w.done; ca.iter = nc.iter;
+  hipStream_t st = m->stream;
+  HIPCHK(launch_chain_kernel(ca, nchains, st));
+  for (int i = 0; i < warm_pairs; ++i) {
+    HIPCHK(launch_gene_kernel(m->L, m->CM, ga, m->nblocks, nchains, st));
+    HIPCHK(launch_chain_kernel(ca, nchains, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<Cmd> cmds(nchains);
+  HIPCHK(hipMemcpy(cmds.data(), w.cmds, sizeof(Cmd) * nchains, hipMemcpyDeviceToHost));
+  if (cmd_type) *cmd_type = cmds[0].type;
+  if (n_merge >= 0) for (int c = 0; c < nchains; ++c) if (cmds[c].type == CMD_LEAF) {
+    cmds[c].n_merge = n_merge; cmds[c].subtree_complete = 0; cmds[c].pre_flags = PRE_PROP; cmds[c].prop_slot = n_merge; cmds[c].prop_src = -1;
+    cmds[c].eps *= 1e-3;                         // keep the repeated leapfrogs on a bounded trajectory
+  }
+  HIPCHK(hipMemcpy(w.cmds, cmds.data(), sizeof(Cmd) * nchains, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) HIPCHK(launch_gene_kernel(m->L, m->CM, ga, m->nblocks, nchains, st));
+  HIPCHK(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) HIPCHK(launch_gene_kernel(m->L, m->CM, ga, m->nblocks, nchains, st));
+  HIPCHK(hipEventRecord(e1, st));
+  HIPCHK(hipStreamSynchronize(st));
+  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *ms_per_launch = (double)ms / reps;
+  return PPCX_OK;
+}
+
 extern "C" void ppcx_fit_free(ppcx_fit* f) {
   if (!f) return;
   (void)hipSetDevice(f->m->device);

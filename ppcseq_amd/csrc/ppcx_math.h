@@ -19,6 +19,48 @@
 namespace ppcx {
 
 // ---------------------------------------------------------------------------------------------
+// Lean fp64 reciprocal and logarithm for the per-cell loop. ocml's log()/division are correctly
+// rounded via double-double arithmetic (~65 and ~22 VALU instructions); the cell loop is bound by
+// fp64 issue, so it uses:
+//   fast_rcp : v_rcp_f64 seed + one Newton step (relative error ~1e-16; two FMAs)
+//   fast_log : the classic argument reduction x = 2^k m, m in [sqrt(1/2), sqrt 2), s = f/(2+f),
+//              log m = f - (f^2/2 - s (f^2/2 + R(s^2))) with the 7-term minimax R of Sun's fdlibm
+//              e_log.c (public domain algorithm; max error < 1 ulp), ~30 VALU instructions.
+// Valid for finite x > 0 (x = 1 + exp(t) >= 1 or x = y + phi > 0 in this code); inf/NaN propagate.
+// ---------------------------------------------------------------------------------------------
+PPCX_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(r, fma(-x, r, 1.0), r);
+#else
+  return 1.0 / x;
+#endif
+}
+
+PPCX_HD double fast_log(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double m = __builtin_amdgcn_frexp_mant(x);      // [0.5, 1)
+  int k = __builtin_amdgcn_frexp_exp(x);
+#else
+  int k;
+  double m = frexp(x, &k);
+#endif
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;                               // [sqrt(1/2), sqrt 2)
+  k = lo ? k - 1 : k;
+  const double f = m - 1.0;
+  const double s = f * fast_rcp(2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+  const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)k;
+  // k ln2_hi - ((hfsq - (s (hfsq + R) + k ln2_lo)) - f)
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
+// ---------------------------------------------------------------------------------------------
 // log-gamma and digamma for x > 0 with ONE shared logarithm and ONE reciprocal.
 //   x >= 8 : Stirling series  lgamma(x) = (x-1/2)ln x - x + ln(2pi)/2 + sum B2k/(2k(2k-1)x^(2k-1))
 //            digamma(x) = ln x - 1/(2x) - sum B2k/(2k x^2k)          (Abramowitz & Stegun 6.1.40, 6.3.18)
@@ -48,7 +90,7 @@ PPCX_HD void lgamma_digamma_stirling(double x, double lx, double rx, double* lg,
 
 PPCX_HD void lgamma_digamma(double x, double* lg, double* dg) {
   if (x >= 8.0) {
-    lgamma_digamma_stirling(x, log(x), 1.0 / x, lg, dg);
+    lgamma_digamma_stirling(x, fast_log(x), fast_rcp(x), lg, dg);
   } else {
     // P = prod_{k=0..7}(x+k), P' by the product rule, both in one pass
     double P = x, dP = 1.0;
@@ -60,9 +102,9 @@ PPCX_HD void lgamma_digamma(double x, double* lg, double* dg) {
     }
     const double xs = x + 8.0;
     double l8, d8;
-    lgamma_digamma_stirling(xs, log(xs), 1.0 / xs, &l8, &d8);
-    *lg = l8 - log(P);
-    *dg = d8 - dP / P;
+    lgamma_digamma_stirling(xs, fast_log(xs), fast_rcp(xs), &l8, &d8);
+    *lg = l8 - fast_log(P);
+    *dg = d8 - dP * fast_rcp(P);
   }
 }
 

@@ -83,9 +83,9 @@ struct CellAcc {
 PPCX_HD void cell_core(int y, double u, double phi, double lgphi, double dgphi,
                        double* T1, double* SP, double* T3, double* T4, double* xsig) {
   const double w = 1.0 + u;
-  const double sp = log(w);
+  const double sp = fast_log(w);
   const double x = (double)y + phi;
-  *xsig = x * (u / w);
+  *xsig = x * (u * fast_rcp(w));
   *T1 += x * sp;
   *SP += sp;
   if (y > 0) {                                // y == 0 contributes lgamma(phi)-lgamma(phi) = 0 exactly
