@@ -105,6 +105,7 @@ def main():
         hyp = fit.columns(hyper_cols)                      # [chains, n_keep, 6]
         dg = fit.diagnostics()
         tm = fit.timing()
+        kt = fit.kernel_times()
         lp = dg["lp"]
         ge = np.array([float(tm.grad_evals)])
         if dist_on:
@@ -131,7 +132,7 @@ def main():
             ms = kA_ms / kA_n
             chains_per_launch = kA_chains / kA_n
             achieved = b_grad * chains_per_launch / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "ppcx_gene_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
+            roof = {"bound": "hbm", "kernel": "ppcx_loglik_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
                     "algorithmic_bytes_per_launch": b_grad * chains_per_launch, "avg_launch_ms": round(ms, 5),
                     "timed_launches": int(kA_n)}
@@ -151,6 +152,7 @@ def main():
                        "ess_last_step": [round(float(x), 1) for x in ess_detail],
                        "grad_evals": tot_grad, "mean_treedepth": round(float(np.mean(depth_mean)), 2),
                        "divergent_after_warmup": div_total,
+                       "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
                        "us_per_grad_eval_per_chain": round(1e6 * tot_time * world * nch / max(tot_grad, 1), 2)},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -88,9 +88,14 @@ PPCX_API int ppcx_fit_get_columns(ppcx_fit* f, int n_cols, const int32_t* cols, 
 PPCX_API int ppcx_fit_get_diagnostics(ppcx_fit* f, double* lp, double* stepsize, int32_t* treedepth,
                              int32_t* n_leapfrog, int32_t* divergent, double* accept);
 /* wall seconds of the sampling loop, gradient evaluations summed over chains, and the mean duration
- * (ms) / count of the HIP-event-timed gene-kernel launches with the chain-launches they covered    */
+ * (ms) / count of the HIP-event-timed log-likelihood-kernel launches with the chain-launches they covered    */
 PPCX_API int ppcx_fit_get_timing(ppcx_fit* f, double* seconds, long long* grad_evals, double* gene_kernel_ms_mean,
                         long long* gene_kernel_samples, double* gene_kernel_chain_launches_mean);
+
+/* mean HIP-event durations (ms) of the three kernels of a leapfrog over the timed launches, and the number of
+ * (loglik, close, update) launch triples the run issued                                                   */
+PPCX_API int ppcx_fit_get_kernel_times(ppcx_fit* f, double* loglik_ms, double* close_ms, double* update_ms,
+                              long long* launch_triples);
 
 /* generated quantities + credible intervals (.stan:259-266; R/utilities.R:685-703 full analysis,
  * :733-784 approximated analysis when resample != 0 and n_gen = how_many_posterior_draws).

@@ -12,13 +12,13 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libppcx.so")
+LIB_PATH = os.environ.get("PPCX_LIB", os.path.join(_HERE, "libppcx.so"))   # PPCX_LIB: development builds
 
 EXPORTS = [
     "ppcx_version", "ppcx_device_count", "ppcx_last_error", "ppcx_model_create", "ppcx_model_set_exclusions",
     "ppcx_model_set_launch", "ppcx_model_get_launch", "ppcx_model_dim", "ppcx_model_destroy", "ppcx_log_prob_grad",
     "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
-    "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_bench_gene_kernel",
+    "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_bench_gene_kernel",
 ]
 
 
@@ -63,6 +63,7 @@ def load() -> C.CDLL:
     lib.ppcx_fit_get_columns.argtypes = [C.c_void_p, C.c_int, ip, dp]
     lib.ppcx_fit_get_diagnostics.argtypes = [C.c_void_p, dp, dp, ip, ip, ip, dp]
     lib.ppcx_fit_get_timing.argtypes = [C.c_void_p, dp, C.POINTER(C.c_longlong), dp, C.POINTER(C.c_longlong), dp]
+    lib.ppcx_fit_get_kernel_times.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_longlong)]
     lib.ppcx_fit_ppc.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_ulonglong, C.c_int, C.c_int, dp, ip]
     lib.ppcx_fit_free.argtypes = [C.c_void_p]
     lib.ppcx_bench_gene_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.POINTER(C.c_int)]
@@ -199,6 +200,12 @@ class Fit:
         ge, ns = C.c_longlong(), C.c_longlong()
         _check(load().ppcx_fit_get_timing(self._h, C.byref(s), C.byref(ge), C.byref(ms), C.byref(ns), C.byref(cl)))
         return Timing(s.value, ge.value, ms.value, ns.value, cl.value)
+
+    def kernel_times(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        n = C.c_longlong()
+        _check(load().ppcx_fit_get_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return dict(loglik_ms=a.value, close_ms=b.value, update_ms=c.value, launch_triples=n.value)
 
     def ppc(self, truncation_compensation=1.0, p_lo=0.025, p_hi=0.975, seed=1, n_gen=0, resample=False,
             return_counts_rng=False):

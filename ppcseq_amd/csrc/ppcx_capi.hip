@@ -6,7 +6,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <chrono>
+#include <stdlib.h>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/ppcx.h"
 #include "ppcx_kernels.h"
@@ -43,6 +45,7 @@ struct ppcx_fit {
   int *d_treedepth = nullptr, *d_nleap = nullptr, *d_div = nullptr;
   double seconds = 0; long long grad_evals = 0;
   double kA_ms_mean = 0; long long kA_samples = 0; double kA_chain_launches_mean = 0;
+  double kC_ms_mean = 0, kU_ms_mean = 0; long long launch_triples = 0;
 };
 
 extern "C" int ppcx_version(void) { return 100; }
@@ -52,7 +55,7 @@ extern "C" const char* ppcx_last_error(void) { return g_err.c_str(); }
 // choose lanes-per-gene L and blocks per chain: maximise (lane utilisation) x (SIMD balance)
 static void choose_launch(ppcx_model* m, int nchains) {
   const int G = m->d.G, S = m->d.S;
-  const double slots = 1024.0 * 2.0;           // SIMDs x resident waves per SIMD (VGPR-limited)
+  const double slots = 1024.0;                 // SIMDs: waves are spread evenly when they are all resident
   int bestL = 64; double best = -1.0;
   for (int L = 1; L <= 64; L <<= 1) {
     const int iters = (S + L - 1) / L;
@@ -185,67 +188,132 @@ extern "C" void ppcx_nuts_config_default(ppcx_nuts_config* c) {
   c->chain_id_offset = 0;
 }
 
-// device scratch of one run of the launch pump
+// device scratch of one run of the launch pump. States, commands, hyper-coordinate vectors and the T0 slab
+// are double-buffered: update launch k reads buffer k&1 and writes buffer (k+1)&1.
 struct Work {
-  double *vecs = nullptr, *hyper_vecs = nullptr, *partials = nullptr;
-  Cmd* cmds = nullptr; ChainState* states = nullptr; int* done = nullptr;
+  double *vecs = nullptr, *hyper_vecs[2] = {nullptr, nullptr}, *partials = nullptr, *t0[2] = {nullptr, nullptr}, *sums = nullptr;
+  Cmd* cmds[2] = {nullptr, nullptr}; ChainState* states[2] = {nullptr, nullptr}; int* done = nullptr;
   int* done_host = nullptr;
-  long Dpad = 0;
+  long Dpad = 0; int nb_update = 1, nb_close = 1; long launches = 0;
+  hipStream_t stream = nullptr; bool own_stream = false;
   ~Work() {
-    (void)hipFree(vecs); (void)hipFree(hyper_vecs); (void)hipFree(partials); (void)hipFree(cmds);
-    (void)hipFree(states); (void)hipFree(done);
+    (void)hipFree(vecs); (void)hipFree(partials); (void)hipFree(done); (void)hipFree(sums);
+    for (int i = 0; i < 2; ++i) { (void)hipFree(hyper_vecs[i]); (void)hipFree(t0[i]); (void)hipFree(cmds[i]); (void)hipFree(states[i]); }
     if (done_host) (void)hipHostFree(done_host);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 };
 
 static int work_alloc(Work& w, ppcx_model* m, int nchains) {
   const int D = m->d.D;
+  if (!w.stream) w.stream = m->stream;
   w.Dpad = ((long)D + 31) / 32 * 32;
+  w.nb_update = (D + 255) / 256; if (w.nb_update > 1024) w.nb_update = 1024; if (w.nb_update < 1) w.nb_update = 1;
   HIPCHK(hipMalloc(&w.vecs, sizeof(double) * (size_t)nchains * V_COUNT * w.Dpad));
-  HIPCHK(hipMalloc(&w.hyper_vecs, sizeof(double) * (size_t)nchains * V_COUNT * 8));
-  HIPCHK(hipMalloc(&w.partials, sizeof(double) * (size_t)nchains * m->nblocks * PT_COUNT));
-  HIPCHK(hipMalloc(&w.cmds, sizeof(Cmd) * nchains));
-  HIPCHK(hipMalloc(&w.states, sizeof(ChainState) * nchains));
+  w.nb_close = (m->d.G + 255) / 256;
+  HIPCHK(hipMalloc(&w.partials, sizeof(double) * (size_t)nchains * w.nb_close * PT_COUNT));
+  HIPCHK(hipMalloc(&w.sums, sizeof(double) * (size_t)nchains * (5 + m->CM) * m->d.G));
+  HIPCHK(hipMemsetAsync(w.sums, 0, sizeof(double) * (size_t)nchains * (5 + m->CM) * m->d.G, w.stream));
   HIPCHK(hipMalloc(&w.done, sizeof(int) * nchains));
   HIPCHK(hipHostMalloc(&w.done_host, sizeof(int) * nchains));
-  HIPCHK(hipMemsetAsync(w.vecs, 0, sizeof(double) * (size_t)nchains * V_COUNT * w.Dpad, m->stream));
-  HIPCHK(hipMemsetAsync(w.hyper_vecs, 0, sizeof(double) * (size_t)nchains * V_COUNT * 8, m->stream));
-  HIPCHK(hipMemsetAsync(w.partials, 0, sizeof(double) * (size_t)nchains * m->nblocks * PT_COUNT, m->stream));
-  HIPCHK(hipMemsetAsync(w.cmds, 0, sizeof(Cmd) * nchains, m->stream));
-  HIPCHK(hipMemsetAsync(w.done, 0, sizeof(int) * nchains, m->stream));
-  for (int c = 0; c < nchains; ++c) {          // inverse metric starts at identity
-    HIPCHK(launch_fill_kernel(w.vecs + ((size_t)c * V_COUNT + V_MINV) * w.Dpad, w.Dpad, 1.0, m->stream));
-    HIPCHK(launch_fill_kernel(w.hyper_vecs + ((size_t)c * V_COUNT + V_MINV) * 8, 8, 1.0, m->stream));
+  for (int i = 0; i < 2; ++i) {
+    HIPCHK(hipMalloc(&w.hyper_vecs[i], sizeof(double) * (size_t)nchains * V_COUNT * 8));
+    HIPCHK(hipMalloc(&w.t0[i], sizeof(double) * (size_t)nchains * w.nb_update));
+    HIPCHK(hipMalloc(&w.cmds[i], sizeof(Cmd) * nchains));
+    HIPCHK(hipMalloc(&w.states[i], sizeof(ChainState) * nchains));
+    HIPCHK(hipMemsetAsync(w.hyper_vecs[i], 0, sizeof(double) * (size_t)nchains * V_COUNT * 8, w.stream));
+    HIPCHK(hipMemsetAsync(w.t0[i], 0, sizeof(double) * (size_t)nchains * w.nb_update, w.stream));
+    HIPCHK(hipMemsetAsync(w.cmds[i], 0, sizeof(Cmd) * nchains, w.stream));
+    HIPCHK(hipMemsetAsync(w.states[i], 0, sizeof(ChainState) * nchains, w.stream));
   }
+  HIPCHK(hipMemsetAsync(w.vecs, 0, sizeof(double) * (size_t)nchains * V_COUNT * w.Dpad, w.stream));
+  HIPCHK(hipMemsetAsync(w.partials, 0, sizeof(double) * (size_t)nchains * w.nb_close * PT_COUNT, w.stream));
+  HIPCHK(hipMemsetAsync(w.done, 0, sizeof(int) * nchains, w.stream));
+  for (int c = 0; c < nchains; ++c) {          // inverse metric starts at identity
+    HIPCHK(launch_fill_kernel(w.vecs + ((size_t)c * V_COUNT + V_MINV) * w.Dpad, w.Dpad, 1.0, w.stream));
+    HIPCHK(launch_fill_kernel(w.hyper_vecs[0] + ((size_t)c * V_COUNT + V_MINV) * 8, 8, 1.0, w.stream));
+  }
+  w.launches = 0;
   return PPCX_OK;
 }
 
-struct PumpStats { double kA_ms_sum = 0; long long kA_samples = 0; double chain_launches = 0; long long pairs = 0; };
+struct RunIO {                  // output buffers of a run (device pointers, may be null)
+  double* draws = nullptr; long draws_stride = 0; int n_keep = 0, iter = 0;
+  double *lp = nullptr, *stepsize = nullptr, *accept = nullptr; int *treedepth = nullptr, *nleap = nullptr, *div = nullptr;
+};
 
-// Launch (A,B) pairs until every chain reports done. `max_pairs` bounds the loop.
-static int pump(ppcx_model* m, Work& w, int nchains, const GeneArgs& ga, const ChainArgs& ca, long long max_pairs,
-                bool time_kernels, PumpStats* stats) {
-  hipStream_t st = m->stream;
-  HIPCHK(launch_chain_kernel(ca, nchains, st));                 // PH_START -> first command
+static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
+  const int in = (int)(w.launches & 1), out = in ^ 1;
+  UpdateArgs ua;
+  ua.d = m->d;
+  ua.states_in = w.states[in]; ua.states_out = w.states[out];
+  ua.cmds_in = w.cmds[in]; ua.cmds_out = w.cmds[out];
+  ua.hyper_in = w.hyper_vecs[in]; ua.hyper_out = w.hyper_vecs[out];
+  ua.t0_in = w.t0[in]; ua.t0_out = w.t0[out];
+  ua.partials = w.partials; ua.nblocks_close = w.nb_close;
+  ua.vecs = w.vecs; ua.Dpad = w.Dpad;
+  ua.draws = io.draws; ua.draws_chain_stride = io.draws_stride; ua.n_keep = io.n_keep; ua.iter = io.iter;
+  ua.out_lp = io.lp; ua.out_stepsize = io.stepsize; ua.out_treedepth = io.treedepth; ua.out_n_leapfrog = io.nleap;
+  ua.out_divergent = io.div; ua.out_accept = io.accept; ua.done = w.done;
+  hipError_t e = launch_update_kernel(ua, w.nb_update, nchains, w.stream);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("update kernel: ") + hipGetErrorString(e));
+  w.launches++;
+  return PPCX_OK;
+}
+static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
+  LoglikArgs la;
+  la.d = m->d; la.counts = m->d_counts; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
+  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums;
+  hipError_t e = launch_loglik_kernel(m->L, m->CM, la, m->nblocks, nchains, w.stream);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("loglik kernel: ") + hipGetErrorString(e));
+  return PPCX_OK;
+}
+static int launch_close(ppcx_model* m, Work& w, int nchains) {
+  CloseArgs ca;
+  ca.d = m->d; ca.Sy = m->d_Sy; ca.SyE = m->d_SyE; ca.SyX = m->d_SyX; ca.ncell = m->d_ncell; ca.Lg1 = m->d_Lg1;
+  ca.sums = w.sums; ca.vecs = w.vecs; ca.Dpad = w.Dpad; ca.cmds = w.cmds[w.launches & 1]; ca.partials = w.partials;
+  hipError_t e = launch_close_kernel(m->CM, ca, w.nb_close, nchains, w.stream);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("close kernel: ") + hipGetErrorString(e));
+  return PPCX_OK;
+}
+static int launch_gene(ppcx_model* m, Work& w, int nchains) {   // one gradient evaluation = loglik + close
+  int rc = launch_loglik(m, w, nchains);
+  return rc != PPCX_OK ? rc : launch_close(m, w, nchains);
+}
+static ChainState* current_states(Work& w) { return w.states[w.launches & 1]; }
+static double* current_hyper(Work& w) { return w.hyper_vecs[w.launches & 1]; }
+
+struct PumpStats { double kA_ms_sum = 0, kC_ms_sum = 0, kU_ms_sum = 0; long long kA_samples = 0; double chain_launches = 0; long long pairs = 0; };
+
+// Launch (gene, update) pairs until every chain reports done. `max_pairs` bounds the loop.
+static int pump(ppcx_model* m, Work& w, int nchains, const RunIO& io, long long max_pairs, bool time_kernels,
+                PumpStats* stats) {
+  hipStream_t st = w.stream;
+  int rc = launch_update(m, w, nchains, io);                   // PH_START -> first command
+  if (rc != PPCX_OK) return rc;
   const int batch = 32, sample_every = 16;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (time_kernels) { HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1)); }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  if (time_kernels) { HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1)); HIPCHK(hipEventCreate(&ev2)); HIPCHK(hipEventCreate(&ev3)); }
   long long pairs = 0; int n_done = 0;
-  int rc = PPCX_OK;
   while (true) {
     bool sampled = false;
     for (int i = 0; i < batch; ++i, ++pairs) {
       const bool smp = time_kernels && !sampled && (pairs / batch) % sample_every == 0 && i == batch / 2;
       if (smp) HIPCHK(hipEventRecord(ev0, st));
-      HIPCHK(launch_gene_kernel(m->L, m->CM, ga, m->nblocks, nchains, st));
+      if ((rc = launch_loglik(m, w, nchains)) != PPCX_OK) return rc;
       if (smp) { HIPCHK(hipEventRecord(ev1, st)); sampled = true; }
-      HIPCHK(launch_chain_kernel(ca, nchains, st));
+      if ((rc = launch_close(m, w, nchains)) != PPCX_OK) return rc;
+      if (smp) HIPCHK(hipEventRecord(ev2, st));
+      if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
+      if (smp) HIPCHK(hipEventRecord(ev3, st));
     }
     HIPCHK(hipMemcpyAsync(w.done_host, w.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (sampled && n_done == 0) {               // only launches in which every chain was still active
       float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
       stats->kA_ms_sum += ms; stats->kA_samples++; stats->chain_launches += nchains;
+      HIPCHK(hipEventElapsedTime(&ms, ev1, ev2)); stats->kC_ms_sum += ms;
+      HIPCHK(hipEventElapsedTime(&ms, ev2, ev3)); stats->kU_ms_sum += ms;
     }
     n_done = 0;
     for (int c = 0; c < nchains; ++c) {
@@ -258,17 +326,10 @@ static int pump(ppcx_model* m, Work& w, int nchains, const GeneArgs& ga, const C
   }
   if (ev0) (void)hipEventDestroy(ev0);
   if (ev1) (void)hipEventDestroy(ev1);
+  if (ev2) (void)hipEventDestroy(ev2);
+  if (ev3) (void)hipEventDestroy(ev3);
   stats->pairs = pairs;
   return rc;
-}
-
-static GeneArgs gene_args(ppcx_model* m, Work& w, double* draws, long draws_stride) {
-  GeneArgs ga;
-  ga.d = m->d; ga.counts = m->d_counts; ga.sampleE = m->d_E; ga.exposure = m->d_expo; ga.X = m->d_X;
-  ga.Sy = m->d_Sy; ga.SyE = m->d_SyE; ga.SyX = m->d_SyX; ga.ncell = m->d_ncell; ga.Lg1 = m->d_Lg1;
-  ga.vecs = w.vecs; ga.Dpad = w.Dpad; ga.cmds = w.cmds; ga.partials = w.partials;
-  ga.draws = draws; ga.draws_chain_stride = draws_stride;
-  return ga;
 }
 
 extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, double* lp, double* grad) {
@@ -287,7 +348,7 @@ extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, 
     cfg.chains = nb; cfg.iter = 0; cfg.warmup = 0; cfg.seed = 0; cfg.adapt_delta = 0.8; cfg.max_treedepth = 10;
     cfg.init_radius = 2; cfg.stepsize0 = 1; cfg.init_buffer = 75; cfg.term_buffer = 50; cfg.window = 25; cfg.chain_id_offset = 0;
     for (int c = 0; c < nb; ++c) state_init(states[c], cfg, c, 1);
-    HIPCHK(hipMemcpyAsync(w.states, states.data(), sizeof(ChainState) * nb, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(w.states[0], states.data(), sizeof(ChainState) * nb, hipMemcpyHostToDevice, m->stream));
     std::vector<double> hq((size_t)nb * V_COUNT * 8, 0.0);
     for (int c = 0; c < nb; ++c) {
       const double* uc = u + (size_t)(p0 + c) * D;
@@ -295,16 +356,13 @@ extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, 
       for (int k = 0; k < 6; ++k) hq[((size_t)c * V_COUNT + V_Q1) * 8 + k] = uc[hyper_index(m->d, k)];
       for (int k = 0; k < 8; ++k) hq[((size_t)c * V_COUNT + V_MINV) * 8 + k] = 1.0;
     }
-    HIPCHK(hipMemcpyAsync(w.hyper_vecs, hq.data(), sizeof(double) * hq.size(), hipMemcpyHostToDevice, m->stream));
-    GeneArgs ga = gene_args(m, w, nullptr, 0);
-    ChainArgs ca; memset(&ca, 0, sizeof ca);
-    ca.d = m->d; ca.states = w.states; ca.cmds = w.cmds; ca.partials = w.partials; ca.nblocks = m->nblocks;
-    ca.hyper_vecs = w.hyper_vecs; ca.done = w.done;
+    HIPCHK(hipMemcpyAsync(w.hyper_vecs[0], hq.data(), sizeof(double) * hq.size(), hipMemcpyHostToDevice, m->stream));
+    RunIO io;
     PumpStats ps;
-    rc = pump(m, w, nb, ga, ca, 64, false, &ps);
+    rc = pump(m, w, nb, io, 64, false, &ps);
     if (rc != PPCX_OK) return rc;
-    HIPCHK(hipMemcpy(states.data(), w.states, sizeof(ChainState) * nb, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(hq.data(), w.hyper_vecs, sizeof(double) * hq.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(states.data(), current_states(w), sizeof(ChainState) * nb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hq.data(), current_hyper(w), sizeof(double) * hq.size(), hipMemcpyDeviceToHost));
     for (int c = 0; c < nb; ++c) {
       lp[p0 + c] = states[c].lp_eval;
       if (grad) {
@@ -323,6 +381,8 @@ extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, 
 // same work.
 extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs, int reps, int n_merge,
                                       double* ms_per_launch, int* cmd_type) {
+  const int which = n_merge >= 100 ? (n_merge / 100) : 0;      // 0 loglik, 1 close, 2 both (development aid)
+  if (n_merge >= 100) n_merge %= 100;
   if (!m || nchains < 1 || reps < 1 || !ms_per_launch) return fail(PPCX_ERR_ARG, "bad arguments");
   HIPCHK(hipSetDevice(m->device));
   choose_launch(m, nchains);
@@ -334,31 +394,29 @@ extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs
   nc.init_radius = 2; nc.stepsize0 = 1; nc.init_buffer = 75; nc.term_buffer = 50; nc.window = 25;
   std::vector<ChainState> states(nchains);
   for (int c = 0; c < nchains; ++c) state_init(states[c], nc, c, 0);
-  HIPCHK(hipMemcpyAsync(w.states, states.data(), sizeof(ChainState) * nchains, hipMemcpyHostToDevice, m->stream));
-  GeneArgs ga = gene_args(m, w, nullptr, 0);
-  ChainArgs ca; memset(&ca, 0, sizeof ca);
-  ca.d = m->d; ca.states = w.states; ca.cmds = w.cmds; ca.partials = w.partials; ca.nblocks = m->nblocks;
-  ca.hyper_vecs = w.hyper_vecs; ca.done = w.done; ca.iter = nc.iter;
+  HIPCHK(hipMemcpyAsync(w.states[0], states.data(), sizeof(ChainState) * nchains, hipMemcpyHostToDevice, m->stream));
+  RunIO io; io.iter = nc.iter;
   hipStream_t st = m->stream;
-  HIPCHK(launch_chain_kernel(ca, nchains, st));
+  if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
   for (int i = 0; i < warm_pairs; ++i) {
-    HIPCHK(launch_gene_kernel(m->L, m->CM, ga, m->nblocks, nchains, st));
-    HIPCHK(launch_chain_kernel(ca, nchains, st));
+    if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
+    if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
   }
   HIPCHK(hipStreamSynchronize(st));
+  Cmd* dcmds = w.cmds[w.launches & 1];
   std::vector<Cmd> cmds(nchains);
-  HIPCHK(hipMemcpy(cmds.data(), w.cmds, sizeof(Cmd) * nchains, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cmds.data(), dcmds, sizeof(Cmd) * nchains, hipMemcpyDeviceToHost));
   if (cmd_type) *cmd_type = cmds[0].type;
   if (n_merge >= 0) for (int c = 0; c < nchains; ++c) if (cmds[c].type == CMD_LEAF) {
-    cmds[c].n_merge = n_merge; cmds[c].subtree_complete = 0; cmds[c].pre_flags = PRE_PROP; cmds[c].prop_slot = n_merge; cmds[c].prop_src = -1;
-    cmds[c].eps *= 1e-3;                         // keep the repeated leapfrogs on a bounded trajectory
+    cmds[c].n_merge = n_merge; cmds[c].subtree_complete = 0;
+    cmds[c].eps *= 1e-3;                         // keep the repeated second half kicks on a bounded trajectory
   }
-  HIPCHK(hipMemcpy(w.cmds, cmds.data(), sizeof(Cmd) * nchains, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dcmds, cmds.data(), sizeof(Cmd) * nchains, hipMemcpyHostToDevice));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) HIPCHK(launch_gene_kernel(m->L, m->CM, ga, m->nblocks, nchains, st));
+  for (int i = 0; i < 3; ++i) if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) HIPCHK(launch_gene_kernel(m->L, m->CM, ga, m->nblocks, nchains, st));
+  for (int i = 0; i < reps; ++i) if ((rc = (which == 1 ? launch_close(m, w, nchains) : (which == 2 ? launch_gene(m, w, nchains) : launch_loglik(m, w, nchains)))) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
@@ -405,33 +463,66 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   FHIP(hipMemsetAsync(f->d_treedepth, 0, sizeof(int) * (size_t)nch * iter, m->stream));
   FHIP(hipMemsetAsync(f->d_nleap, 0, sizeof(int) * (size_t)nch * iter, m->stream));
   FHIP(hipMemsetAsync(f->d_div, 0, sizeof(int) * (size_t)nch * iter, m->stream));
-  Work w;
-  int rc = work_alloc(w, m, nch);
-  if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }
-  std::vector<ChainState> states(nch);
-  for (int c = 0; c < nch; ++c) state_init(states[c], nc, c, 0);
-  FHIP(hipMemcpyAsync(w.states, states.data(), sizeof(ChainState) * nch, hipMemcpyHostToDevice, m->stream));
-  GeneArgs ga = gene_args(m, w, f->d_draws, (long)n_keep * D);
-  ChainArgs ca; memset(&ca, 0, sizeof ca);
-  ca.d = m->d; ca.states = w.states; ca.cmds = w.cmds; ca.partials = w.partials; ca.nblocks = m->nblocks;
-  ca.hyper_vecs = w.hyper_vecs; ca.draws = f->d_draws; ca.draws_chain_stride = (long)n_keep * D;
-  ca.n_keep = n_keep; ca.iter = iter;
-  ca.out_lp = f->d_lp; ca.out_stepsize = f->d_stepsize; ca.out_treedepth = f->d_treedepth;
-  ca.out_n_leapfrog = f->d_nleap; ca.out_divergent = f->d_div; ca.out_accept = f->d_accept; ca.done = w.done;
   FHIP(hipStreamSynchronize(m->stream));
+  // Chains can be split into groups that run on their own streams from their own host threads
+  // (PPCX_STREAM_GROUPS=n): while one group sits in its latency-bound close/update kernels the other group's
+  // log-likelihood kernel has the CUs. Default 1: a single in-order stream keeps per-kernel timings clean.
+  int ngrp = 1;
+  if (const char* e = getenv("PPCX_STREAM_GROUPS")) { int v = atoi(e); if (v >= 1) ngrp = v < nch ? v : nch; }
+  struct Group { int c0 = 0, n = 0; Work w; RunIO io; PumpStats ps; int rc = PPCX_OK; std::string err; long long leap = 0; };
+  std::vector<Group> grp(ngrp);
   const long long max_pairs = (long long)iter * ((1LL << cfg->max_treedepth) + 8) + 100000;
-  PumpStats ps;
+  for (int g = 0; g < ngrp; ++g) {
+    Group& G = grp[g];
+    G.c0 = (int)((long long)nch * g / ngrp); G.n = (int)((long long)nch * (g + 1) / ngrp) - G.c0;
+    if (g > 0) { FHIP(hipStreamCreateWithFlags(&G.w.stream, hipStreamNonBlocking)); G.w.own_stream = true; }
+    int rc = work_alloc(G.w, m, G.n);
+    if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }
+    std::vector<ChainState> states(G.n);
+    NutsConfig ncg = nc; ncg.chain_id_offset = nc.chain_id_offset + G.c0;
+    for (int c = 0; c < G.n; ++c) state_init(states[c], ncg, c, 0);
+    FHIP(hipMemcpy(G.w.states[0], states.data(), sizeof(ChainState) * G.n, hipMemcpyHostToDevice));
+    const size_t c0 = (size_t)G.c0;
+    G.io.draws = f->d_draws ? f->d_draws + c0 * n_keep * D : nullptr; G.io.draws_stride = (long)n_keep * D;
+    G.io.n_keep = n_keep; G.io.iter = iter;
+    G.io.lp = f->d_lp ? f->d_lp + c0 * n_keep : nullptr;
+    G.io.stepsize = f->d_stepsize + c0 * iter; G.io.accept = f->d_accept + c0 * iter;
+    G.io.treedepth = f->d_treedepth + c0 * iter; G.io.nleap = f->d_nleap + c0 * iter; G.io.div = f->d_div + c0 * iter;
+    FHIP(hipStreamSynchronize(G.w.stream));
+  }
   const auto t0 = std::chrono::steady_clock::now();
-  rc = pump(m, w, nch, ga, ca, max_pairs, true, &ps);
+  auto run_group = [&](Group* G) {
+    (void)hipSetDevice(m->device);
+    G->rc = pump(m, G->w, G->n, G->io, max_pairs, true, &G->ps);
+    if (G->rc != PPCX_OK) { G->err = g_err; return; }
+    std::vector<ChainState> states(G->n);
+    if (hipMemcpy(states.data(), current_states(G->w), sizeof(ChainState) * G->n, hipMemcpyDeviceToHost) != hipSuccess) {
+      G->rc = PPCX_ERR_HIP; G->err = "reading back the chain states failed"; return;
+    }
+    for (int c = 0; c < G->n; ++c) G->leap += states[c].total_leapfrogs;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int g = 1; g < ngrp; ++g) th.emplace_back(run_group, &grp[g]);
+    run_group(&grp[0]);
+    for (auto& t : th) t.join();
+  }
   const auto t1 = std::chrono::steady_clock::now();
-  if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }
+  for (int g = 0; g < ngrp; ++g) if (grp[g].rc != PPCX_OK) { const int rc = grp[g].rc; const std::string e = grp[g].err; ppcx_fit_free(f); return fail(rc, e); }
   f->seconds = std::chrono::duration<double>(t1 - t0).count();
-  FHIP(hipMemcpy(states.data(), w.states, sizeof(ChainState) * nch, hipMemcpyDeviceToHost));
   f->grad_evals = 0;
-  for (int c = 0; c < nch; ++c) f->grad_evals += states[c].total_leapfrogs;
+  PumpStats ps;
+  for (int g = 0; g < ngrp; ++g) {
+    f->grad_evals += grp[g].leap;
+    ps.kA_ms_sum += grp[g].ps.kA_ms_sum; ps.kC_ms_sum += grp[g].ps.kC_ms_sum; ps.kU_ms_sum += grp[g].ps.kU_ms_sum;
+    ps.kA_samples += grp[g].ps.kA_samples; ps.chain_launches += grp[g].ps.chain_launches; ps.pairs += grp[g].ps.pairs;
+  }
   f->kA_samples = ps.kA_samples;
   f->kA_ms_mean = ps.kA_samples ? ps.kA_ms_sum / (double)ps.kA_samples : 0.0;
   f->kA_chain_launches_mean = ps.kA_samples ? ps.chain_launches / (double)ps.kA_samples : 0.0;
+  f->kC_ms_mean = ps.kA_samples ? ps.kC_ms_sum / (double)ps.kA_samples : 0.0;
+  f->kU_ms_mean = ps.kA_samples ? ps.kU_ms_sum / (double)ps.kA_samples : 0.0;
+  f->launch_triples = ps.pairs;
   *out = f;
   return PPCX_OK;
 }
@@ -483,6 +574,15 @@ extern "C" int ppcx_fit_get_diagnostics(ppcx_fit* f, double* lp, double* stepsiz
   if (n_leapfrog) HIPCHK(hipMemcpy(n_leapfrog, f->d_nleap, sizeof(int) * ni, hipMemcpyDeviceToHost));
   if (divergent) HIPCHK(hipMemcpy(divergent, f->d_div, sizeof(int) * ni, hipMemcpyDeviceToHost));
   if (accept) HIPCHK(hipMemcpy(accept, f->d_accept, sizeof(double) * ni, hipMemcpyDeviceToHost));
+  return PPCX_OK;
+}
+extern "C" int ppcx_fit_get_kernel_times(ppcx_fit* f, double* loglik_ms, double* close_ms, double* update_ms,
+                                         long long* launch_triples) {
+  if (!f) return fail(PPCX_ERR_ARG, "fit is NULL");
+  if (loglik_ms) *loglik_ms = f->kA_ms_mean;
+  if (close_ms) *close_ms = f->kC_ms_mean;
+  if (update_ms) *update_ms = f->kU_ms_mean;
+  if (launch_triples) *launch_triples = f->launch_triples;
   return PPCX_OK;
 }
 extern "C" int ppcx_fit_get_timing(ppcx_fit* f, double* seconds, long long* grad_evals, double* gene_kernel_ms_mean,

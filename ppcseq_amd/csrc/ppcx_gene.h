@@ -1,6 +1,8 @@
-// ppcx_gene.h -- the per-gene body of kernel A, split into the three phases between which the
-// wavefront combines partial sums:  gene_begin  ->  gene_cells (per lane)  ->  [L-lane butterfly]
-// ->  gene_end  ->  tree bookkeeping (coord_merge_dots / coord_store_slot / coord_top_dots).
+// ppcx_gene.h -- the per-gene bodies of the kernels:
+//   log-likelihood kernel : gene_load -> gene_consts -> gene_cells (per lane) -> [L-lane butterfly] -> per-gene sums
+//   close kernel          : gene_load -> gene_finish -> tree bookkeeping (coord_merge_dots / coord_store_slot /
+//                           coord_top_dots)
+//   update kernel         : chain_step (scalar state machine) and coord_update (per coordinate)
 // Shared by the gfx950 kernel (ppcx_kernels.hip) and the CPU emulation harness in tests/emul.
 #pragma once
 #include "ppcx_nuts.h"
@@ -11,83 +13,105 @@ template <int CM>
 struct GeneCtx {
   static constexpr int NCM = CM + 1;          // coordinates a gene can own: intercept, sigma_raw, CM-1 slopes
   int gg, ncoord;
-  bool active, writer, has_slopes, fast;
+  bool active, has_slopes, fast;
   int idx[NCM];
-  double minv[NCM], ph[NCM], qn[NCM];
   GeneParams<CM> gp;
-  double T0;
 };
 
-// pre-operations, half kick + drift of the gene's coordinates, per-gene constants
+// number of per-gene sums handed from the log-likelihood kernel to the close kernel: T1, SP, T2u, T3, T4, T2x[CM]
+template <int CM> struct GeneSums { static constexpr int N = 5 + CM; };
+
+// load the gene's (already drifted) coordinates: coefficients, sigma_raw, phi
 template <int CM>
-PPCX_HD void gene_begin(const Dims& d, const Cmd& c, const VecRef& v, int g, bool lane_is_writer, double* draws,
-                        GeneCtx<CM>& x) {
+PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, GeneCtx<CM>& x) {
   constexpr int NCM = CM + 1;
   x.active = g < d.G;
-  x.writer = x.active && lane_is_writer;
   x.gg = x.active ? g : 0;
   const int C = d.C;
   const int nslope = x.gg < d.K ? (C - 1 > 1 ? C - 1 : 1) : 0;   // alpha_sub_1 exists even for C == 1 (.stan:189)
   x.ncoord = x.active ? 2 + nslope : 0;
-  x.T0 = 0.0;
-  const double eps = c.eps;
+  double q[NCM];
 #pragma unroll
   for (int j = 0; j < NCM; ++j) {
     x.idx[j] = j == 0 ? d.off_intercept + x.gg : (j == 1 ? d.off_sigma_raw + x.gg : coef_index(d, j - 1, x.gg));
-    CoordVals cv{0.0, 0.0, 0.0, 1.0};
-    if (j < x.ncoord) cv = coord_pre(c, v, x.idx[j], x.idx[j], x.writer, draws, d.D, c.k0, c.k1, &x.T0);
-    x.minv[j] = cv.minv;
-    x.ph[j] = cv.p + 0.5 * eps * cv.g;         // half kick
-    x.qn[j] = cv.q + eps * cv.minv * x.ph[j];  // drift
+    q[j] = j < x.ncoord ? v.at(V_Q0 + 3 * c.dir, x.idx[j]) : 0.0;
   }
   x.has_slopes = x.active && x.gg < d.K && C >= 2;
   x.fast = d.x0_is_one && !x.has_slopes;
-  x.gp.coef[0] = x.qn[0];
+  x.gp.coef[0] = q[0];
 #pragma unroll
-  for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < C) ? x.qn[cc + 1] : 0.0;
-  x.gp.sigma_raw = x.qn[1];
-  x.gp.phi = exp(-x.gp.sigma_raw);             // sigma = 1 ./ exp(sigma_raw)   (.stan:203)
+  for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < C) ? q[cc + 1] : 0.0;
+  x.gp.sigma_raw = q[1];
+  x.gp.phi = fast_exp(-x.gp.sigma_raw);        // sigma = 1 ./ exp(sigma_raw)   (.stan:203)
+  x.gp.lgphi = 0.0; x.gp.dgphi = 0.0; x.gp.A = 0.0;
+}
+// the per-gene constants of the cell loop
+template <int CM>
+PPCX_HD void gene_consts(GeneCtx<CM>& x) {
   lgamma_digamma(x.gp.phi, &x.gp.lgphi, &x.gp.dgphi);
-  x.gp.A = exp(x.gp.coef[0] + x.gp.sigma_raw);
+  x.gp.A = fast_exp(x.gp.coef[0] + x.gp.sigma_raw);
 }
 
-// the cells s = sub, sub+L, ... of the gene's row of counts
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PPCX_WAVE_ANY(p) (__any(p) != 0)
+#else
+#define PPCX_WAVE_ANY(p) (p)
+#endif
+
+// the cells s = sub, sub+L, ... of the gene's row of counts, four at a time: the counts and per-sample
+// constants of a chunk are fetched before any arithmetic so their latency overlaps the previous chunk
 template <int CM>
 PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, const double* sE, const double* sExpo,
                         const double* sX, int sub, int L, CellAcc<CM>& acc) {
   const int S = d.S, C = d.C;
   const GeneParams<CM>& gp = x.gp;
-  if (x.fast) {
-    for (int s = sub; s < S; s += L) {
-      const int y = x.active ? row[s] : -1;
-      if (y >= 0) {
-        double xsig;
-        cell_core(y, sE[s] * gp.A, gp.phi, gp.lgphi, gp.dgphi, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
-        acc.T2u += xsig;
+#ifndef PPCX_CELL_UNROLL
+#define PPCX_CELL_UNROLL 1
+#endif
+  constexpr int U = PPCX_CELL_UNROLL;
+  for (int s0 = sub; s0 < S; s0 += U * L) {
+    int y[U]; double u[U]; int sc[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int s = s0 + k * L;
+      const bool in = x.active && s < S;
+      sc[k] = s < S ? s : S - 1;
+      y[k] = in ? row[sc[k]] : -1;
+    }
+    if (x.fast) {
+#pragma unroll
+      for (int k = 0; k < U; ++k) u[k] = y[k] >= 0 ? sE[sc[k]] * gp.A : 0.0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        double t = sExpo[sc[k]] + gp.sigma_raw;
+#pragma unroll
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) t += sX[cc * S + sc[k]] * gp.coef[cc];
+        u[k] = y[k] >= 0 ? fast_exp(t) : 0.0;
       }
     }
-  } else {
-    for (int s = sub; s < S; s += L) {
-      const int y = x.active ? row[s] : -1;
-      if (y >= 0) {
-        double t = sExpo[s] + gp.sigma_raw;
+    bool small = false;
 #pragma unroll
-        for (int cc = 0; cc < CM; ++cc) if (cc < C) t += sX[cc * S + s] * gp.coef[cc];
-        double xsig;
-        cell_core(y, exp(t), gp.phi, gp.lgphi, gp.dgphi, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
-        acc.T2u += xsig;
+    for (int k = 0; k < U; ++k) small = small || (y[k] > 0 && (double)y[k] + gp.phi < 8.0);
+    const bool small_any = PPCX_WAVE_ANY(small);
 #pragma unroll
-        for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.T2x[cc] += sX[cc * S + s] * xsig;
+    for (int k = 0; k < U; ++k) {
+      double xsig;
+      cell_eval(y[k], u[k], gp.phi, gp.lgphi, gp.dgphi, small_any, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
+      acc.T2u += xsig;
+      if (!x.fast) {
+#pragma unroll
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.T2x[cc] = fma(sX[cc * S + sc[k]], xsig, acc.T2x[cc]);
       }
     }
   }
 }
 
-// close the gene with the reduced sums: gradient, second half kick, stores, partial sums part[0..9]
+// close the gene with its reduced sums: gradient, second half kick, stores, partial sums part[0..9]
 template <int CM>
-PPCX_HD void gene_end(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, CellAcc<CM>& acc,
-                      const double* Sy, const double* SyE, const double* SyXg, const double* ncell,
-                      const double* Lg1, double* part, double* pn) {
+PPCX_HD void gene_finish(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, CellAcc<CM>& acc,
+                         const double* Sy, const double* SyE, const double* SyXg, const double* ncell,
+                         const double* Lg1, double* part, double* pn, double* minv) {
   constexpr int NCM = CM + 1;
   if (x.fast) acc.T2x[0] = acc.T2u;
   double SyX[CM];
@@ -101,21 +125,33 @@ PPCX_HD void gene_end(const Dims& d, const Cmd& c, const VecRef& v, const GeneCt
 #pragma unroll
   for (int j = 0; j < NCM; ++j) {
     const double gnew = j == 0 ? go.g_coef[0] : (j == 1 ? go.g_sigma_raw : go.g_coef[j >= 2 ? j - 1 : 0]);
-    pn[j] = x.ph[j] + 0.5 * c.eps * gnew;      // half kick
-    if (j < x.ncoord && x.writer) {
-      v.at(V_Q0 + 3 * c.dir, x.idx[j]) = x.qn[j];
+    pn[j] = 0.0; minv[j] = 1.0;
+    if (j < x.ncoord) {
+      minv[j] = v.at(V_MINV, x.idx[j]);
+      pn[j] = v.at(V_P0 + 3 * c.dir, x.idx[j]) + 0.5 * c.eps * gnew;      // second half kick
       v.at(V_P0 + 3 * c.dir, x.idx[j]) = pn[j];
       v.at(V_G0 + 3 * c.dir, x.idx[j]) = gnew;
-      part[PT_T1] += pn[j] * pn[j] * x.minv[j];
+      part[PT_T1] += pn[j] * pn[j] * minv[j];
       bad = bad || !isfinite(gnew);
     }
   }
-  if (x.writer) {
+  if (x.active) {
     part[PT_LP] = go.lp;
 #pragma unroll
     for (int k = 0; k < 6; ++k) part[PT_H0 + k] = go.h[k];
-    part[PT_T0] = x.T0;
     part[PT_NONFINITE] = bad ? 1.0 : 0.0;
+  }
+}
+
+// per-coordinate part of kernel B for one gene-owned coordinate: pre-operations of the new command, then the
+// first half kick and the drift of the next leapfrog (written in place into the end being advanced)
+PPCX_HD void coord_update(const Cmd& nc, const VecRef& v, int i, double* draws, int D, double* T0,
+                          const CoordCache* cc = nullptr) {
+  const CoordVals cv = coord_pre(nc, v, i, i, true, draws, D, nc.k0, nc.k1, T0, cc);
+  if (nc.type != CMD_FLUSH) {
+    const double ph = cv.p + 0.5 * nc.eps * cv.g;
+    v.at(V_P0 + 3 * nc.dir, i) = ph;
+    v.at(V_Q0 + 3 * nc.dir, i) = cv.q + nc.eps * cv.minv * ph;
   }
 }
 
@@ -126,14 +162,13 @@ struct ChainIO {
   double* draws;                 // this chain's [n_keep][D] or null
   ChainOut out;
 };
-PPCX_HD void chain_step(const Dims& d, ChainState& st, const Cmd& ex, const double* red, bool have_parts,
-                        const VecRef& hv, const ChainIO& io, Cmd& nc) {
-  Reduced rd;
+PPCX_HD void chain_step(const Dims& d, ChainState& st, const Cmd& ex, const double* red, double T0_genes,
+                        bool have_parts, const VecRef& hv, const ChainIO& io, Reduced& rd, Cmd& nc) {
   double lp = 0.0; bool finite = true;
   if (have_parts && ex.type != CMD_FLUSH) {
     rd.lp_genes = red[PT_LP];
     for (int k = 0; k < 6; ++k) rd.hsum[k] = red[PT_H0 + k];
-    rd.T0 = red[PT_T0] + st.T0h; rd.T1 = red[PT_T1]; rd.nonfinite = red[PT_NONFINITE];
+    rd.T0 = T0_genes + st.T0h; rd.T1 = red[PT_T1]; rd.nonfinite = red[PT_NONFINITE];
     for (int l = 0; l < kLev; ++l) for (int k = 0; k < 6; ++k) rd.dots[l][k] = red[PT_DOTS + 6 * l + k];
     for (int k = 0; k < 6; ++k) rd.top[k] = red[PT_TOP + k];
     double g6[6];

@@ -1,36 +1,44 @@
 // ppcx_kernels.h -- argument blocks and launchers of the gfx950 kernels (ppcx_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
-#include "ppcx_nuts.h"
+#include "ppcx_gene.h"
 
 namespace ppcx {
 
-struct GeneArgs {
+struct LoglikArgs {
   Dims d;
   const int* counts;            // G x S gene-major, excluded cells = -1
   const double* sampleE;        // exp(exposure_s)
   const double* exposure;       // S
   const double* X;              // S x C column-major
+  double* vecs;                 // [chains][V_COUNT][Dpad] (read only here)
+  long Dpad;
+  const Cmd* cmds;              // [chains]
+  double* sums;                 // [chains][5+CM][G]
+};
+
+struct CloseArgs {
+  Dims d;
   const double* Sy;             // per-gene sufficient statistics over non-excluded cells
   const double* SyE;
   const double* SyX;            // [C][G]
   const double* ncell;
   const double* Lg1;            // per-gene sum of lgamma(y+1)
-  double* vecs;                 // [chains][V_COUNT][Dpad]
-  long Dpad;
-  const Cmd* cmds;              // [chains]
-  double* partials;             // [chains][nblocks][PT_COUNT]
-  double* draws;                // [chains][n_keep][D] or null
-  long draws_chain_stride;
+  const double* sums;
+  double* vecs; long Dpad;
+  const Cmd* cmds;
+  double* partials;             // [chains][nblocks_close][PT_COUNT]
 };
 
-struct ChainArgs {
+struct UpdateArgs {
   Dims d;
-  ChainState* states;
-  Cmd* cmds;
-  const double* partials;
-  int nblocks;
-  double* hyper_vecs;           // [chains][V_COUNT][8]
+  const ChainState* states_in; ChainState* states_out;   // double-buffered between launches
+  const Cmd* cmds_in; Cmd* cmds_out;
+  const double* hyper_in; double* hyper_out;             // [chains][V_COUNT][8]
+  const double* t0_in; double* t0_out;                   // [chains][nblocks_update]
+  const double* partials;                                // [chains][nblocks_close][PT_COUNT]
+  int nblocks_close;
+  double* vecs; long Dpad;
   double* draws; long draws_chain_stride;
   int n_keep, iter;
   double* out_lp; double* out_stepsize; int* out_treedepth; int* out_n_leapfrog; int* out_divergent; double* out_accept;
@@ -49,8 +57,9 @@ struct PpcArgs {
   int* counts_rng;              // [n_gen][K*S] or null
 };
 
-hipError_t launch_gene_kernel(int L, int CM, const GeneArgs& a, int nblocks, int nchains, hipStream_t st);
-hipError_t launch_chain_kernel(const ChainArgs& a, int nchains, hipStream_t st);
+hipError_t launch_loglik_kernel(int L, int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st);
+hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st);
+hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_ppc_kernel(const PpcArgs& a, hipStream_t st);
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st);
 hipError_t launch_fill_kernel(double* p, long n, double val, hipStream_t st);

@@ -1,17 +1,18 @@
 // ppcx_kernels.hip -- gfx950 kernels of the NB hierarchical NUTS / posterior-predictive engine.
 //
-//   ppcx_gene_kernel<L,CM>  "kernel A": one leapfrog (or evaluation) for every chain, fused with the
-//                           per-coordinate NUTS bookkeeping; streams the int32 count matrix once.
-//                           Replaces lp_reduce + map_rect + X*alpha + the gene-level priors of
-//                           inst/stan/negBinomial_MPI.stan:58-120,:205,:219-240 and Stan's leapfrog.
-//   ppcx_chain_kernel       "kernel B": per-chain reduction of block partials, hyper-parameters,
-//                           NUTS/adaptation state machine (ppcx_nuts.h).
+//   ppcx_loglik_kernel<L,CM> "kernel A1": streams the int32 count matrix once per gradient evaluation and reduces
+//                           it to a handful of sums per gene. Replaces lp_reduce + map_rect + X*alpha of
+//                           inst/stan/negBinomial_MPI.stan:58-120,:205,:226-240.
+//   ppcx_close_kernel<CM>   "kernel A2": per gene: priors (.stan:219-223), gradient, second half kick of the
+//                           leapfrog, NUTS tree bookkeeping of the gene's coordinates, block partial sums.
+//   ppcx_update_kernel      "kernel B": reduction of A's block partials, hyper-parameters, NUTS/adaptation
+//                           state machine (ppcx_nuts.h) and the per-coordinate updates of the next command.
 //   ppcx_ppc_kernel         generated quantities (.stan:259-266) + credible-interval summary
 //                           (R/utilities.R:685-703 / :733-784): NB draws straight into LDS, bitonic
 //                           sort, type-7 quantiles, mean, sd.
 //   ppcx_gather_kernel      column gather of the retained draws.
 //
-// Work decomposition of kernel A (DESIGN.md "lp/grad kernel"): a gene is owned by L lanes of one
+// Work decomposition of kernel A1 (DESIGN.md "lp/grad kernel"): a gene is owned by L lanes of one
 // wavefront (L in {1,2,4,...,64}, chosen per problem so that ceil(S/L)*L wastes few lanes and the
 // launch fills 1024 SIMDs evenly); lanes stride over that gene's samples, read the per-sample
 // constants from LDS, and combine with an L-lane xor-shuffle butterfly. Per-block partial sums go to a
@@ -24,38 +25,40 @@ namespace ppcx {
 
 __device__ __forceinline__ double wave_xor_add(double v, int mask) { return v + __shfl_xor(v, mask, 64); }
 
+// -----------------------------------------------------------------------------------------------------
+// kernel A1: the log-likelihood kernel. Streams the count matrix once and leaves, per gene, the sums
+// T1 = sum x log w, SP = sum log w, T2u = sum x u/w, T3 = sum [lgamma(y+phi) - lgamma(phi)],
+// T4 = sum [psi(y+phi) - psi(phi)] (+ T2x[c] = sum X_sc x u/w for genes with slopes).
+// -----------------------------------------------------------------------------------------------------
 template <int L, int CM>
-__global__ __launch_bounds__(256, 2) void ppcx_gene_kernel(GeneArgs a) {
-  constexpr int NCM = CM + 1;
+__global__ __launch_bounds__(256, 4) void ppcx_loglik_kernel(LoglikArgs a) {
   constexpr int GPW = 64 / L;                 // genes per wavefront
+  constexpr int NS = GeneSums<CM>::N;
   extern __shared__ double lds[];
   const int chain = blockIdx.y;
-  const Cmd c = a.cmds[chain];
-  if (c.type == CMD_DONE) return;
+  const Cmd& c = a.cmds[chain];
+  if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
   const Dims& d = a.d;
   const int S = d.S, C = d.C;
-  double* wacc = lds;                          // [4][PT_COUNT]
-  double* sE = lds + 4 * PT_COUNT;             // exp(exposure_s)
+  double* sE = lds;                            // exp(exposure_s)
   double* sExpo = sE + S;
   double* sX = sExpo + S;                      // S x C column-major
   const int tid = threadIdx.x;
-  for (int i = tid; i < 4 * PT_COUNT; i += 256) wacc[i] = 0.0;
-  for (int i = tid; i < S; i += 256) { sE[i] = a.sampleE[i]; sExpo[i] = a.exposure[i]; }
-  for (int i = tid; i < S * C; i += 256) sX[i] = a.X[i];
+  const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
+  for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
+  if (any_generic) {
+    for (int i = tid; i < S; i += 256) sExpo[i] = a.exposure[i];
+    for (int i = tid; i < S * C; i += 256) sX[i] = a.X[i];
+  }
   __syncthreads();
-
   const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
-  double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
+  double* sums = a.sums + (long)chain * NS * d.G;
   const int wave = tid >> 6, lane = tid & 63, sub = lane % L, gl = lane / L;
   const int ngroups = (d.G + GPW - 1) / GPW;
-  const bool do_eval = c.type != CMD_FLUSH;
-  const int m_merge = c.type == CMD_LEAF ? c.n_merge : 0;
-
   for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
     GeneCtx<CM> x;
-    gene_begin<CM>(d, c, v, grp * GPW + gl, sub == 0, draws, x);
-    if (!do_eval) continue;                   // CMD_FLUSH: bookkeeping only (uniform over the launch)
-
+    gene_load<CM>(d, c, v, grp * GPW + gl, x);
+    gene_consts<CM>(x);
     CellAcc<CM> acc; acc.zero();
     gene_cells<CM>(d, x, a.counts + (long)x.gg * S, sE, sExpo, sX, sub, L, acc);
     // L-lane butterfly: every lane of the gene ends with the gene totals
@@ -63,96 +66,147 @@ __global__ __launch_bounds__(256, 2) void ppcx_gene_kernel(GeneArgs a) {
     for (int msk = 1; msk < L; msk <<= 1) {
       acc.T1 = wave_xor_add(acc.T1, msk); acc.SP = wave_xor_add(acc.SP, msk); acc.T2u = wave_xor_add(acc.T2u, msk);
       acc.T3 = wave_xor_add(acc.T3, msk); acc.T4 = wave_xor_add(acc.T4, msk);
-      if (!d.x0_is_one || (C >= 2 && d.K > 0)) {   // uniform: some gene of this launch may take the generic path
+      if (any_generic) {
 #pragma unroll
         for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.T2x[cc] = wave_xor_add(acc.T2x[cc], msk);
       }
     }
-    double pn[NCM], part[10];
-    gene_end<CM>(d, c, v, x, acc, a.Sy, a.SyE, a.SyX, a.ncell, a.Lg1, part, pn);
+    if (x.active && sub == 0) {
+      const long G = d.G;
+      sums[0 * G + x.gg] = acc.T1; sums[1 * G + x.gg] = acc.SP; sums[2 * G + x.gg] = acc.T2u;
+      sums[3 * G + x.gg] = acc.T3; sums[4 * G + x.gg] = acc.T4;
+      if (any_generic) {
 #pragma unroll
-    for (int msk = L; msk < 64; msk <<= 1) {
-#pragma unroll
-      for (int k = 0; k < 10; ++k) part[k] = wave_xor_add(part[k], msk);
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) sums[(5 + cc) * G + x.gg] = acc.T2x[cc];
+      }
     }
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 10; ++k) wacc[wave * PT_COUNT + k] += part[k];
-    }
+  }
+}
 
-    if (c.type == CMD_LEAF) {                  // iterative build_tree bookkeeping for this gene's coordinates
-      NodeVals nv[NCM];
+// -----------------------------------------------------------------------------------------------------
+// kernel A2: one thread per gene closes it -- priors, gradient, second half kick of the gene's coordinates,
+// U-turn dot products and subtree slots -- and the workgroup leaves its partial sums in a slab.
+// -----------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void block_accumulate(double* vals, double* wacc, int wave, int lane) {
 #pragma unroll
-      for (int j = 0; j < NCM; ++j) nv[j] = NodeVals{pn[j], pn[j]};
-      for (int lev = 0; lev < m_merge; ++lev) {
-        double dots[6] = {0, 0, 0, 0, 0, 0};
-        if (x.writer) {
+  for (int msk = 1; msk < 64; msk <<= 1) {      // the N butterflies advance together: shuffle latencies overlap
 #pragma unroll
-          for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots(v, x.idx[j], lev, pn[j], x.minv[j], &nv[j], dots);
-        }
+    for (int k = 0; k < N; ++k) vals[k] = wave_xor_add(vals[k], msk);
+  }
+  if (lane == 0) {
 #pragma unroll
-        for (int msk = L; msk < 64; msk <<= 1) {
+    for (int k = 0; k < N; ++k) wacc[wave * PT_COUNT + k] = vals[k];
+  }
+}
+
+template <int CM>
+__global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
+  constexpr int NCM = CM + 1;
+  constexpr int NS = GeneSums<CM>::N;
+  __shared__ double wacc[4 * PT_COUNT];
+  const int chain = blockIdx.y;
+  const Cmd& c = a.cmds[chain];
+  if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
+  const Dims& d = a.d;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
+  const double* sums = a.sums + (long)chain * NS * d.G;
+  const int g = blockIdx.x * 256 + tid;
+  const bool any_generic = !d.x0_is_one || (d.C >= 2 && d.K > 0);
+  GeneCtx<CM> x;
+  gene_load<CM>(d, c, v, g, x);
+  CellAcc<CM> acc; acc.zero();
+  if (x.active) {
+    const long G = d.G;
+    acc.T1 = sums[0 * G + g]; acc.SP = sums[1 * G + g]; acc.T2u = sums[2 * G + g];
+    acc.T3 = sums[3 * G + g]; acc.T4 = sums[4 * G + g];
+    if (any_generic) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) dots[k] = wave_xor_add(dots[k], msk);
-        }
-        if (lane == 0) {
+      for (int cc = 0; cc < CM; ++cc) if (cc < d.C) acc.T2x[cc] = sums[(5 + cc) * G + g];
+    }
+  }
+  double pn[NCM], minv[NCM], part[10];
+  gene_finish<CM>(d, c, v, x, acc, a.Sy, a.SyE, a.SyX, a.ncell, a.Lg1, part, pn, minv);
+  block_accumulate<10>(part, wacc, wave, lane);
+  if (c.type == CMD_LEAF) {
+    NodeVals nv[NCM];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) wacc[wave * PT_COUNT + PT_DOTS + 6 * lev + k] += dots[k];
-        }
-      }
-      if (!c.subtree_complete) {
-        if (x.writer) {
+    for (int j = 0; j < NCM; ++j) nv[j] = NodeVals{pn[j], pn[j]};
+    for (int lev = 0; lev < c.n_merge; ++lev) {
+      double dots[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-          for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_store_slot(v, x.idx[j], m_merge, pn[j], nv[j]);
-        }
-      } else {
-        double top[6] = {0, 0, 0, 0, 0, 0};
-        if (x.writer) {
+      for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots(v, x.idx[j], lev, pn[j], minv[j], &nv[j], dots);
+      block_accumulate<6>(dots, wacc + PT_DOTS + 6 * lev, wave, lane);
+    }
+    if (!c.subtree_complete) {
 #pragma unroll
-          for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_top_dots(v, x.idx[j], c.dir, pn[j], x.minv[j], nv[j], top);
-        }
+      for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_store_slot(v, x.idx[j], c.n_merge, pn[j], nv[j]);
+    } else {
+      double top[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int msk = L; msk < 64; msk <<= 1) {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) top[k] = wave_xor_add(top[k], msk);
-        }
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) wacc[wave * PT_COUNT + PT_TOP + k] += top[k];
-        }
-      }
+      for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_top_dots(v, x.idx[j], c.dir, pn[j], minv[j], nv[j], top);
+      block_accumulate<6>(top, wacc + PT_TOP, wave, lane);
     }
   }
   __syncthreads();
   const int np = parts_used(c);
   double* slab = a.partials + ((long)chain * gridDim.x + blockIdx.x) * PT_COUNT;
-  for (int k = tid; k < np; k += 256)
-    slab[k] = ((wacc[k] + wacc[PT_COUNT + k]) + wacc[2 * PT_COUNT + k]) + wacc[3 * PT_COUNT + k];
+  for (int k = tid; k < np; k += 256) {
+    const bool used = k < 10 || (k >= PT_DOTS && k < PT_DOTS + 6 * c.n_merge) || (k >= PT_TOP && c.subtree_complete);
+    slab[k] = used ? ((wacc[k] + wacc[PT_COUNT + k]) + wacc[2 * PT_COUNT + k]) + wacc[3 * PT_COUNT + k] : 0.0;
+  }
 }
 
 // -----------------------------------------------------------------------------------------------------
-// kernel B
+// kernel B: reduce A's partial sums, advance the chain (redundantly per workgroup), update coordinates
 // -----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ppcx_chain_kernel(ChainArgs a) {
+__global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
   __shared__ double sm[8][32];
   __shared__ double red[PT_COUNT];
   __shared__ double hv[V_COUNT * 8];           // the six hyper coordinates of every per-coordinate vector
-  const int chain = blockIdx.x, tid = threadIdx.x;
-  ChainState* stp = a.states + chain;
-  if (stp->phase == PH_DONE) return;
-  const Cmd ex = a.cmds[chain];
-  double* hvg = a.hyper_vecs + (long)chain * V_COUNT * 8;
+  __shared__ double sT0[256];
+  __shared__ Cmd s_nc, s_ex;                   // the state machine works on LDS copies: no scratch, no global latency
+  __shared__ ChainState s_st;
+  __shared__ Reduced s_rd;
+  const int chain = blockIdx.y, tid = threadIdx.x;
+  const ChainState* st_in = a.states_in + chain;
+  if (st_in->phase == PH_DONE) {               // finished chain: carry its final state across the double buffer
+    if (blockIdx.x == 0) {
+      if (tid == 0) { a.states_out[chain] = *st_in; a.cmds_out[chain] = a.cmds_in[chain]; }
+      const double* hi = a.hyper_in + (long)chain * V_COUNT * 8;
+      double* ho = a.hyper_out + (long)chain * V_COUNT * 8;
+      for (int i = tid; i < V_COUNT * 8; i += 256) ho[i] = hi[i];
+    }
+    return;
+  }
+  {
+    const int* src = reinterpret_cast<const int*>(a.cmds_in + chain); int* dst = reinterpret_cast<int*>(&s_ex);
+    for (int i = tid; i < (int)(sizeof(Cmd) / sizeof(int)); i += 256) dst[i] = src[i];
+    const int* s2 = reinterpret_cast<const int*>(st_in); int* d2 = reinterpret_cast<int*>(&s_st);
+    for (int i = tid; i < (int)(sizeof(ChainState) / sizeof(int)); i += 256) d2[i] = s2[i];
+  }
+  const Cmd& ex = s_ex;
+  const Dims& d = a.d;
+  // this thread's first coordinate is fetched now; its latency hides behind the reduction and the state machine
+  const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
+  const int i_first = 3 + blockIdx.x * 256 + tid;
+  CoordCache cache;
+  if (i_first < d.off_tail) cache = coord_prefetch(v, i_first);
+  const double* hvg = a.hyper_in + (long)chain * V_COUNT * 8;
   for (int i = tid; i < V_COUNT * 8; i += 256) hv[i] = hvg[i];
   for (int i = tid; i < PT_COUNT; i += 256) red[i] = 0.0;
-  const bool have_parts = stp->phase != PH_START;
+  const bool have_parts = st_in->phase != PH_START;
   __syncthreads();
+  double T0g = 0.0;
   if (have_parts) {
-    const int np = parts_used(ex);
-    const double* slab = a.partials + (long)chain * a.nblocks * PT_COUNT;
+    // every workgroup reduces the same slab in the same order: bitwise identical sums everywhere
+    const int np = (ex.type == CMD_FLUSH) ? 0 : parts_used(ex);
+    const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
     for (int v0 = 0; v0 < np; v0 += 32) {
       const int vv = v0 + (tid & 31), ch = tid >> 5;
       double s = 0.0;
-      if (vv < np) for (int b = ch; b < a.nblocks; b += 8) s += slab[(long)b * PT_COUNT + vv];
+      if (vv < np) for (int b = ch; b < a.nblocks_close; b += 8) s += slab[(long)b * PT_COUNT + vv];
       sm[ch][tid & 31] = s;
       __syncthreads();
       if (tid < 32 && v0 + tid < np) {
@@ -163,26 +217,52 @@ __global__ __launch_bounds__(256) void ppcx_chain_kernel(ChainArgs a) {
       }
       __syncthreads();
     }
+    // kinetic energy of the momenta drawn by the previous update launch
+    const double* t0s = a.t0_in + (long)chain * gridDim.x;
+    double s = 0.0;
+    for (int b = tid; b < (int)gridDim.x; b += 256) s += t0s[b];
+    sT0[tid] = s;
+    __syncthreads();
+    for (int stp = 128; stp > 0; stp >>= 1) { if (tid < stp) sT0[tid] += sT0[tid + stp]; __syncthreads(); }
+    T0g = sT0[0];
+    __syncthreads();
   }
-  __syncthreads();
   if (tid == 0) {
-    ChainState st = *stp;
+    ChainState& st = s_st;
     ChainIO io;
-    io.draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
-    io.out.lp = a.out_lp ? a.out_lp + (long)chain * a.n_keep : nullptr;
-    io.out.stepsize = a.out_stepsize ? a.out_stepsize + (long)chain * a.iter : nullptr;
-    io.out.treedepth = a.out_treedepth ? a.out_treedepth + (long)chain * a.iter : nullptr;
-    io.out.n_leapfrog = a.out_n_leapfrog ? a.out_n_leapfrog + (long)chain * a.iter : nullptr;
-    io.out.divergent = a.out_divergent ? a.out_divergent + (long)chain * a.iter : nullptr;
-    io.out.accept = a.out_accept ? a.out_accept + (long)chain * a.iter : nullptr;
-    Cmd nc;
-    chain_step(a.d, st, ex, red, have_parts, VecRef{hv, 8}, io, nc);
-    *stp = st;
-    a.cmds[chain] = nc;
-    if (st.phase == PH_DONE) a.done[chain] = 1 + st.error;
+    const bool lead = blockIdx.x == 0;           // only one workgroup writes the outputs
+    io.draws = (lead && a.draws) ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
+    io.out.lp = (lead && a.out_lp) ? a.out_lp + (long)chain * a.n_keep : nullptr;
+    io.out.stepsize = (lead && a.out_stepsize) ? a.out_stepsize + (long)chain * a.iter : nullptr;
+    io.out.treedepth = (lead && a.out_treedepth) ? a.out_treedepth + (long)chain * a.iter : nullptr;
+    io.out.n_leapfrog = (lead && a.out_n_leapfrog) ? a.out_n_leapfrog + (long)chain * a.iter : nullptr;
+    io.out.divergent = (lead && a.out_divergent) ? a.out_divergent + (long)chain * a.iter : nullptr;
+    io.out.accept = (lead && a.out_accept) ? a.out_accept + (long)chain * a.iter : nullptr;
+    chain_step(d, st, ex, red, T0g, have_parts, VecRef{hv, 8}, io, s_rd, s_nc);
+    if (lead && st.phase == PH_DONE) a.done[chain] = 1 + st.error;
   }
   __syncthreads();
-  for (int i = tid; i < V_COUNT * 8; i += 256) hvg[i] = hv[i];
+  if (blockIdx.x == 0) {
+    double* hvo = a.hyper_out + (long)chain * V_COUNT * 8;
+    for (int i = tid; i < V_COUNT * 8; i += 256) hvo[i] = hv[i];
+    const int* src = reinterpret_cast<const int*>(&s_nc); int* dst = reinterpret_cast<int*>(a.cmds_out + chain);
+    for (int i = tid; i < (int)(sizeof(Cmd) / sizeof(int)); i += 256) dst[i] = src[i];
+    const int* s2 = reinterpret_cast<const int*>(&s_st); int* d2 = reinterpret_cast<int*>(a.states_out + chain);
+    for (int i = tid; i < (int)(sizeof(ChainState) / sizeof(int)); i += 256) d2[i] = s2[i];
+  }
+  // per-coordinate work of the new command for this workgroup's slice of the gene-owned coordinates
+  const Cmd& nc = s_nc;
+  double T0 = 0.0;
+  if (nc.type != CMD_DONE) {
+    double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
+    if (i_first < d.off_tail) coord_update(nc, v, i_first, draws, d.D, &T0, &cache);
+    for (int i = i_first + gridDim.x * 256; i < d.off_tail; i += gridDim.x * 256)
+      coord_update(nc, v, i, draws, d.D, &T0);
+  }
+  sT0[tid] = T0;
+  __syncthreads();
+  for (int stp = 128; stp > 0; stp >>= 1) { if (tid < stp) sT0[tid] += sT0[tid + stp]; __syncthreads(); }
+  if (tid == 0) a.t0_out[(long)chain * gridDim.x + blockIdx.x] = sT0[0];
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -273,31 +353,38 @@ __global__ void ppcx_fill_kernel(double* p, long n, double val) {
 // launch helpers (host)
 // -----------------------------------------------------------------------------------------------------
 template <int L, int CM>
-static hipError_t launch_gene_t(const GeneArgs& a, dim3 grid, size_t lds_bytes, hipStream_t st) {
-  hipLaunchKernelGGL((ppcx_gene_kernel<L, CM>), grid, dim3(256), lds_bytes, st, a);
+static hipError_t launch_loglik_t(const LoglikArgs& a, dim3 grid, size_t lds_bytes, hipStream_t st) {
+  hipLaunchKernelGGL((ppcx_loglik_kernel<L, CM>), grid, dim3(256), lds_bytes, st, a);
   return hipGetLastError();
 }
 template <int CM>
-static hipError_t launch_gene_l(int L, const GeneArgs& a, dim3 grid, size_t lds_bytes, hipStream_t st) {
+static hipError_t launch_loglik_l(int L, const LoglikArgs& a, dim3 grid, size_t lds_bytes, hipStream_t st) {
   switch (L) {
-    case 1: return launch_gene_t<1, CM>(a, grid, lds_bytes, st);
-    case 2: return launch_gene_t<2, CM>(a, grid, lds_bytes, st);
-    case 4: return launch_gene_t<4, CM>(a, grid, lds_bytes, st);
-    case 8: return launch_gene_t<8, CM>(a, grid, lds_bytes, st);
-    case 16: return launch_gene_t<16, CM>(a, grid, lds_bytes, st);
-    case 32: return launch_gene_t<32, CM>(a, grid, lds_bytes, st);
-    default: return launch_gene_t<64, CM>(a, grid, lds_bytes, st);
+    case 1: return launch_loglik_t<1, CM>(a, grid, lds_bytes, st);
+    case 2: return launch_loglik_t<2, CM>(a, grid, lds_bytes, st);
+    case 4: return launch_loglik_t<4, CM>(a, grid, lds_bytes, st);
+    case 8: return launch_loglik_t<8, CM>(a, grid, lds_bytes, st);
+    case 16: return launch_loglik_t<16, CM>(a, grid, lds_bytes, st);
+    case 32: return launch_loglik_t<32, CM>(a, grid, lds_bytes, st);
+    default: return launch_loglik_t<64, CM>(a, grid, lds_bytes, st);
   }
 }
-hipError_t launch_gene_kernel(int L, int CM, const GeneArgs& a, int nblocks, int nchains, hipStream_t st) {
-  const size_t lds_bytes = sizeof(double) * (4 * PT_COUNT + (size_t)a.d.S * (2 + a.d.C));
+hipError_t launch_loglik_kernel(int L, int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st) {
+  const size_t lds_bytes = sizeof(double) * ((size_t)a.d.S * (2 + a.d.C));
   const dim3 grid(nblocks, nchains);
-  if (CM <= 2) return launch_gene_l<2>(L, a, grid, lds_bytes, st);
-  if (CM <= 4) return launch_gene_l<4>(L, a, grid, lds_bytes, st);
-  return launch_gene_l<8>(L, a, grid, lds_bytes, st);
+  if (CM <= 2) return launch_loglik_l<2>(L, a, grid, lds_bytes, st);
+  if (CM <= 4) return launch_loglik_l<4>(L, a, grid, lds_bytes, st);
+  return launch_loglik_l<8>(L, a, grid, lds_bytes, st);
 }
-hipError_t launch_chain_kernel(const ChainArgs& a, int nchains, hipStream_t st) {
-  hipLaunchKernelGGL(ppcx_chain_kernel, dim3(nchains), dim3(256), 0, st, a);
+hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st) {
+  const dim3 grid(nblocks, nchains);
+  if (CM <= 2) hipLaunchKernelGGL((ppcx_close_kernel<2>), grid, dim3(256), 0, st, a);
+  else if (CM <= 4) hipLaunchKernelGGL((ppcx_close_kernel<4>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((ppcx_close_kernel<8>), grid, dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st) {
+  hipLaunchKernelGGL(ppcx_update_kernel, dim3(nblocks, nchains), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_ppc_kernel(const PpcArgs& a, hipStream_t st) {

@@ -60,6 +60,24 @@ PPCX_HD double fast_log(double x) {
   return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
+// exp(x) for |x| < 700 by x = k ln2 + r, |r| <= ln2/2 and the rational form of Sun's fdlibm e_exp.c
+// (public domain algorithm; error < 1 ulp): c = r - r^2 P(r^2), exp(r) = 1 + r + r c / (2 - c).
+PPCX_HD double fast_exp(double x) {
+  const double kf = rint(x * 1.44269504088896338700e+00);
+  const double hi = fma(kf, -6.93147180369123816490e-01, x);
+  const double lo = kf * 1.90821492927058770002e-10;
+  const double r = hi - lo;
+  const double t = r * r;
+  const double c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 +
+                   t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
+  const double y = 1.0 - ((lo - (r * c) * fast_rcp(2.0 - c)) - hi);
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ldexp(y, (int)kf);
+#else
+  return ldexp(y, (int)kf);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // log-gamma and digamma for x > 0 with ONE shared logarithm and ONE reciprocal.
 //   x >= 8 : Stirling series  lgamma(x) = (x-1/2)ln x - x + ln(2pi)/2 + sum B2k/(2k(2k-1)x^(2k-1))
@@ -124,7 +142,7 @@ PPCX_HD double log_sum_exp(double a, double b) {
   if (a == -INFINITY) return b;
   if (b == -INFINITY) return a;
   const double m = a > b ? a : b;
-  return m + log1p(exp(-fabs(a - b)));
+  return m + fast_log(1.0 + fast_exp(-fabs(a - b)));
 }
 
 // ---------------------------------------------------------------------------------------------

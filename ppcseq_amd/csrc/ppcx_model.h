@@ -58,11 +58,11 @@ struct Hyper {                  // constrained hyper-parameters + derived consta
 PPCX_HD Hyper make_hyper(const double* u6, double lambda_mu_mu) {
   Hyper h;
   h.lambda_mu = u6[0] + lambda_mu_mu;        // <offset = lambda_mu_mu>  (.stan:183)
-  h.lambda_sigma = exp(u6[1]);               // <lower = 0>              (.stan:184)
+  h.lambda_sigma = fast_exp(u6[1]);          // <lower = 0>              (.stan:184)
   h.lambda_skew = u6[2];
-  h.sigma_slope = -exp(u6[3]);               // <upper = 0>              (.stan:195)
+  h.sigma_slope = -fast_exp(u6[3]);          // <upper = 0>              (.stan:195)
   h.sigma_intercept = u6[4];
-  h.sigma_sigma = exp(u6[5]);                // <lower = 0>              (.stan:197)
+  h.sigma_sigma = fast_exp(u6[5]);           // <lower = 0>              (.stan:197)
   h.xi = h.lambda_mu + lambda_mu_mu;         // offset enters twice by construction (.stan:219)
   h.inv_om = 1.0 / h.lambda_sigma; h.log_om = u6[1];
   h.inv_ss = 1.0 / h.sigma_sigma; h.inv_ss2 = h.inv_ss * h.inv_ss; h.log_ss = u6[5];
@@ -79,21 +79,38 @@ struct CellAcc {
     for (int c = 0; c < CM; ++c) T2x[c] = 0.0; }
 };
 
-// shared tail of one cell once u = exp(t) is known
-PPCX_HD void cell_core(int y, double u, double phi, double lgphi, double dgphi,
+// One cell once u = exp(t) is known. The common case (y + phi >= 8) is straight-line code so that the
+// compiler can overlap the dependency chains of neighbouring cells; `small_any` is true when some lane of
+// the wavefront (device) / this cell (host) has 0 < y + phi < 8 and needs the shifted recurrence.
+// y < 0 marks an excluded or out-of-range cell and contributes nothing; y == 0 contributes
+// lgamma(phi) - lgamma(phi) = 0 exactly to T3/T4.
+PPCX_HD void cell_eval(int y, double u, double phi, double lgphi, double dgphi, bool small_any,
                        double* T1, double* SP, double* T3, double* T4, double* xsig) {
+  const bool valid = y >= 0, pos = y > 0;
+  const double x = (double)(valid ? y : 0) + phi;
   const double w = 1.0 + u;
-  const double sp = fast_log(w);
-  const double x = (double)y + phi;
-  *xsig = x * (u * fast_rcp(w));
-  *T1 += x * sp;
+  const double sp = valid ? fast_log(w) : 0.0;
+  *xsig = valid ? x * (u * fast_rcp(w)) : 0.0;
+  *T1 = fma(x, sp, *T1);
   *SP += sp;
-  if (y > 0) {                                // y == 0 contributes lgamma(phi)-lgamma(phi) = 0 exactly
-    double lg, dg;
-    lgamma_digamma(x, &lg, &dg);
-    *T3 += lg - lgphi;
-    *T4 += dg - dgphi;
+  const bool big = x >= 8.0;
+  const double xe = big ? x : x + 8.0;
+  double lg, dg;
+  lgamma_digamma_stirling(xe, fast_log(xe), fast_rcp(xe), &lg, &dg);
+  if (small_any) {
+    double P = x, dP = 1.0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const double f = x + (double)k;
+      dP = fma(dP, f, P);
+      P = P * f;
+    }
+    const double lP = fast_log(P), qP = dP * fast_rcp(P);
+    lg -= big ? 0.0 : lP;
+    dg -= big ? 0.0 : qP;
   }
+  *T3 += pos ? lg - lgphi : 0.0;
+  *T4 += pos ? dg - dgphi : 0.0;
 }
 
 // everything a gene's lanes need that does not depend on the sample

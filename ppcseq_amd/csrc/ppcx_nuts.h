@@ -8,13 +8,16 @@
 // Euclidean metric, dual-averaging step size, windowed variance adaptation).
 //
 // MI355X-first structure (DESIGN.md "NUTS on the device"):
-//   * kernel A (`ppcx_gene_kernel`)  : one launch = one leapfrog for every chain. Each gene's coordinates
-//     (intercept, sigma_raw, slopes) live with the lanes that stream that gene's counts, so position /
-//     momentum updates, the likelihood+prior gradient and all tree bookkeeping for those coordinates
-//     are fused into the one pass over the count matrix.
-//   * kernel B (`ppcx_chain_kernel`) : one workgroup per chain reduces the per-block partial sums,
-//     owns the six hyper-parameters, and runs the scalar NUTS / adaptation state machine
-//     (`chain_advance`), emitting the next `Cmd` for kernel A.
+//   * kernel A (`ppcx_gene_kernel`)  : one launch = the gradient evaluation of one leapfrog for every chain.
+//     Each gene's coordinates (intercept, sigma_raw, slopes) live with the lanes that stream that gene's
+//     counts, so the likelihood+prior gradient, the second half kick and the tree bookkeeping of those
+//     coordinates (U-turn dot products, subtree slots) are fused into the one pass over the count matrix.
+//   * kernel B (`ppcx_update_kernel`): every workgroup reduces the per-block partial sums of A in the same
+//     fixed order and runs the scalar NUTS / adaptation state machine (`chain_step`) redundantly -- no
+//     grid barrier, no extra launch -- then applies the per-coordinate operations the new command asks for
+//     (proposal / sample copies, draw storage, Welford / metric updates, momentum refresh) and the first
+//     half kick + drift of the next leapfrog to its slice of the coordinates. State and commands are
+//     double-buffered between launches so that no workgroup can read what another has already advanced.
 //   The host only pumps (A,B) launch pairs and polls a done flag: no per-leapfrog host round trip.
 //   Stan's recursive build_tree is evaluated iteratively: a completed left subtree of level d parks
 //   its (rho, p_begin, p_end, proposal, log weight) in slot d until its right sibling completes.
@@ -68,6 +71,16 @@ struct VecRef {
   PPCX_HD double& at(int v, int i) const { return base[(long)v * stride + i]; }
 };
 struct CoordVals { double q, p, g, minv; };
+// both ends and the metric of one coordinate, fetched ahead of the state machine so that the memory latency
+// overlaps it (kernel B); coord_pre loads from memory when no cache is given
+struct CoordCache { double q[2], p[2], g[2], minv; };
+PPCX_HD CoordCache coord_prefetch(const VecRef& v, int i) {
+  CoordCache c;
+  c.q[0] = v.at(V_Q0, i); c.p[0] = v.at(V_P0, i); c.g[0] = v.at(V_G0, i);
+  c.q[1] = v.at(V_Q1, i); c.p[1] = v.at(V_P1, i); c.g[1] = v.at(V_G1, i);
+  c.minv = v.at(V_MINV, i);
+  return c;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // per-coordinate pre-operations (lazy bookkeeping decided by the previous chain_advance) followed by
@@ -77,18 +90,18 @@ struct CoordVals { double q, p, g, minv; };
 // `i` indexes the vectors, `flat` is the coordinate's index in the Stan-ordered unconstrained vector
 // (RNG stream id and draws column); they differ only for kernel B's LDS copy of the hyper coordinates.
 PPCX_HD CoordVals coord_pre(const Cmd& c, const VecRef& v, int i, int flat, bool writer, double* draws, int D,
-                            uint32_t k0, uint32_t k1, double* T0) {
+                            uint32_t k0, uint32_t k1, double* T0, const CoordCache* cc = nullptr) {
   const int f = c.pre_flags;
   if (f & PRE_PROP) {
     double q_, g_;
-    if (c.prop_src < 0) { q_ = v.at(V_Q0 + 3 * c.pre_dir, i); g_ = v.at(V_G0 + 3 * c.pre_dir, i); }
+    if (c.prop_src < 0) { q_ = cc ? cc->q[c.pre_dir] : v.at(V_Q0 + 3 * c.pre_dir, i); g_ = cc ? cc->g[c.pre_dir] : v.at(V_G0 + 3 * c.pre_dir, i); }
     else { q_ = v.at(V_LPQ + c.prop_src, i); g_ = v.at(V_LPG + c.prop_src, i); }
     if (writer) { v.at(V_LPQ + c.prop_slot, i) = q_; v.at(V_LPG + c.prop_slot, i) = g_; }
   }
   double sq = 0.0, sg = 0.0;
   bool have_s = false;
   if (f & PRE_SAMPLE) {
-    if (c.sample_src < 0) { sq = v.at(V_Q0 + 3 * c.pre_dir, i); sg = v.at(V_G0 + 3 * c.pre_dir, i); }
+    if (c.sample_src < 0) { sq = cc ? cc->q[c.pre_dir] : v.at(V_Q0 + 3 * c.pre_dir, i); sg = cc ? cc->g[c.pre_dir] : v.at(V_G0 + 3 * c.pre_dir, i); }
     else { sq = v.at(V_LPQ + c.sample_src, i); sg = v.at(V_LPG + c.sample_src, i); }
     have_s = true;
     if (writer) { v.at(V_SQ, i) = sq; v.at(V_SG, i) = sg; }
@@ -96,8 +109,8 @@ PPCX_HD CoordVals coord_pre(const Cmd& c, const VecRef& v, int i, int flat, bool
   if (!have_s && (f & (PRE_STORE_DRAW | PRE_WELFORD | PRE_NEW_TRANSITION | PRE_EPS_TRY))) {
     sq = v.at(V_SQ, i); sg = v.at(V_SG, i);
   }
-  if ((f & PRE_STORE_DRAW) && writer) draws[(long)c.draw_index * D + flat] = sq;
-  double minv = v.at(V_MINV, i);
+  if ((f & PRE_STORE_DRAW) && writer && draws) draws[(long)c.draw_index * D + flat] = sq;
+  double minv = cc ? cc->minv : v.at(V_MINV, i);
   if (f & (PRE_WELFORD | PRE_METRIC)) {
     double m = v.at(V_WM, i), m2 = v.at(V_WM2, i);
     if (f & PRE_WELFORD) {                     // Welford update with the new sample (Stan welford_var_estimator)
@@ -133,7 +146,8 @@ PPCX_HD CoordVals coord_pre(const Cmd& c, const VecRef& v, int i, int flat, bool
     r.p = coord_normal((uint32_t)flat, c.rng_c1, 3u, c.rng_c3, k0, k1) / sqrt(minv);
     if (writer) { v.at(V_Q1, i) = sq; v.at(V_G1, i) = sg; v.at(V_P1, i) = r.p; *T0 += r.p * r.p * minv; }
   } else {
-    r.q = v.at(V_Q0 + 3 * c.dir, i); r.p = v.at(V_P0 + 3 * c.dir, i); r.g = v.at(V_G0 + 3 * c.dir, i);
+    if (cc) { r.q = cc->q[c.dir]; r.p = cc->p[c.dir]; r.g = cc->g[c.dir]; }
+    else { r.q = v.at(V_Q0 + 3 * c.dir, i); r.p = v.at(V_P0 + 3 * c.dir, i); r.g = v.at(V_G0 + 3 * c.dir, i); }
   }
   if ((f & PRE_SAVE_NEAR) && writer) v.at(V_PNEAR, i) = r.p;
   return r;
@@ -410,13 +424,13 @@ PPCX_HD void chain_advance(ChainState& st, const Cmd& ex, const Reduced& rd, dou
       if ((h - st.H0) > 1000.0) st.divergent = 1;
       ++st.n_leapfrog; ++st.total_leapfrogs;
       const double dlt = st.H0 - h;
-      st.sum_metro += dlt > 0.0 ? 1.0 : exp(dlt);
+      st.sum_metro += dlt > 0.0 ? 1.0 : (dlt < -700.0 ? 0.0 : fast_exp(dlt));
       double n_lsw = dlt, n_V = Vn; int n_src = -1;            // the node closed so far: this leaf
       bool valid = !st.divergent;
       if (valid) for (int d = 0; d < ex.n_merge; ++d) {         // merges in post-order, as the recursion unwinds
         const double lsw_sub = log_sum_exp(st.Llsw[d], n_lsw);
         bool take_final = n_lsw > lsw_sub;
-        if (!take_final) take_final = tree_uniform(st) < exp(n_lsw - lsw_sub);
+        if (!take_final) take_final = tree_uniform(st) < fast_exp(n_lsw - lsw_sub);
         if (!take_final) { n_src = d; n_V = st.LV[d]; }
         n_lsw = lsw_sub;
         if (!all_positive(rd.dots[d])) { valid = false; break; }
@@ -433,7 +447,7 @@ PPCX_HD void chain_advance(ChainState& st, const Cmd& ex, const Reduced& rd, dou
       // the new subtree is valid and complete (base_nuts::transition after build_tree)
       ++st.depth;
       bool accept = n_lsw > st.lsw_tree;
-      if (!accept) accept = tree_uniform(st) < exp(n_lsw - st.lsw_tree);
+      if (!accept) accept = tree_uniform(st) < fast_exp(n_lsw - st.lsw_tree);
       if (accept) { nc.pre_flags |= PRE_SAMPLE; nc.sample_src = n_src; st.V_sample = n_V; }
       st.lsw_tree = log_sum_exp(st.lsw_tree, n_lsw);
       const bool persist = all_positive(rd.top);

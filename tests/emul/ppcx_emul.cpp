@@ -1,6 +1,6 @@
 // CPU emulation harness (TEST INFRASTRUCTURE): drives the SAME __host__ __device__ source that the
 // gfx950 kernels are built from (ppcseq_amd/csrc/ppcx_{math,model,nuts,gene}.h) with plain loops in
-// place of wavefront lanes, so the host logic -- command protocol, iterative NUTS tree, adaptation --
+// place of wavefront lanes and workgroups, so the host logic -- command protocol, iterative NUTS tree, adaptation --
 // can be checked against the oracle without a GPU. It is never loaded by the product package.
 #include <stdint.h>
 #include <stdlib.h>
@@ -34,34 +34,48 @@ static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, c
 }
 
 template <int CM>
-static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double* draws, double* red) {
+static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double* red) {
   constexpr int NCM = CM + 1;
   const Dims& d = m.d;
   for (int k = 0; k < PT_COUNT; ++k) red[k] = 0.0;
-  if (c.type == CMD_DONE) return;
+  if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
   for (int g = 0; g < d.G; ++g) {
+    // log-likelihood kernel (one lane per gene here)
     GeneCtx<CM> x;
-    gene_begin<CM>(d, c, v, g, true, draws, x);
-    if (c.type == CMD_FLUSH) continue;
+    gene_load<CM>(d, c, v, g, x);
+    gene_consts<CM>(x);
     CellAcc<CM> acc; acc.zero();
     gene_cells<CM>(d, x, m.counts.data() + (size_t)g * d.S, m.E.data(), m.expo.data(), m.X.data(), 0, 1, acc);
-    double pn[NCM], part[10];
-    gene_end<CM>(d, c, v, x, acc, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.ncell.data(), m.Lg1.data(), part, pn);
+    // close kernel
+    GeneCtx<CM> x2;
+    gene_load<CM>(d, c, v, g, x2);
+    double pn[NCM], minv[NCM], part[10];
+    gene_finish<CM>(d, c, v, x2, acc, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.ncell.data(), m.Lg1.data(), part, pn, minv);
     for (int k = 0; k < 10; ++k) red[k] += part[k];
     if (c.type == CMD_LEAF) {
       NodeVals nv[NCM];
       for (int j = 0; j < NCM; ++j) nv[j] = NodeVals{pn[j], pn[j]};
       for (int lev = 0; lev < c.n_merge; ++lev)
-        for (int j = 0; j < x.ncoord; ++j) coord_merge_dots(v, x.idx[j], lev, pn[j], x.minv[j], &nv[j], red + PT_DOTS + 6 * lev);
-      if (!c.subtree_complete) { for (int j = 0; j < x.ncoord; ++j) coord_store_slot(v, x.idx[j], c.n_merge, pn[j], nv[j]); }
-      else for (int j = 0; j < x.ncoord; ++j) coord_top_dots(v, x.idx[j], c.dir, pn[j], x.minv[j], nv[j], red + PT_TOP);
+        for (int j = 0; j < x2.ncoord; ++j) coord_merge_dots(v, x2.idx[j], lev, pn[j], minv[j], &nv[j], red + PT_DOTS + 6 * lev);
+      if (!c.subtree_complete) { for (int j = 0; j < x2.ncoord; ++j) coord_store_slot(v, x2.idx[j], c.n_merge, pn[j], nv[j]); }
+      else for (int j = 0; j < x2.ncoord; ++j) coord_top_dots(v, x2.idx[j], c.dir, pn[j], minv[j], nv[j], red + PT_TOP);
     }
   }
 }
-static void gene_pass_dispatch(const EmulModel& m, const Cmd& c, const VecRef& v, double* draws, double* red) {
-  if (m.CM == 2) gene_pass<2>(m, c, v, draws, red);
-  else if (m.CM == 4) gene_pass<4>(m, c, v, draws, red);
-  else gene_pass<8>(m, c, v, draws, red);
+static void gene_pass_dispatch(const EmulModel& m, const Cmd& c, const VecRef& v, double* red) {
+  if (m.CM == 2) gene_pass<2>(m, c, v, red);
+  else if (m.CM == 4) gene_pass<4>(m, c, v, red);
+  else gene_pass<8>(m, c, v, red);
+}
+// kernel B: state machine, then the per-coordinate operations of the new command; returns T0 of the gene coordinates
+static double update_pass(const EmulModel& m, ChainState& st, const Cmd& ex, const double* red, double T0_prev,
+                          bool have_parts, const VecRef& v, const VecRef& h, const ChainIO& io, Cmd& nc) {
+  Reduced rd;
+  chain_step(m.d, st, ex, red, T0_prev, have_parts, h, io, rd, nc);
+  double T0 = 0.0;
+  if (nc.type != CMD_DONE)
+    for (int i = 3; i < m.d.off_tail; ++i) coord_update(nc, v, i, io.draws, m.d.D, &T0);
+  return T0;
 }
 
 struct EmulCfg { int chains, iter, warmup; unsigned long long seed; double adapt_delta; int max_treedepth;
@@ -80,10 +94,10 @@ int emul_log_prob_grad(int G, int S, int C, int K, const int32_t* counts, const 
   Cmd c, n; cmd_clear(c);
   ChainIO io; memset(&io, 0, sizeof io);
   VecRef v{vecs.data(), D}, h{hv.data(), 8};
-  chain_step(m.d, st, c, red.data(), false, h, io, n); c = n;
+  double T0 = update_pass(m, st, c, red.data(), 0.0, false, v, h, io, n); c = n;
   while (c.type != CMD_DONE) {
-    gene_pass_dispatch(m, c, v, nullptr, red.data());
-    chain_step(m.d, st, c, red.data(), true, h, io, n); c = n;
+    gene_pass_dispatch(m, c, v, red.data());
+    T0 = update_pass(m, st, c, red.data(), T0, true, v, h, io, n); c = n;
   }
   *lp = st.lp_eval;
   for (int i = 0; i < D; ++i) grad[i] = vecs[(size_t)V_G1 * D + i];
@@ -115,11 +129,11 @@ int emul_fit_nuts(int G, int S, int C, int K, const int32_t* counts, const doubl
     io.out.treedepth = treedepth + (size_t)ch * cfg->iter; io.out.n_leapfrog = n_leapfrog + (size_t)ch * cfg->iter;
     io.out.divergent = divergent + (size_t)ch * cfg->iter; io.out.accept = accept + (size_t)ch * cfg->iter;
     VecRef v{vecs.data(), D}, h{hv.data(), 8};
-    chain_step(m.d, st, c, red.data(), false, h, io, n); c = n;
+    double T0 = update_pass(m, st, c, red.data(), 0.0, false, v, h, io, n); c = n;
     long guard = 0;
     while (c.type != CMD_DONE) {
-      gene_pass_dispatch(m, c, v, io.draws, red.data());
-      chain_step(m.d, st, c, red.data(), true, h, io, n); c = n;
+      gene_pass_dispatch(m, c, v, red.data());
+      T0 = update_pass(m, st, c, red.data(), T0, true, v, h, io, n); c = n;
       if (++guard > 50000000L) { rc = -5; break; }
     }
     if (st.error) rc = -3;

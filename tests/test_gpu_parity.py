@@ -257,7 +257,7 @@ def test_full_size_properties_20k_by_200(L):
         for lanes in [4, 8, 16, 32, 64]:
             m.set_launch(lanes, 0)
             lp, g = m.log_prob_grad(u)
-            assert abs(lp - lp0) <= 1e-12 * abs(lp0) and np.max(np.abs(g - g0) / (1 + np.abs(g0))) < 1e-11
+            assert abs(lp - lp0) <= 1e-12 * abs(lp0) and np.max(np.abs(g - g0) / (1 + np.abs(g0))) < 1e-9
         m.set_launch(0, 0)
         ex1, ex2 = np.array([5, 777, 123456], np.int32), np.array([5, 777, 123456, 3999999], np.int32)
         m.set_exclusions(ex1); a = m.log_prob_grad(u)[0]
