@@ -33,6 +33,7 @@ struct ppcx_model {
   std::vector<double> X_host, expo_host;
   int* d_counts = nullptr;
   double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_ncell = nullptr, *d_Lg1 = nullptr;
+  LogTabEntry* d_logtab = nullptr;
   hipStream_t stream = nullptr;
 };
 
@@ -143,6 +144,8 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   MHIP(hipMalloc(&m->d_SyX, sizeof(double) * (size_t)C * G));
   MHIP(hipMalloc(&m->d_ncell, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_Lg1, sizeof(double) * G));
+  MHIP(hipMalloc(&m->d_logtab, sizeof(LogTabEntry) * kLogTabSize));
+  { LogTabEntry tab[kLogTabSize]; fill_log_table(tab); MHIP(hipMemcpy(m->d_logtab, tab, sizeof(tab), hipMemcpyHostToDevice)); }
   MHIP(hipMemcpy(m->d_E, E.data(), sizeof(double) * S, hipMemcpyHostToDevice));
   MHIP(hipMemcpy(m->d_expo, exposure, sizeof(double) * S, hipMemcpyHostToDevice));
   MHIP(hipMemcpy(m->d_X, X, sizeof(double) * (size_t)S * C, hipMemcpyHostToDevice));
@@ -176,7 +179,7 @@ extern "C" void ppcx_model_destroy(ppcx_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipFree(m->d_counts); (void)hipFree(m->d_E); (void)hipFree(m->d_expo); (void)hipFree(m->d_X);
-  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_Lg1);
+  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -263,7 +266,7 @@ static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
 static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
   LoglikArgs la;
   la.d = m->d; la.counts = m->d_counts; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
-  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums;
+  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab;
   hipError_t e = launch_loglik_kernel(m->L, m->CM, la, m->nblocks, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("loglik kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
@@ -364,7 +367,7 @@ extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, 
     HIPCHK(hipMemcpy(states.data(), current_states(w), sizeof(ChainState) * nb, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(hq.data(), current_hyper(w), sizeof(double) * hq.size(), hipMemcpyDeviceToHost));
     for (int c = 0; c < nb; ++c) {
-      lp[p0 + c] = states[c].lp_eval;
+      lp[p0 + c] = states[c].sc.lp_eval;
       if (grad) {
         double* gc = grad + (size_t)(p0 + c) * D;
         HIPCHK(hipMemcpy(gc, w.vecs + ((size_t)c * V_COUNT + V_G1) * w.Dpad, sizeof(double) * D, hipMemcpyDeviceToHost));
@@ -381,7 +384,7 @@ extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, 
 // same work.
 extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs, int reps, int n_merge,
                                       double* ms_per_launch, int* cmd_type) {
-  const int which = n_merge >= 100 ? (n_merge / 100) : 0;      // 0 loglik, 1 close, 2 both (development aid)
+  const int which = n_merge >= 100 ? (n_merge / 100) : 0;      // 0 loglik, 1 close, 2 both, 3 update (development aid)
   if (n_merge >= 100) n_merge %= 100;
   if (!m || nchains < 1 || reps < 1 || !ms_per_launch) return fail(PPCX_ERR_ARG, "bad arguments");
   HIPCHK(hipSetDevice(m->device));
@@ -416,7 +419,7 @@ extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) if ((rc = (which == 1 ? launch_close(m, w, nchains) : (which == 2 ? launch_gene(m, w, nchains) : launch_loglik(m, w, nchains)))) != PPCX_OK) return rc;
+  for (int i = 0; i < reps; ++i) if ((rc = (which == 1 ? launch_close(m, w, nchains) : (which == 2 ? launch_gene(m, w, nchains) : (which == 3 ? launch_update(m, w, nchains, io) : launch_loglik(m, w, nchains))))) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
@@ -499,7 +502,7 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
     if (hipMemcpy(states.data(), current_states(G->w), sizeof(ChainState) * G->n, hipMemcpyDeviceToHost) != hipSuccess) {
       G->rc = PPCX_ERR_HIP; G->err = "reading back the chain states failed"; return;
     }
-    for (int c = 0; c < G->n; ++c) G->leap += states[c].total_leapfrogs;
+    for (int c = 0; c < G->n; ++c) G->leap += states[c].sc.total_leapfrogs;
   };
   {
     std::vector<std::thread> th;

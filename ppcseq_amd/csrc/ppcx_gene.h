@@ -52,56 +52,34 @@ PPCX_HD void gene_consts(GeneCtx<CM>& x) {
   x.gp.A = fast_exp(x.gp.coef[0] + x.gp.sigma_raw);
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PPCX_WAVE_ANY(p) (__any(p) != 0)
-#else
-#define PPCX_WAVE_ANY(p) (p)
-#endif
-
-// the cells s = sub, sub+L, ... of the gene's row of counts, four at a time: the counts and per-sample
-// constants of a chunk are fetched before any arithmetic so their latency overlaps the previous chunk
+// the cells s = sub, sub+L, ... of the gene's row of counts. Excluded cells (count < 0) are skipped.
 template <int CM>
 PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, const double* sE, const double* sExpo,
-                        const double* sX, int sub, int L, CellAcc<CM>& acc) {
+                        const double* sX, const LogTabEntry* tab, int sub, int L, CellAcc<CM>& acc) {
   const int S = d.S, C = d.C;
   const GeneParams<CM>& gp = x.gp;
-#ifndef PPCX_CELL_UNROLL
-#define PPCX_CELL_UNROLL 1
-#endif
-  constexpr int U = PPCX_CELL_UNROLL;
-  for (int s0 = sub; s0 < S; s0 += U * L) {
-    int y[U]; double u[U]; int sc[U];
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const int s = s0 + k * L;
-      const bool in = x.active && s < S;
-      sc[k] = s < S ? s : S - 1;
-      y[k] = in ? row[sc[k]] : -1;
-    }
-    if (x.fast) {
-#pragma unroll
-      for (int k = 0; k < U; ++k) u[k] = y[k] >= 0 ? sE[sc[k]] * gp.A : 0.0;
-    } else {
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        double t = sExpo[sc[k]] + gp.sigma_raw;
-#pragma unroll
-        for (int cc = 0; cc < CM; ++cc) if (cc < C) t += sX[cc * S + sc[k]] * gp.coef[cc];
-        u[k] = y[k] >= 0 ? fast_exp(t) : 0.0;
+  if (!x.active) return;
+  if (x.fast) {
+    for (int s = sub; s < S; s += L) {
+      const int y = row[s];
+      if (y >= 0) {
+        double xsig;
+        cell_eval(y, sE[s] * gp.A, gp.phi, gp.lgphi, gp.dgphi, tab, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
+        acc.T2u += xsig;
       }
     }
-    bool small = false;
+  } else {
+    for (int s = sub; s < S; s += L) {
+      const int y = row[s];
+      if (y >= 0) {
+        double t = sExpo[s] + gp.sigma_raw;
 #pragma unroll
-    for (int k = 0; k < U; ++k) small = small || (y[k] > 0 && (double)y[k] + gp.phi < 8.0);
-    const bool small_any = PPCX_WAVE_ANY(small);
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) t += sX[cc * S + s] * gp.coef[cc];
+        double xsig;
+        cell_eval(y, fast_exp(t), gp.phi, gp.lgphi, gp.dgphi, tab, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
+        acc.T2u += xsig;
 #pragma unroll
-    for (int k = 0; k < U; ++k) {
-      double xsig;
-      cell_eval(y[k], u[k], gp.phi, gp.lgphi, gp.dgphi, small_any, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
-      acc.T2u += xsig;
-      if (!x.fast) {
-#pragma unroll
-        for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.T2x[cc] = fma(sX[cc * S + sc[k]], xsig, acc.T2x[cc]);
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.T2x[cc] = fma(sX[cc * S + s], xsig, acc.T2x[cc]);
       }
     }
   }
@@ -162,8 +140,8 @@ struct ChainIO {
   double* draws;                 // this chain's [n_keep][D] or null
   ChainOut out;
 };
-PPCX_HD void chain_step(const Dims& d, ChainState& st, const Cmd& ex, const double* red, double T0_genes,
-                        bool have_parts, const VecRef& hv, const ChainIO& io, Reduced& rd, Cmd& nc) {
+PPCX_HD void chain_step(const Dims& d, ChainScalars& st, TreeArrays& ta, const Cmd& ex, const double* red,
+                        double T0_genes, bool have_parts, const VecRef& hv, const ChainIO& io, Reduced& rd, Cmd& nc) {
   double lp = 0.0; bool finite = true;
   if (have_parts && ex.type != CMD_FLUSH) {
     rd.lp_genes = red[PT_LP];
@@ -188,7 +166,7 @@ PPCX_HD void chain_step(const Dims& d, ChainState& st, const Cmd& ex, const doub
       }
     }
   }
-  chain_advance(st, ex, rd, lp, finite, io.out, nc);
+  chain_advance(st, ta, ex, rd, lp, finite, io.out, nc);
   nc.k0 = st.k0; nc.k1 = st.k1;
   if (nc.type != CMD_DONE) {
     double T0h = 0.0;

@@ -15,6 +15,7 @@ struct LoglikArgs {
   long Dpad;
   const Cmd* cmds;              // [chains]
   double* sums;                 // [chains][5+CM][G]
+  const LogTabEntry* logtab;    // 128 entries (device)
 };
 
 struct CloseArgs {

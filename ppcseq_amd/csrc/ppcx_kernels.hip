@@ -40,10 +40,12 @@ __global__ __launch_bounds__(256, 4) void ppcx_loglik_kernel(LoglikArgs a) {
   if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
   const Dims& d = a.d;
   const int S = d.S, C = d.C;
-  double* sE = lds;                            // exp(exposure_s)
+  LogTabEntry* stab = reinterpret_cast<LogTabEntry*>(lds);   // 128 x {1/c, log c}: 2 KB, 16-byte aligned at the LDS base
+  double* sE = lds + 2 * kLogTabSize;          // exp(exposure_s)
   double* sExpo = sE + S;
   double* sX = sExpo + S;                      // S x C column-major
   const int tid = threadIdx.x;
+  for (int i = tid; i < kLogTabSize; i += 256) stab[i] = a.logtab[i];
   const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
   for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
   if (any_generic) {
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256, 4) void ppcx_loglik_kernel(LoglikArgs a) {
     gene_load<CM>(d, c, v, grp * GPW + gl, x);
     gene_consts<CM>(x);
     CellAcc<CM> acc; acc.zero();
-    gene_cells<CM>(d, x, a.counts + (long)x.gg * S, sE, sExpo, sX, sub, L, acc);
+    gene_cells<CM>(d, x, a.counts + (long)x.gg * S, sE, sExpo, sX, stab, sub, L, acc);
     // L-lane butterfly: every lane of the gene ends with the gene totals
 #pragma unroll
     for (int msk = 1; msk < L; msk <<= 1) {
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
   __shared__ Reduced s_rd;
   const int chain = blockIdx.y, tid = threadIdx.x;
   const ChainState* st_in = a.states_in + chain;
-  if (st_in->phase == PH_DONE) {               // finished chain: carry its final state across the double buffer
+  if (st_in->sc.phase == PH_DONE) {            // finished chain: carry its final state across the double buffer
     if (blockIdx.x == 0) {
       if (tid == 0) { a.states_out[chain] = *st_in; a.cmds_out[chain] = a.cmds_in[chain]; }
       const double* hi = a.hyper_in + (long)chain * V_COUNT * 8;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
   const double* hvg = a.hyper_in + (long)chain * V_COUNT * 8;
   for (int i = tid; i < V_COUNT * 8; i += 256) hv[i] = hvg[i];
   for (int i = tid; i < PT_COUNT; i += 256) red[i] = 0.0;
-  const bool have_parts = st_in->phase != PH_START;
+  const bool have_parts = st_in->sc.phase != PH_START;
   __syncthreads();
   double T0g = 0.0;
   if (have_parts) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
     __syncthreads();
   }
   if (tid == 0) {
-    ChainState& st = s_st;
+    ChainScalars st = s_st.sc;                   // scalars in registers; the run-time-indexed arrays stay in LDS
     ChainIO io;
     const bool lead = blockIdx.x == 0;           // only one workgroup writes the outputs
     io.draws = (lead && a.draws) ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
@@ -238,7 +240,12 @@ __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
     io.out.n_leapfrog = (lead && a.out_n_leapfrog) ? a.out_n_leapfrog + (long)chain * a.iter : nullptr;
     io.out.divergent = (lead && a.out_divergent) ? a.out_divergent + (long)chain * a.iter : nullptr;
     io.out.accept = (lead && a.out_accept) ? a.out_accept + (long)chain * a.iter : nullptr;
-    chain_step(d, st, ex, red, T0g, have_parts, VecRef{hv, 8}, io, s_rd, s_nc);
+#ifndef PPCX_ABLATE_NOSTEP
+    chain_step(d, st, s_st.ta, ex, red, T0g, have_parts, VecRef{hv, 8}, io, s_rd, s_nc);
+#else
+    if (have_parts) s_nc = ex; else chain_step(d, st, s_st.ta, ex, red, T0g, have_parts, VecRef{hv, 8}, io, s_rd, s_nc);
+#endif
+    s_st.sc = st;
     if (lead && st.phase == PH_DONE) a.done[chain] = 1 + st.error;
   }
   __syncthreads();
@@ -255,7 +262,9 @@ __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
   double T0 = 0.0;
   if (nc.type != CMD_DONE) {
     double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
+#ifndef PPCX_ABLATE_NOCOORD
     if (i_first < d.off_tail) coord_update(nc, v, i_first, draws, d.D, &T0, &cache);
+#endif
     for (int i = i_first + gridDim.x * 256; i < d.off_tail; i += gridDim.x * 256)
       coord_update(nc, v, i, draws, d.D, &T0);
   }
@@ -370,7 +379,7 @@ static hipError_t launch_loglik_l(int L, const LoglikArgs& a, dim3 grid, size_t 
   }
 }
 hipError_t launch_loglik_kernel(int L, int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st) {
-  const size_t lds_bytes = sizeof(double) * ((size_t)a.d.S * (2 + a.d.C));
+  const size_t lds_bytes = sizeof(double) * (2 * kLogTabSize + (size_t)a.d.S * (2 + a.d.C));
   const dim3 grid(nblocks, nchains);
   if (CM <= 2) return launch_loglik_l<2>(L, a, grid, lds_bytes, st);
   if (CM <= 4) return launch_loglik_l<4>(L, a, grid, lds_bytes, st);

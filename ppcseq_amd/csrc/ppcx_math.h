@@ -60,6 +60,53 @@ PPCX_HD double fast_log(double x) {
   return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Table-driven fp64 logarithm for the cell loop (no division, no frexp, no selects): for x = 2^e m,
+// m in [1,2), the top 7 mantissa bits j pick c_j = 1 + (j + 1/2)/128; with r = m/c_j - 1 (one FMA with the
+// tabulated 1/c_j, |r| < 2^-8)  log x = e ln2 + log c_j + log1p(r), log1p by its degree-6 Taylor polynomial
+// (truncation < r^7/7 ~ 2e-18). The 128 x {1/c_j, log c_j} table (2 KB) lives in LDS on the device.
+// Valid for finite normal x > 0; inf/NaN inputs give finite garbage, which the callers catch through the
+// non-finite gradient that accompanies them (u = inf makes u/w NaN).
+// ---------------------------------------------------------------------------------------------
+struct LogTabEntry { double cinv, logc; };
+constexpr int kLogTabSize = 128;
+
+PPCX_HD unsigned long long dbl_bits(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (unsigned long long)__double_as_longlong(x);
+#else
+  unsigned long long b; __builtin_memcpy(&b, &x, 8); return b;
+#endif
+}
+PPCX_HD double bits_dbl(unsigned long long b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __longlong_as_double((long long)b);
+#else
+  double x; __builtin_memcpy(&x, &b, 8); return x;
+#endif
+}
+inline void fill_log_table(LogTabEntry* t) {          // host: exact-to-rounding entries
+  for (int j = 0; j < kLogTabSize; ++j) {
+    const long double c = 1.0L + ((long double)j + 0.5L) / (long double)kLogTabSize;
+    t[j].cinv = (double)(1.0L / c);
+    t[j].logc = (double)logl(1.0L / (long double)t[j].cinv);   // log of the reciprocal actually stored
+  }
+}
+PPCX_HD double table_log(double x, const LogTabEntry* tab) {
+  const unsigned long long b = dbl_bits(x);
+  const int e = (int)(b >> 52) - 1023;
+  const int j = (int)(b >> 45) & (kLogTabSize - 1);
+  const double m = bits_dbl((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+  const LogTabEntry t = tab[j];
+  const double r = fma(m, t.cinv, -1.0);
+  double p = fma(r, -1.0 / 6.0, 0.2);
+  p = fma(r, p, -0.25);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -0.5);
+  p = fma(r, p, 1.0);
+  return fma((double)e, 6.93147180559945286227e-01, fma(r, p, t.logc));
+}
+
 // exp(x) for |x| < 700 by x = k ln2 + r, |r| <= ln2/2 and the rational form of Sun's fdlibm e_exp.c
 // (public domain algorithm; error < 1 ulp): c = r - r^2 P(r^2), exp(r) = 1 + r + r c / (2 - c).
 PPCX_HD double fast_exp(double x) {
@@ -101,6 +148,19 @@ PPCX_HD void lgamma_digamma_stirling(double x, double lx, double rx, double* lg,
   d = 1.0 / 132.0 - r2 * d;
   d = 1.0 / 240.0 - r2 * d;
   d = 1.0 / 252.0 - r2 * d;
+  d = 1.0 / 120.0 - r2 * d;
+  d = 1.0 / 12.0 - r2 * d;
+  *dg = lx - 0.5 * rx - r2 * d;
+}
+
+// 4-term tails: valid for x >= 32 (next terms x^-9/1188 and x^-10/132 are < 3e-17 there)
+PPCX_HD void lgamma_digamma_stirling4(double x, double lx, double rx, double* lg, double* dg) {
+  const double r2 = rx * rx;
+  double t = 1.0 / 1260.0 - r2 * (1.0 / 1680.0);
+  t = 1.0 / 360.0 - r2 * t;
+  t = 1.0 / 12.0 - r2 * t;
+  *lg = (x - 0.5) * lx - x + 0.91893853320467274178 + rx * t;
+  double d = 1.0 / 252.0 - r2 * (1.0 / 240.0);
   d = 1.0 / 120.0 - r2 * d;
   d = 1.0 / 12.0 - r2 * d;
   *dg = lx - 0.5 * rx - r2 * d;

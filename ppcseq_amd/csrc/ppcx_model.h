@@ -79,25 +79,35 @@ struct CellAcc {
     for (int c = 0; c < CM; ++c) T2x[c] = 0.0; }
 };
 
-// One cell once u = exp(t) is known. The common case (y + phi >= 8) is straight-line code so that the
-// compiler can overlap the dependency chains of neighbouring cells; `small_any` is true when some lane of
-// the wavefront (device) / this cell (host) has 0 < y + phi < 8 and needs the shifted recurrence.
-// y < 0 marks an excluded or out-of-range cell and contributes nothing; y == 0 contributes
-// lgamma(phi) - lgamma(phi) = 0 exactly to T3/T4.
-PPCX_HD void cell_eval(int y, double u, double phi, double lgphi, double dgphi, bool small_any,
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PPCX_WAVE_ANY(p) (__any(p) != 0)
+#define PPCX_WAVE_ALL(p) (__all(p) != 0)
+#else
+#define PPCX_WAVE_ANY(p) (p)
+#define PPCX_WAVE_ALL(p) (p)
+#endif
+
+// One valid cell (y >= 0) once u = exp(t) is known. The per-lane work is free of selects and divisions in
+// the common case: the three regimes of the Stirling evaluation are chosen per WAVEFRONT (device) / per cell
+// (host emulation): every lane has y+phi >= 32 (4-term tails), every lane >= 8 (7-term tails), or some lane
+// needs the shift-by-8 recurrence. y == 0 contributes lgamma(phi) - lgamma(phi) = 0 up to rounding.
+PPCX_HD void cell_eval(int y, double u, double phi, double lgphi, double dgphi, const LogTabEntry* tab,
                        double* T1, double* SP, double* T3, double* T4, double* xsig) {
-  const bool valid = y >= 0, pos = y > 0;
-  const double x = (double)(valid ? y : 0) + phi;
+  const double x = (double)y + phi;
   const double w = 1.0 + u;
-  const double sp = valid ? fast_log(w) : 0.0;
-  *xsig = valid ? x * (u * fast_rcp(w)) : 0.0;
+  const double sp = table_log(w, tab);
+  *xsig = x * (u * fast_rcp(w));
   *T1 = fma(x, sp, *T1);
   *SP += sp;
-  const bool big = x >= 8.0;
-  const double xe = big ? x : x + 8.0;
   double lg, dg;
-  lgamma_digamma_stirling(xe, fast_log(xe), fast_rcp(xe), &lg, &dg);
-  if (small_any) {
+  if (PPCX_WAVE_ALL(x >= 32.0)) {
+    lgamma_digamma_stirling4(x, table_log(x, tab), fast_rcp(x), &lg, &dg);
+  } else if (PPCX_WAVE_ALL(x >= 8.0)) {
+    lgamma_digamma_stirling(x, table_log(x, tab), fast_rcp(x), &lg, &dg);
+  } else {
+    const bool big = x >= 8.0;
+    const double xe = big ? x : x + 8.0;
+    lgamma_digamma_stirling(xe, table_log(xe, tab), fast_rcp(xe), &lg, &dg);
     double P = x, dP = 1.0;
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
@@ -105,12 +115,12 @@ PPCX_HD void cell_eval(int y, double u, double phi, double lgphi, double dgphi, 
       dP = fma(dP, f, P);
       P = P * f;
     }
-    const double lP = fast_log(P), qP = dP * fast_rcp(P);
+    const double lP = table_log(P, tab), qP = dP * fast_rcp(P);
     lg -= big ? 0.0 : lP;
     dg -= big ? 0.0 : qP;
   }
-  *T3 += pos ? lg - lgphi : 0.0;
-  *T4 += pos ? dg - dgphi : 0.0;
+  *T3 += lg - lgphi;
+  *T4 += dg - dgphi;
 }
 
 // everything a gene's lanes need that does not depend on the sample

@@ -217,7 +217,8 @@ struct NutsConfig {
 
 enum Phase : int { PH_START = 0, PH_EVAL_ONLY, PH_INIT, PH_EPS, PH_TREE, PH_FLUSH, PH_DONE };
 
-struct ChainState {
+// scalar part of a chain's state: lives in registers while the state machine runs
+struct ChainScalars {
   int phase, error;
   int eval_only;
   uint32_t k0, k1;
@@ -230,7 +231,6 @@ struct ChainState {
   int depth, leaf_n, dir, n_leapfrog, divergent;
   uint32_t rng_j;
   double H0, lsw_tree, sum_metro;
-  double Llsw[kLev + 1], LV[kLev + 1];
   double V_sample;
   double T0h;                    // kinetic energy of the fresh hyper momenta
   double mu, s_bar, x_bar; int da_counter;
@@ -238,6 +238,10 @@ struct ChainState {
   double lp_eval;                // CMD_EVAL result
   long long total_leapfrogs;
 };
+
+// per-level log weights / potentials of the parked left subtrees (indexed at run time: kept in LDS)
+struct TreeArrays { double Llsw[kLev + 1], LV[kLev + 1]; };
+struct ChainState { ChainScalars sc; TreeArrays ta; };
 
 struct Reduced {
   double lp_genes, hsum[6], T0, T1, nonfinite;
@@ -249,14 +253,15 @@ struct ChainOut {                // per-chain diagnostic arrays (device pointers
   double* stepsize; int* treedepth; int* n_leapfrog; int* divergent; double* accept;   // [iter]
 };
 
-PPCX_HD double tree_uniform(ChainState& st) {
+PPCX_HD double tree_uniform(ChainScalars& st) {
   return coord_uniform(st.rng_j++, (uint32_t)st.it, 2u, 0u, st.k0, st.k1);
 }
 PPCX_HD bool all_positive(const double* d6) {
   return d6[0] > 0 && d6[1] > 0 && d6[2] > 0 && d6[3] > 0 && d6[4] > 0 && d6[5] > 0;
 }
 
-PPCX_HD void state_init(ChainState& st, const NutsConfig& cfg, int local_chain, int eval_only) {
+PPCX_HD void state_init(ChainState& cs, const NutsConfig& cfg, int local_chain, int eval_only) {
+  ChainScalars& st = cs.sc;
   st.phase = PH_START; st.error = 0; st.eval_only = eval_only;
   st.k0 = seed32(cfg.seed); st.k1 = (uint32_t)(cfg.chain_id_offset + local_chain);
   st.iter = cfg.iter; st.warmup = cfg.warmup; st.max_depth = cfg.max_treedepth > kMaxDepth ? kMaxDepth : cfg.max_treedepth;
@@ -274,7 +279,7 @@ PPCX_HD void state_init(ChainState& st, const NutsConfig& cfg, int local_chain, 
   st.mu = 0; st.s_bar = 0; st.x_bar = 0; st.da_counter = 0;
   st.win_next = st.init_buffer + st.window - 1; st.win_size = st.window; st.win_counter = 0; st.wn = 0;
   st.lp_eval = 0; st.total_leapfrogs = 0;
-  for (int d = 0; d <= kLev; ++d) { st.Llsw[d] = 0; st.LV[d] = 0; }
+  for (int d = 0; d <= kLev; ++d) { cs.ta.Llsw[d] = 0; cs.ta.LV[d] = 0; }
 }
 
 PPCX_HD void cmd_clear(Cmd& c) {
@@ -286,18 +291,18 @@ PPCX_HD void cmd_clear(Cmd& c) {
 }
 
 // ----- helpers that fill in the next command ---------------------------------------------------------
-PPCX_HD void issue_eps_try(ChainState& st, Cmd& nc) {
+PPCX_HD void issue_eps_try(ChainScalars& st, Cmd& nc) {
   nc.type = CMD_EPS_TRY; nc.pre_flags |= PRE_EPS_TRY; nc.dir = 1; nc.eps = st.eps;
   nc.rng_c1 = (unsigned)st.eps_call; nc.rng_c3 = (unsigned)st.eps_attempt;
   st.eps_attempt++;
   st.phase = PH_EPS;
 }
-PPCX_HD void start_eps_heuristic(ChainState& st, Cmd& nc) {   // Stan base_hmc::init_stepsize
+PPCX_HD void start_eps_heuristic(ChainScalars& st, Cmd& nc) {   // Stan base_hmc::init_stepsize
   st.eps_dir = 0; st.eps_attempt = 0;
   if (st.eps == 0 || st.eps > 1e7 || isnan(st.eps)) { st.error = 2; nc.type = CMD_DONE; st.phase = PH_DONE; return; }
   issue_eps_try(st, nc);
 }
-PPCX_HD void set_leaf(ChainState& st, Cmd& nc, int leaf_n) {
+PPCX_HD void set_leaf(ChainScalars& st, Cmd& nc, int leaf_n) {
   st.leaf_n = leaf_n;
   nc.type = CMD_LEAF; nc.dir = st.dir; nc.eps = st.dir ? st.eps : -st.eps;
   nc.leaf_n = leaf_n;
@@ -307,12 +312,12 @@ PPCX_HD void set_leaf(ChainState& st, Cmd& nc, int leaf_n) {
   nc.subtree_complete = (leaf_n == (1 << st.depth));
   st.phase = PH_TREE;
 }
-PPCX_HD void start_doubling(ChainState& st, Cmd& nc) {
+PPCX_HD void start_doubling(ChainScalars& st, Cmd& nc) {
   st.dir = tree_uniform(st) > 0.5 ? 1 : 0;
   nc.pre_flags |= PRE_SAVE_NEAR;
   set_leaf(st, nc, 1);
 }
-PPCX_HD void start_transition(ChainState& st, Cmd& nc) {
+PPCX_HD void start_transition(ChainScalars& st, Cmd& nc) {
   nc.pre_flags |= PRE_NEW_TRANSITION;
   nc.rng_c1 = (unsigned)st.it;
   st.depth = 0; st.rng_j = 0; st.lsw_tree = 0.0; st.sum_metro = 0.0; st.n_leapfrog = 0; st.divergent = 0;
@@ -320,7 +325,7 @@ PPCX_HD void start_transition(ChainState& st, Cmd& nc) {
 }
 
 // A transition has ended: diagnostics, adaptation (Stan adapt_diag_e_nuts::transition), next command.
-PPCX_HD void end_transition(ChainState& st, Cmd& nc, const ChainOut& out) {
+PPCX_HD void end_transition(ChainScalars& st, Cmd& nc, const ChainOut& out) {
   const int it = st.it;
   const double accept = st.sum_metro / (double)st.n_leapfrog;
   if (out.stepsize) out.stepsize[it] = st.eps;
@@ -375,8 +380,8 @@ PPCX_HD void end_transition(ChainState& st, Cmd& nc, const ChainOut& out) {
 // (hyper-coordinate contributions already added), `lp` the complete log density at the evaluated point.
 // Fills `nc` (except hyp_q, which the caller sets after the hyper pre-ops/half step).
 // ---------------------------------------------------------------------------------------------------
-PPCX_HD void chain_advance(ChainState& st, const Cmd& ex, const Reduced& rd, double lp, bool grads_finite,
-                           const ChainOut& out, Cmd& nc) {
+PPCX_HD void chain_advance(ChainScalars& st, TreeArrays& ta, const Cmd& ex, const Reduced& rd, double lp,
+                           bool grads_finite, const ChainOut& out, Cmd& nc) {
   cmd_clear(nc);
   switch (st.phase) {
     case PH_START: {
@@ -428,10 +433,10 @@ PPCX_HD void chain_advance(ChainState& st, const Cmd& ex, const Reduced& rd, dou
       double n_lsw = dlt, n_V = Vn; int n_src = -1;            // the node closed so far: this leaf
       bool valid = !st.divergent;
       if (valid) for (int d = 0; d < ex.n_merge; ++d) {         // merges in post-order, as the recursion unwinds
-        const double lsw_sub = log_sum_exp(st.Llsw[d], n_lsw);
+        const double lsw_sub = log_sum_exp(ta.Llsw[d], n_lsw);
         bool take_final = n_lsw > lsw_sub;
         if (!take_final) take_final = tree_uniform(st) < fast_exp(n_lsw - lsw_sub);
-        if (!take_final) { n_src = d; n_V = st.LV[d]; }
+        if (!take_final) { n_src = d; n_V = ta.LV[d]; }
         n_lsw = lsw_sub;
         if (!all_positive(rd.dots[d])) { valid = false; break; }
       }
@@ -439,7 +444,7 @@ PPCX_HD void chain_advance(ChainState& st, const Cmd& ex, const Reduced& rd, dou
       if (!valid) { end_transition(st, nc, out); return; }
       if (!ex.subtree_complete) {
         const int m = ex.n_merge;
-        st.Llsw[m] = n_lsw; st.LV[m] = n_V;
+        ta.Llsw[m] = n_lsw; ta.LV[m] = n_V;
         nc.pre_flags |= PRE_PROP; nc.prop_slot = m; nc.prop_src = n_src;
         set_leaf(st, nc, ex.leaf_n + 1);
         return;

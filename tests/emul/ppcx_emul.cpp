@@ -10,6 +10,8 @@
 
 using namespace ppcx;
 
+static const LogTabEntry* log_table() { static LogTabEntry t[kLogTabSize]; static bool init = false; if (!init) { fill_log_table(t); init = true; } return t; }
+
 struct EmulModel {
   Dims d; int CM;
   std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, ncell, Lg1;
@@ -45,7 +47,7 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
     gene_load<CM>(d, c, v, g, x);
     gene_consts<CM>(x);
     CellAcc<CM> acc; acc.zero();
-    gene_cells<CM>(d, x, m.counts.data() + (size_t)g * d.S, m.E.data(), m.expo.data(), m.X.data(), 0, 1, acc);
+    gene_cells<CM>(d, x, m.counts.data() + (size_t)g * d.S, m.E.data(), m.expo.data(), m.X.data(), log_table(), 0, 1, acc);
     // close kernel
     GeneCtx<CM> x2;
     gene_load<CM>(d, c, v, g, x2);
@@ -71,7 +73,7 @@ static void gene_pass_dispatch(const EmulModel& m, const Cmd& c, const VecRef& v
 static double update_pass(const EmulModel& m, ChainState& st, const Cmd& ex, const double* red, double T0_prev,
                           bool have_parts, const VecRef& v, const VecRef& h, const ChainIO& io, Cmd& nc) {
   Reduced rd;
-  chain_step(m.d, st, ex, red, T0_prev, have_parts, h, io, rd, nc);
+  chain_step(m.d, st.sc, st.ta, ex, red, T0_prev, have_parts, h, io, rd, nc);
   double T0 = 0.0;
   if (nc.type != CMD_DONE)
     for (int i = 3; i < m.d.off_tail; ++i) coord_update(nc, v, i, io.draws, m.d.D, &T0);
@@ -99,7 +101,7 @@ int emul_log_prob_grad(int G, int S, int C, int K, const int32_t* counts, const 
     gene_pass_dispatch(m, c, v, red.data());
     T0 = update_pass(m, st, c, red.data(), T0, true, v, h, io, n); c = n;
   }
-  *lp = st.lp_eval;
+  *lp = st.sc.lp_eval;
   for (int i = 0; i < D; ++i) grad[i] = vecs[(size_t)V_G1 * D + i];
   for (int k = 0; k < 6; ++k) grad[hyper_index(m.d, k)] = hv[V_G1 * 8 + k];
   return 0;
@@ -136,7 +138,7 @@ int emul_fit_nuts(int G, int S, int C, int K, const int32_t* counts, const doubl
       T0 = update_pass(m, st, c, red.data(), T0, true, v, h, io, n); c = n;
       if (++guard > 50000000L) { rc = -5; break; }
     }
-    if (st.error) rc = -3;
+    if (st.sc.error) rc = -3;
   }
   return rc;
 }
