@@ -49,12 +49,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
+    # one process per GPU; if a box has fewer GPUs than ranks (single-GPU rehearsal) ranks share devices
+    n_dev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % n_dev
+    backend = os.environ.get("PPCX_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; "gloo" for rehearsals
     if dist_on:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    dev = f"cuda:{local_rank}"
-    torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    dev = f"cuda:{dev_index}" if backend == "nccl" else "cpu"   # where the collectives' tensors live
+    torch.cuda.set_device(dev_index)
 
     G, S, C = args.genes, args.samples, 2
     seed_data = 20253
@@ -67,7 +71,7 @@ def main():
     if dist_on:
         arrays = D.broadcast_arrays(arrays, device=dev)
     K = int(arrays["K"][0])
-    model = _lib.Model(arrays["counts"], arrays["X"], arrays["exposure"], K, device=local_rank)
+    model = _lib.Model(arrays["counts"], arrays["X"], arrays["exposure"], K, device=dev_index)
     if args.lanes or args.groups_per_wave:
         model.set_launch(args.lanes, args.groups_per_wave)
     Dm = model.D

@@ -271,3 +271,40 @@ def test_full_size_properties_20k_by_200(L):
         assert dg["n_leapfrog"].min() >= 1 and np.isfinite(dg["stepsize"]).all()
     finally:
         m.close()
+
+
+def test_reference_readme_example(L, bundled):
+    """Second known answer held by the reference: README.md:50-92 -- genes with FDR < 0.01 (15 genes) checked
+    against 500 negative controls, `~ Label`, percent_false_positive_genes = 5: only CYP1A1 and LYZ have one
+    failed sample, which is a deleterious outlier (README shows the reference's default VB path; the NUTS path
+    must reach the same calls)."""
+    import pandas as pd
+    from ppcseq_amd.methods import identify_outliers
+    genes = [str(g) for g in bundled["genes"]]
+    samples = [str(s) for s in bundled["samples"]]
+    G, S = len(genes), len(samples)
+    df = pd.DataFrame({
+        "symbol": np.repeat(genes, S), "sample": np.tile(samples, G), "value": bundled["value"].reshape(-1),
+        "PValue": np.repeat(bundled["PValue"], S), "FDR": np.repeat(bundled["FDR"], S),
+        "Label": np.tile(bundled["Label"].astype(str), G)})
+    df["is_significant"] = df["FDR"] < 0.01
+    res = identify_outliers(df, formula="~ Label", sample="sample", transcript="symbol", abundance="value",
+                            significance="PValue", do_check="is_significant", percent_false_positive_genes=5,
+                            cores=4, seed=7)
+    assert len(res) == 15
+    flagged = res[res["tot_deleterious_outliers"] > 0]["symbol"].tolist()
+    by = res.set_index("symbol")
+    # the two robust calls of the README, on the samples the reference's figure shows
+    assert {"CYP1A1", "LYZ"} <= set(flagged)
+    for g, smp in [("CYP1A1", "11165PP"), ("LYZ", "11164PP")]:
+        sw = by.loc[g, "sample_wise_data"]
+        assert sw[sw["deleterious_outliers"]]["sample"].tolist() == [smp]
+        assert by.loc[g, "ppc_samples_failed"] == 1
+    # pfp = 5 % tolerates false-positive genes and the 0.24 % tail quantile rests on ~5 of 2100 draws, so other
+    # calls may appear, but only borderline ones (count within 2x of the interval end), and few
+    extras = [g for g in flagged if g not in ("CYP1A1", "LYZ")]
+    assert len(extras) <= 3
+    for g in extras:
+        sw = by.loc[g, "sample_wise_data"]
+        bad = sw[sw["deleterious_outliers"]]
+        assert len(bad) == 1 and float(bad["value"].iloc[0]) < 2.0 * float(bad[".upper"].iloc[0]) + 10
