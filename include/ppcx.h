@@ -112,6 +112,23 @@ PPCX_API void ppcx_fit_free(ppcx_fit* f);
 PPCX_API void ppcx_do_inference_C(const int* dims, const int* counts, const double* X, const double* exposure_rate,
                          const int* excl, const double* reals, double* ci, double* slope, int* status);
 
+/* --- gene shards = the reference's map_rect over gene shards (inst/stan/negBinomial_MPI.stan:226-240;
+ * round-robin gene->shard assignment R/utilities.R:130-136; here contiguous gene ranges). A shard model holds
+ * genes [g0, g1) of a G_total-gene problem whose first K_total genes are the checked ones; the six
+ * hyper-parameters are replicated and every leapfrog exchanges one vector of <= 76 partial sums (log density,
+ * 6 hyper-gradient sums, kinetic energies, U-turn dot products).
+ *   ppcx_fit_nuts_shards : all shards in this process on one device (testing, or splitting oversize problems)
+ *   ppcx_fit_nuts_comm   : one shard per process / GPU, sums all-reduced with RCCL over xGMI              */
+typedef struct ppcx_comm ppcx_comm;
+PPCX_API int ppcx_model_create_shard(int device, int G_total, int S, int C, int K_total, int g0, int g1,
+                            const int32_t* counts_shard, const double* X, const double* exposure_rate,
+                            double lambda_mu_mu, int n_excl, const int32_t* excl_local, ppcx_model** out);
+PPCX_API int ppcx_fit_nuts_shards(ppcx_model** shards, int n_shards, const ppcx_nuts_config* cfg, ppcx_fit** fits);
+PPCX_API int ppcx_comm_unique_id(char* out128);               /* rank 0 creates it, the host layer broadcasts it */
+PPCX_API int ppcx_comm_create(int device, int nranks, int rank, const char* id128, ppcx_comm** out);
+PPCX_API void ppcx_comm_destroy(ppcx_comm* c);
+PPCX_API int ppcx_fit_nuts_comm(ppcx_model* shard, const ppcx_nuts_config* cfg, ppcx_comm* comm, ppcx_fit** out);
+
 /* Development aid, not part of the reference boundary: mean duration (ms) of `reps` back-to-back launches of
  * the gene kernel on the command the chains hold after `warm_pairs` launch pairs (n_merge < 0: as is).       */
 PPCX_API int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs, int reps, int n_merge,

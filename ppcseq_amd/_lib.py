@@ -19,6 +19,8 @@ EXPORTS = [
     "ppcx_model_set_launch", "ppcx_model_get_launch", "ppcx_model_dim", "ppcx_model_destroy", "ppcx_log_prob_grad",
     "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
     "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_bench_gene_kernel",
+    "ppcx_model_create_shard", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
+    "ppcx_fit_nuts_comm",
 ]
 
 
@@ -68,6 +70,13 @@ def load() -> C.CDLL:
     lib.ppcx_fit_free.argtypes = [C.c_void_p]
     lib.ppcx_bench_gene_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.POINTER(C.c_int)]
     lib.ppcx_fit_free.restype = None
+    lib.ppcx_model_create_shard.argtypes = [C.c_int] * 7 + [ip, dp, dp, C.c_double, C.c_int, ip, C.POINTER(C.c_void_p)]
+    lib.ppcx_fit_nuts_shards.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(NutsConfig), C.POINTER(C.c_void_p)]
+    lib.ppcx_comm_unique_id.argtypes = [C.c_char_p]
+    lib.ppcx_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.ppcx_comm_destroy.argtypes = [C.c_void_p]
+    lib.ppcx_comm_destroy.restype = None
+    lib.ppcx_fit_nuts_comm.argtypes = [C.c_void_p, C.POINTER(NutsConfig), C.c_void_p, C.POINTER(C.c_void_p)]
     _lib = lib
     return lib
 
@@ -88,7 +97,9 @@ def device_count() -> int:
 class Model:
     """Device-resident model inputs (Stan data block in logical form, include/ppcx.h)."""
 
-    def __init__(self, counts, X, exposure_rate, K, lambda_mu_mu=5.612671, excl=None, device=0):
+    def __init__(self, counts, X, exposure_rate, K, lambda_mu_mu=5.612671, excl=None, device=0, shard=None):
+        """shard = (G_total, K_total, g0, g1): `counts` then holds only genes [g0, g1) of the whole problem and K is
+        ignored (the shard's checked genes are those of the first K_total that fall in its range)."""
         lib = load()
         counts = np.ascontiguousarray(counts, dtype=np.int32)
         if counts.ndim != 2:
@@ -103,9 +114,19 @@ class Model:
         excl = np.ascontiguousarray(excl if excl is not None else np.zeros(0), dtype=np.int32)
         self.X, self.exposure_rate = X, exposure_rate
         h = C.c_void_p()
-        _check(lib.ppcx_model_create(int(device), self.G, self.S, self.C, self.K, _p(counts, C.c_int32),
-                                     _p(X, C.c_double), _p(exposure_rate, C.c_double), float(lambda_mu_mu),
-                                     int(excl.size), _p(excl, C.c_int32), C.byref(h)))
+        self.shard = shard
+        if shard is None:
+            _check(lib.ppcx_model_create(int(device), self.G, self.S, self.C, self.K, _p(counts, C.c_int32),
+                                         _p(X, C.c_double), _p(exposure_rate, C.c_double), float(lambda_mu_mu),
+                                         int(excl.size), _p(excl, C.c_int32), C.byref(h)))
+        else:
+            Gt, Kt, g0, g1 = (int(v) for v in shard)
+            if g1 - g0 != self.G:
+                raise ValueError("counts must hold exactly the genes of the shard")
+            self.K = max(0, min(g1, Kt) - min(g0, Kt))
+            _check(lib.ppcx_model_create_shard(int(device), Gt, self.S, self.C, Kt, g0, g1, _p(counts, C.c_int32),
+                                               _p(X, C.c_double), _p(exposure_rate, C.c_double), float(lambda_mu_mu),
+                                               int(excl.size), _p(excl, C.c_int32), C.byref(h)))
         self._h = h
         self.D = int(lib.ppcx_model_dim(h))
 
@@ -138,6 +159,13 @@ class Model:
         _check(load().ppcx_fit_nuts(self._h, C.byref(cfg), C.byref(h)))
         return Fit(self, h)
 
+    def fit_nuts_comm(self, comm: "Comm", **kw) -> "Fit":
+        """This process's gene shard of a multi-GPU fit; partial sums all-reduced over RCCL every leapfrog."""
+        cfg = _make_cfg(**kw)
+        h = C.c_void_p()
+        _check(load().ppcx_fit_nuts_comm(self._h, C.byref(cfg), comm._h, C.byref(h)))
+        return Fit(self, h)
+
     def bench_gene_kernel(self, nchains=1, warm_pairs=40, reps=50, n_merge=1):
         ms, t = C.c_double(), C.c_int()
         _check(load().ppcx_bench_gene_kernel(self._h, nchains, warm_pairs, reps, n_merge, C.byref(ms), C.byref(t)))
@@ -153,6 +181,42 @@ class Model:
             self.close()
         except Exception:
             pass
+
+
+def _make_cfg(chains=3, iter=300, warmup=150, seed=1, adapt_delta=0.8, max_treedepth=10, init_radius=2.0,
+              stepsize0=1.0, init_buffer=75, term_buffer=50, window=25, chain_id_offset=0):
+    return NutsConfig(chains, iter, warmup, seed, adapt_delta, max_treedepth, init_radius, stepsize0,
+                      init_buffer, term_buffer, window, chain_id_offset)
+
+
+def fit_nuts_shards(models, **kw):
+    """Gene-sharded fit with every shard in this process (one device): returns one Fit per shard."""
+    cfg = _make_cfg(**kw)
+    n = len(models)
+    hm = (C.c_void_p * n)(*[m._h for m in models])
+    hf = (C.c_void_p * n)()
+    _check(load().ppcx_fit_nuts_shards(hm, n, C.byref(cfg), hf))
+    return [Fit(m, C.c_void_p(h)) for m, h in zip(models, hf)]
+
+
+class Comm:
+    """RCCL communicator of a gene-sharded multi-GPU fit (one rank per GPU)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(load().ppcx_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, nranks, rank, unique_id: bytes, device=0):
+        h = C.c_void_p()
+        _check(load().ppcx_comm_create(int(device), int(nranks), int(rank), unique_id, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().ppcx_comm_destroy(self._h)
+            self._h = None
 
 
 @dataclass

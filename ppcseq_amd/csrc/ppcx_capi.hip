@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <chrono>
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string>
 #include <thread>
@@ -194,13 +195,13 @@ extern "C" void ppcx_nuts_config_default(ppcx_nuts_config* c) {
 // device scratch of one run of the launch pump. States, commands, hyper-coordinate vectors and the T0 slab
 // are double-buffered: update launch k reads buffer k&1 and writes buffer (k+1)&1.
 struct Work {
-  double *vecs = nullptr, *hyper_vecs[2] = {nullptr, nullptr}, *partials = nullptr, *t0[2] = {nullptr, nullptr}, *sums = nullptr;
+  double *vecs = nullptr, *hyper_vecs[2] = {nullptr, nullptr}, *partials = nullptr, *t0[2] = {nullptr, nullptr}, *sums = nullptr, *red = nullptr;
   Cmd* cmds[2] = {nullptr, nullptr}; ChainState* states[2] = {nullptr, nullptr}; int* done = nullptr;
   int* done_host = nullptr;
   long Dpad = 0; int nb_update = 1, nb_close = 1; long launches = 0;
   hipStream_t stream = nullptr; bool own_stream = false;
   ~Work() {
-    (void)hipFree(vecs); (void)hipFree(partials); (void)hipFree(done); (void)hipFree(sums);
+    (void)hipFree(vecs); (void)hipFree(partials); (void)hipFree(done); (void)hipFree(sums); (void)hipFree(red);
     for (int i = 0; i < 2; ++i) { (void)hipFree(hyper_vecs[i]); (void)hipFree(t0[i]); (void)hipFree(cmds[i]); (void)hipFree(states[i]); }
     if (done_host) (void)hipHostFree(done_host);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -218,6 +219,8 @@ static int work_alloc(Work& w, ppcx_model* m, int nchains) {
   HIPCHK(hipMalloc(&w.sums, sizeof(double) * (size_t)nchains * (5 + m->CM) * m->d.G));
   HIPCHK(hipMemsetAsync(w.sums, 0, sizeof(double) * (size_t)nchains * (5 + m->CM) * m->d.G, w.stream));
   HIPCHK(hipMalloc(&w.done, sizeof(int) * nchains));
+  HIPCHK(hipMalloc(&w.red, sizeof(double) * (size_t)nchains * PT_COUNT));
+  HIPCHK(hipMemsetAsync(w.red, 0, sizeof(double) * (size_t)nchains * PT_COUNT, w.stream));
   HIPCHK(hipHostMalloc(&w.done_host, sizeof(int) * nchains));
   for (int i = 0; i < 2; ++i) {
     HIPCHK(hipMalloc(&w.hyper_vecs[i], sizeof(double) * (size_t)nchains * V_COUNT * 8));
@@ -252,8 +255,8 @@ static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
   ua.states_in = w.states[in]; ua.states_out = w.states[out];
   ua.cmds_in = w.cmds[in]; ua.cmds_out = w.cmds[out];
   ua.hyper_in = w.hyper_vecs[in]; ua.hyper_out = w.hyper_vecs[out];
-  ua.t0_in = w.t0[in]; ua.t0_out = w.t0[out];
-  ua.partials = w.partials; ua.nblocks_close = w.nb_close;
+  ua.t0_out = w.t0[out];
+  ua.red = w.red;
   ua.vecs = w.vecs; ua.Dpad = w.Dpad;
   ua.draws = io.draws; ua.draws_chain_stride = io.draws_stride; ua.n_keep = io.n_keep; ua.iter = io.iter;
   ua.out_lp = io.lp; ua.out_stepsize = io.stepsize; ua.out_treedepth = io.treedepth; ua.out_n_leapfrog = io.nleap;
@@ -279,6 +282,14 @@ static int launch_close(ppcx_model* m, Work& w, int nchains) {
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("close kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
 }
+static int launch_reduce(ppcx_model* m, Work& w, int nchains) {
+  ReduceArgs ra;
+  ra.cmds = w.cmds[w.launches & 1]; ra.partials = w.partials; ra.nblocks_close = w.nb_close;
+  ra.t0 = w.t0[w.launches & 1]; ra.nblocks_update = w.nb_update; ra.red = w.red;
+  hipError_t e = launch_reduce_kernel(ra, nchains, w.stream);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("reduce kernel: ") + hipGetErrorString(e));
+  return PPCX_OK;
+}
 static int launch_gene(ppcx_model* m, Work& w, int nchains) {   // one gradient evaluation = loglik + close
   int rc = launch_loglik(m, w, nchains);
   return rc != PPCX_OK ? rc : launch_close(m, w, nchains);
@@ -288,29 +299,77 @@ static double* current_hyper(Work& w) { return w.hyper_vecs[w.launches & 1]; }
 
 struct PumpStats { double kA_ms_sum = 0, kC_ms_sum = 0, kU_ms_sum = 0; long long kA_samples = 0; double chain_launches = 0; long long pairs = 0; };
 
-// Launch (gene, update) pairs until every chain reports done. `max_pairs` bounds the loop.
-static int pump(ppcx_model* m, Work& w, int nchains, const RunIO& io, long long max_pairs, bool time_kernels,
+// ---- RCCL, bound at run time (dlopen) so the library has no link-time dependency and shares the RCCL that
+// the process may already have loaded (torch ships one)
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId_t;
+struct RcclApi {
+  void* h = nullptr;
+  int (*GetUniqueId)(ncclUniqueId_t*) = nullptr;
+  int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId_t, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+  if (g_rccl.h) return PPCX_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.h) break; }
+  if (!g_rccl.h) return fail(PPCX_ERR_HIP, "cannot load librccl.so");
+  g_rccl.GetUniqueId = (int (*)(ncclUniqueId_t*))dlsym(g_rccl.h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(ncclComm_t*, int, ncclUniqueId_t, int))dlsym(g_rccl.h, "ncclCommInitRank");
+  g_rccl.CommDestroy = (int (*)(ncclComm_t))dlsym(g_rccl.h, "ncclCommDestroy");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t))dlsym(g_rccl.h, "ncclAllReduce");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) return fail(PPCX_ERR_HIP, "librccl.so lacks the expected symbols");
+  return PPCX_OK;
+}
+struct ppcx_comm { ncclComm_t comm = nullptr; int nranks = 1, rank = 0, device = 0; };
+
+// One shard of a run: its model (all genes, or a contiguous gene range) and its device scratch.
+struct Shard { ppcx_model* m; Work* w; RunIO io; };
+
+// Launch (loglik, close, reduce [, exchange], update) rounds until every chain reports done. With several
+// shards in one process they share shard 0's stream and their partial sums are added by ppcx_sum_shards_kernel;
+// with a communicator the sums are all-reduced over the ranks (RCCL, xGMI) between reduce and update.
+static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long max_pairs, bool time_kernels,
                 PumpStats* stats) {
-  hipStream_t st = w.stream;
-  int rc = launch_update(m, w, nchains, io);                   // PH_START -> first command
-  if (rc != PPCX_OK) return rc;
+  const int ns = (int)sh.size();
+  hipStream_t st = sh[0].w->stream;
+  int rc = PPCX_OK;
+  for (int k = 0; k < ns; ++k) if ((rc = launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;   // PH_START
   const int batch = 32, sample_every = 16;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   if (time_kernels) { HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1)); HIPCHK(hipEventCreate(&ev2)); HIPCHK(hipEventCreate(&ev3)); }
   long long pairs = 0; int n_done = 0;
+  Work& w0 = *sh[0].w;
   while (true) {
     bool sampled = false;
     for (int i = 0; i < batch; ++i, ++pairs) {
       const bool smp = time_kernels && !sampled && (pairs / batch) % sample_every == 0 && i == batch / 2;
       if (smp) HIPCHK(hipEventRecord(ev0, st));
-      if ((rc = launch_loglik(m, w, nchains)) != PPCX_OK) return rc;
+      for (int k = 0; k < ns; ++k) if ((rc = launch_loglik(sh[k].m, *sh[k].w, nchains)) != PPCX_OK) return rc;
       if (smp) { HIPCHK(hipEventRecord(ev1, st)); sampled = true; }
-      if ((rc = launch_close(m, w, nchains)) != PPCX_OK) return rc;
+      for (int k = 0; k < ns; ++k) {
+        if ((rc = launch_close(sh[k].m, *sh[k].w, nchains)) != PPCX_OK) return rc;
+        if ((rc = launch_reduce(sh[k].m, *sh[k].w, nchains)) != PPCX_OK) return rc;
+      }
+      if (ns > 1) {
+        ShardSumArgs sa; sa.n_shards = ns; sa.n = nchains * PT_COUNT;
+        for (int k = 0; k < ns; ++k) sa.bufs[k] = sh[k].w->red;
+        hipError_t e = launch_sum_shards_kernel(sa, st);
+        if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("shard sum kernel: ") + hipGetErrorString(e));
+      }
+      if (comm && comm->nranks >= 1 && comm->comm) {
+        const int e = g_rccl.AllReduce(w0.red, w0.red, (size_t)nchains * PT_COUNT, /*ncclDouble*/ 8, /*ncclSum*/ 0, comm->comm, st);
+        if (e != 0) return fail(PPCX_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"));
+      }
       if (smp) HIPCHK(hipEventRecord(ev2, st));
-      if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
+      for (int k = 0; k < ns; ++k) if ((rc = launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;
       if (smp) HIPCHK(hipEventRecord(ev3, st));
     }
-    HIPCHK(hipMemcpyAsync(w.done_host, w.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(w0.done_host, w0.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (sampled && n_done == 0) {               // only launches in which every chain was still active
       float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
@@ -320,9 +379,9 @@ static int pump(ppcx_model* m, Work& w, int nchains, const RunIO& io, long long 
     }
     n_done = 0;
     for (int c = 0; c < nchains; ++c) {
-      if (w.done_host[c]) ++n_done;
-      if (w.done_host[c] == 2) rc = fail(PPCX_ERR_INIT, "no finite initial point after 100 attempts");
-      if (w.done_host[c] == 3) rc = fail(PPCX_ERR_STEPSIZE, "step-size heuristic diverged");
+      if (w0.done_host[c]) ++n_done;
+      if (w0.done_host[c] == 2) rc = fail(PPCX_ERR_INIT, "no finite initial point after 100 attempts");
+      if (w0.done_host[c] == 3) rc = fail(PPCX_ERR_STEPSIZE, "step-size heuristic diverged");
     }
     if (n_done == nchains) break;
     if (pairs > max_pairs) { rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished"); break; }
@@ -333,6 +392,12 @@ static int pump(ppcx_model* m, Work& w, int nchains, const RunIO& io, long long 
   if (ev3) (void)hipEventDestroy(ev3);
   stats->pairs = pairs;
   return rc;
+}
+static int pump(ppcx_model* m, Work& w, int nchains, const RunIO& io, long long max_pairs, bool time_kernels,
+                PumpStats* stats, ppcx_comm* comm = nullptr) {
+  std::vector<Shard> sh(1);
+  sh[0].m = m; sh[0].w = &w; sh[0].io = io;
+  return pump(sh, nchains, comm, max_pairs, time_kernels, stats);
 }
 
 extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, double* lp, double* grad) {
@@ -403,6 +468,7 @@ extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs
   if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
   for (int i = 0; i < warm_pairs; ++i) {
     if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
+    if ((rc = launch_reduce(m, w, nchains)) != PPCX_OK) return rc;
     if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
   }
   HIPCHK(hipStreamSynchronize(st));
@@ -528,6 +594,132 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   f->launch_triples = ps.pairs;
   *out = f;
   return PPCX_OK;
+}
+
+// ---- gene shards (second mode; the reference's map_rect over gene shards, .stan:226-240) ---------
+extern "C" int ppcx_model_create_shard(int device, int G_total, int S, int C, int K_total, int g0, int g1,
+                                       const int32_t* counts_shard, const double* X, const double* exposure,
+                                       double lambda_mu_mu, int n_excl, const int32_t* excl_local, ppcx_model** out) {
+  if (g0 < 0 || g1 <= g0 || g1 > G_total || K_total < 0 || K_total > G_total) return fail(PPCX_ERR_ARG, "bad gene range");
+  const int k0 = g0 < K_total ? g0 : K_total;
+  const int k1 = g1 < K_total ? g1 : K_total;
+  int rc = ppcx_model_create(device, g1 - g0, S, C, k1 - k0, counts_shard, X, exposure, lambda_mu_mu, n_excl, excl_local, out);
+  if (rc != PPCX_OK) return rc;
+  (*out)->d.Gt = G_total; (*out)->d.Kt = K_total; (*out)->d.g0 = g0; (*out)->d.k0 = k0;
+  return PPCX_OK;
+}
+
+static int fit_sharded(ppcx_model** models, int ns, const ppcx_nuts_config* cfg, ppcx_comm* comm, ppcx_fit** fits) {
+  if (!models || !cfg || !fits || ns < 1 || ns > kMaxShards) return fail(PPCX_ERR_ARG, "bad shard arguments");
+  for (int k = 0; k < ns; ++k) { fits[k] = nullptr; if (!models[k]) return fail(PPCX_ERR_ARG, "NULL shard model"); }
+  if (cfg->chains < 1 || cfg->chains > 1024 || cfg->iter < 1 || cfg->warmup < 0 || cfg->warmup > cfg->iter)
+    return fail(PPCX_ERR_ARG, "need 1<=chains<=1024, iter>=1, 0<=warmup<=iter");
+  if (cfg->max_treedepth < 1 || cfg->max_treedepth > kMaxDepth) return fail(PPCX_ERR_LIMIT, "max_treedepth must be in 1..10");
+  const int dev = models[0]->device;
+  for (int k = 0; k < ns; ++k) if (models[k]->device != dev) return fail(PPCX_ERR_ARG, "in-process shards must share a device");
+  HIPCHK(hipSetDevice(dev));
+  const int nch = cfg->chains, iter = cfg->iter, n_keep = cfg->iter - cfg->warmup;
+  NutsConfig nc;
+  nc.chains = nch; nc.iter = iter; nc.warmup = cfg->warmup; nc.seed = cfg->seed; nc.adapt_delta = cfg->adapt_delta;
+  nc.max_treedepth = cfg->max_treedepth; nc.init_radius = cfg->init_radius; nc.stepsize0 = cfg->stepsize0;
+  nc.init_buffer = cfg->init_buffer; nc.term_buffer = cfg->term_buffer; nc.window = cfg->window;
+  nc.chain_id_offset = cfg->chain_id_offset;
+  std::vector<Work> works(ns);
+  std::vector<Shard> sh(ns);
+  int rc = PPCX_OK;
+  auto cleanup = [&]() { for (int k = 0; k < ns; ++k) { ppcx_fit_free(fits[k]); fits[k] = nullptr; } };
+#define SHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+  for (int k = 0; k < ns; ++k) {
+    ppcx_model* m = models[k];
+    const int D = m->d.D;
+    choose_launch(m, nch);
+    ppcx_fit* f = new ppcx_fit();
+    fits[k] = f;
+    f->m = m; f->chains = nch; f->n_keep = n_keep; f->iter = iter; f->cfg = nc;
+    if (n_keep > 0) SHIP(hipMalloc(&f->d_draws, sizeof(double) * (size_t)nch * n_keep * D));
+    if (n_keep > 0) SHIP(hipMalloc(&f->d_lp, sizeof(double) * (size_t)nch * n_keep));
+    SHIP(hipMalloc(&f->d_stepsize, sizeof(double) * (size_t)nch * iter));
+    SHIP(hipMalloc(&f->d_accept, sizeof(double) * (size_t)nch * iter));
+    SHIP(hipMalloc(&f->d_treedepth, sizeof(int) * (size_t)nch * iter));
+    SHIP(hipMalloc(&f->d_nleap, sizeof(int) * (size_t)nch * iter));
+    SHIP(hipMalloc(&f->d_div, sizeof(int) * (size_t)nch * iter));
+    SHIP(hipMemset(f->d_stepsize, 0, sizeof(double) * (size_t)nch * iter));
+    SHIP(hipMemset(f->d_accept, 0, sizeof(double) * (size_t)nch * iter));
+    SHIP(hipMemset(f->d_treedepth, 0, sizeof(int) * (size_t)nch * iter));
+    SHIP(hipMemset(f->d_nleap, 0, sizeof(int) * (size_t)nch * iter));
+    SHIP(hipMemset(f->d_div, 0, sizeof(int) * (size_t)nch * iter));
+    works[k].stream = models[0]->stream;        // all in-process shards are ordered on one stream
+    if ((rc = work_alloc(works[k], m, nch)) != PPCX_OK) { cleanup(); return rc; }
+    std::vector<ChainState> states(nch);
+    for (int c = 0; c < nch; ++c) state_init(states[c], nc, c, 0);   // every shard replicates the same chains
+    SHIP(hipMemcpy(works[k].states[0], states.data(), sizeof(ChainState) * nch, hipMemcpyHostToDevice));
+    sh[k].m = m; sh[k].w = &works[k];
+    RunIO& io = sh[k].io;
+    io.draws = f->d_draws; io.draws_stride = (long)n_keep * D; io.n_keep = n_keep; io.iter = iter;
+    io.lp = f->d_lp; io.stepsize = f->d_stepsize; io.accept = f->d_accept; io.treedepth = f->d_treedepth;
+    io.nleap = f->d_nleap; io.div = f->d_div;
+  }
+  SHIP(hipStreamSynchronize(models[0]->stream));
+  const long long max_pairs = (long long)iter * ((1LL << cfg->max_treedepth) + 8) + 100000;
+  PumpStats ps;
+  const auto t0 = std::chrono::steady_clock::now();
+  rc = pump(sh, nch, comm, max_pairs, true, &ps);
+  const auto t1 = std::chrono::steady_clock::now();
+  if (rc != PPCX_OK) { cleanup(); return rc; }
+  std::vector<ChainState> states(nch);
+  SHIP(hipMemcpy(states.data(), current_states(works[0]), sizeof(ChainState) * nch, hipMemcpyDeviceToHost));
+  long long leap = 0;
+  for (int c = 0; c < nch; ++c) leap += states[c].sc.total_leapfrogs;
+  for (int k = 0; k < ns; ++k) {
+    ppcx_fit* f = fits[k];
+    f->seconds = std::chrono::duration<double>(t1 - t0).count();
+    f->grad_evals = leap;
+    f->kA_samples = ps.kA_samples;
+    f->kA_ms_mean = ps.kA_samples ? ps.kA_ms_sum / (double)ps.kA_samples : 0.0;
+    f->kA_chain_launches_mean = ps.kA_samples ? ps.chain_launches / (double)ps.kA_samples : 0.0;
+    f->kC_ms_mean = ps.kA_samples ? ps.kC_ms_sum / (double)ps.kA_samples : 0.0;
+    f->kU_ms_mean = ps.kA_samples ? ps.kU_ms_sum / (double)ps.kA_samples : 0.0;
+    f->launch_triples = ps.pairs;
+  }
+  return PPCX_OK;
+}
+extern "C" int ppcx_fit_nuts_shards(ppcx_model** models, int n_shards, const ppcx_nuts_config* cfg, ppcx_fit** fits) {
+  return fit_sharded(models, n_shards, cfg, nullptr, fits);
+}
+
+// ---- one gene shard per process, sums all-reduced over RCCL -------------------------------------------
+extern "C" int ppcx_comm_unique_id(char* out128) {
+  if (!out128) return fail(PPCX_ERR_ARG, "NULL buffer");
+  int rc = rccl_load();
+  if (rc != PPCX_OK) return rc;
+  ncclUniqueId_t id;
+  const int e = g_rccl.GetUniqueId(&id);
+  if (e != 0) return fail(PPCX_ERR_HIP, "ncclGetUniqueId failed");
+  memcpy(out128, id.internal, 128);
+  return PPCX_OK;
+}
+extern "C" int ppcx_comm_create(int device, int nranks, int rank, const char* id128, ppcx_comm** out) {
+  if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(PPCX_ERR_ARG, "bad communicator arguments");
+  *out = nullptr;
+  int rc = rccl_load();
+  if (rc != PPCX_OK) return rc;
+  HIPCHK(hipSetDevice(device));
+  ncclUniqueId_t id; memcpy(id.internal, id128, 128);
+  ppcx_comm* c = new ppcx_comm();
+  c->nranks = nranks; c->rank = rank; c->device = device;
+  const int e = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+  if (e != 0) { delete c; return fail(PPCX_ERR_HIP, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error")); }
+  *out = c;
+  return PPCX_OK;
+}
+extern "C" void ppcx_comm_destroy(ppcx_comm* c) {
+  if (!c) return;
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  delete c;
+}
+extern "C" int ppcx_fit_nuts_comm(ppcx_model* shard, const ppcx_nuts_config* cfg, ppcx_comm* comm, ppcx_fit** out) {
+  if (!comm) return fail(PPCX_ERR_ARG, "communicator is NULL");
+  return fit_sharded(&shard, 1, cfg, comm, out);
 }
 
 extern "C" int ppcx_fit_info(const ppcx_fit* f, int* chains, int* n_keep, int* D, int* iter) {

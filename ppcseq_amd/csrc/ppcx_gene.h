@@ -123,9 +123,9 @@ PPCX_HD void gene_finish(const Dims& d, const Cmd& c, const VecRef& v, const Gen
 
 // per-coordinate part of kernel B for one gene-owned coordinate: pre-operations of the new command, then the
 // first half kick and the drift of the next leapfrog (written in place into the end being advanced)
-PPCX_HD void coord_update(const Cmd& nc, const VecRef& v, int i, double* draws, int D, double* T0,
+PPCX_HD void coord_update(const Dims& d, const Cmd& nc, const VecRef& v, int i, double* draws, double* T0,
                           const CoordCache* cc = nullptr) {
-  const CoordVals cv = coord_pre(nc, v, i, i, true, draws, D, nc.k0, nc.k1, T0, cc);
+  const CoordVals cv = coord_pre(nc, v, i, i, global_flat(d, i), true, draws, d.D, nc.k0, nc.k1, T0, cc);
   if (nc.type != CMD_FLUSH) {
     const double ph = cv.p + 0.5 * nc.eps * cv.g;
     v.at(V_P0 + 3 * nc.dir, i) = ph;
@@ -171,7 +171,8 @@ PPCX_HD void chain_step(const Dims& d, ChainScalars& st, TreeArrays& ta, const C
   if (nc.type != CMD_DONE) {
     double T0h = 0.0;
     for (int k = 0; k < 6; ++k) {
-      const CoordVals cv = coord_pre(nc, hv, k, hyper_index(d, k), true, io.draws, d.D, st.k0, st.k1, &T0h);
+      const int hcol = hyper_index(d, k);
+      const CoordVals cv = coord_pre(nc, hv, k, hcol, global_flat(d, hcol), true, io.draws, d.D, st.k0, st.k1, &T0h);
       if (nc.type != CMD_FLUSH) {
         const double ph = cv.p + 0.5 * nc.eps * cv.g;
         const double qn = cv.q + nc.eps * cv.minv * ph;

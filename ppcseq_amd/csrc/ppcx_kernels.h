@@ -31,14 +31,23 @@ struct CloseArgs {
   double* partials;             // [chains][nblocks_close][PT_COUNT]
 };
 
+struct ReduceArgs {
+  const Cmd* cmds;
+  const double* partials; int nblocks_close;   // [chains][nblocks_close][PT_COUNT]
+  const double* t0; int nblocks_update;        // [chains][nblocks_update]
+  double* red;                                  // [chains][PT_COUNT]
+};
+
+constexpr int kMaxShards = 16;
+struct ShardSumArgs { double* bufs[kMaxShards]; int n_shards; int n; };
+
 struct UpdateArgs {
   Dims d;
   const ChainState* states_in; ChainState* states_out;   // double-buffered between launches
   const Cmd* cmds_in; Cmd* cmds_out;
   const double* hyper_in; double* hyper_out;             // [chains][V_COUNT][8]
-  const double* t0_in; double* t0_out;                   // [chains][nblocks_update]
-  const double* partials;                                // [chains][nblocks_close][PT_COUNT]
-  int nblocks_close;
+  double* t0_out;                                        // [chains][nblocks_update]
+  const double* red;                                     // [chains][PT_COUNT] reduced sums of this leapfrog
   double* vecs; long Dpad;
   double* draws; long draws_chain_stride;
   int n_keep, iter;
@@ -60,6 +69,8 @@ struct PpcArgs {
 
 hipError_t launch_loglik_kernel(int L, int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st);
+hipError_t launch_reduce_kernel(const ReduceArgs& a, int nchains, hipStream_t st);
+hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st);
 hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_ppc_kernel(const PpcArgs& a, hipStream_t st);
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st);

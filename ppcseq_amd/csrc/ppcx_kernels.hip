@@ -161,10 +161,54 @@ __global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
 }
 
 // -----------------------------------------------------------------------------------------------------
+// reduce step: one workgroup per chain folds the close kernel's slab (and the T0 slab of the previous update
+// launch) into PT_COUNT sums in a fixed order. For gene shards these per-shard sums are then added across
+// shards (RCCL all-reduce between processes, ppcx_sum_shards_kernel inside one process).
+// -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ppcx_reduce_kernel(ReduceArgs a) {
+  __shared__ double sm[8][32];
+  __shared__ double sT0[256];
+  const int chain = blockIdx.x, tid = threadIdx.x;
+  const Cmd& ex = a.cmds[chain];
+  double* out = a.red + (long)chain * PT_COUNT;
+  const int np = (ex.type == CMD_DONE || ex.type == CMD_FLUSH) ? 0 : parts_used(ex);
+  const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
+  for (int v0 = 0; v0 < PT_COUNT; v0 += 32) {
+    const int vv = v0 + (tid & 31), ch = tid >> 5;
+    double s = 0.0;
+    if (vv < np) for (int b = ch; b < a.nblocks_close; b += 8) s += slab[(long)b * PT_COUNT + vv];
+    sm[ch][tid & 31] = s;
+    __syncthreads();
+    if (tid < 32 && v0 + tid < PT_COUNT) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += sm[k][tid];
+      if (v0 + tid != PT_T0) out[v0 + tid] = t;
+    }
+    __syncthreads();
+  }
+  const double* t0s = a.t0 + (long)chain * a.nblocks_update;
+  double s = 0.0;
+  for (int b = tid; b < a.nblocks_update; b += 256) s += t0s[b];
+  sT0[tid] = s;
+  __syncthreads();
+  for (int stp = 128; stp > 0; stp >>= 1) { if (tid < stp) sT0[tid] += sT0[tid + stp]; __syncthreads(); }
+  if (tid == 0) out[PT_T0] = sT0[0];
+}
+
+// in-process gene shards: every shard ends with the sum over shards (fixed order => identical bits everywhere)
+__global__ void ppcx_sum_shards_kernel(ShardSumArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  double s = 0.0;
+  for (int k = 0; k < a.n_shards; ++k) s += a.bufs[k][i];
+  for (int k = 0; k < a.n_shards; ++k) a.bufs[k][i] = s;
+}
+
+// -----------------------------------------------------------------------------------------------------
 // kernel B: reduce A's partial sums, advance the chain (redundantly per workgroup), update coordinates
 // -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
-  __shared__ double sm[8][32];
   __shared__ double red[PT_COUNT];
   __shared__ double hv[V_COUNT * 8];           // the six hyper coordinates of every per-coordinate vector
   __shared__ double sT0[256];
@@ -201,33 +245,11 @@ __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
   const bool have_parts = st_in->sc.phase != PH_START;
   __syncthreads();
   double T0g = 0.0;
-  if (have_parts) {
-    // every workgroup reduces the same slab in the same order: bitwise identical sums everywhere
-    const int np = (ex.type == CMD_FLUSH) ? 0 : parts_used(ex);
-    const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
-    for (int v0 = 0; v0 < np; v0 += 32) {
-      const int vv = v0 + (tid & 31), ch = tid >> 5;
-      double s = 0.0;
-      if (vv < np) for (int b = ch; b < a.nblocks_close; b += 8) s += slab[(long)b * PT_COUNT + vv];
-      sm[ch][tid & 31] = s;
-      __syncthreads();
-      if (tid < 32 && v0 + tid < np) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += sm[k][tid];
-        red[v0 + tid] = t;
-      }
-      __syncthreads();
-    }
-    // kinetic energy of the momenta drawn by the previous update launch
-    const double* t0s = a.t0_in + (long)chain * gridDim.x;
-    double s = 0.0;
-    for (int b = tid; b < (int)gridDim.x; b += 256) s += t0s[b];
-    sT0[tid] = s;
+  if (have_parts) {                              // sums of this leapfrog, already reduced (and, for gene shards,
+    const double* rg = a.red + (long)chain * PT_COUNT;          // summed over the shards) by the reduce step
+    for (int i = tid; i < PT_COUNT; i += 256) red[i] = rg[i];
     __syncthreads();
-    for (int stp = 128; stp > 0; stp >>= 1) { if (tid < stp) sT0[tid] += sT0[tid + stp]; __syncthreads(); }
-    T0g = sT0[0];
-    __syncthreads();
+    T0g = red[PT_T0];
   }
   if (tid == 0) {
     ChainScalars st = s_st.sc;                   // scalars in registers; the run-time-indexed arrays stay in LDS
@@ -263,10 +285,10 @@ __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
   if (nc.type != CMD_DONE) {
     double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
 #ifndef PPCX_ABLATE_NOCOORD
-    if (i_first < d.off_tail) coord_update(nc, v, i_first, draws, d.D, &T0, &cache);
+    if (i_first < d.off_tail) coord_update(d, nc, v, i_first, draws, &T0, &cache);
 #endif
     for (int i = i_first + gridDim.x * 256; i < d.off_tail; i += gridDim.x * 256)
-      coord_update(nc, v, i, draws, d.D, &T0);
+      coord_update(d, nc, v, i, draws, &T0);
   }
   sT0[tid] = T0;
   __syncthreads();
@@ -390,6 +412,14 @@ hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int ncha
   if (CM <= 2) hipLaunchKernelGGL((ppcx_close_kernel<2>), grid, dim3(256), 0, st, a);
   else if (CM <= 4) hipLaunchKernelGGL((ppcx_close_kernel<4>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((ppcx_close_kernel<8>), grid, dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_reduce_kernel(const ReduceArgs& a, int nchains, hipStream_t st) {
+  hipLaunchKernelGGL(ppcx_reduce_kernel, dim3(nchains), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(ppcx_sum_shards_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st) {

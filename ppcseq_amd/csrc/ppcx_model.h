@@ -28,6 +28,7 @@ struct Dims {
   int G, S, C, K, D;
   int off_intercept, off_alpha1, off_alpha2, off_sigma_raw, off_tail;  // Stan declaration order (.stan:183-197)
   int x0_is_one;                // X[,1] == 1 (model.matrix intercept column, R/utilities.R:887-900)
+  int Gt, Kt, g0, k0;           // gene shard: totals of the whole problem and this shard's first gene / checked gene
   double lambda_mu_mu;
 };
 
@@ -41,7 +42,21 @@ PPCX_HD Dims make_dims(int G, int S, int C, int K, double lambda_mu_mu) {
   d.off_tail = d.off_sigma_raw + G;
   d.D = d.off_tail + 3;
   d.x0_is_one = 1; d.lambda_mu_mu = lambda_mu_mu;
+  d.Gt = G; d.Kt = K; d.g0 = 0; d.k0 = 0;
   return d;
+}
+// Index of local coordinate i in the unconstrained vector of the WHOLE problem (Stan order). Used only as
+// the Philox stream id, so that a gene-sharded run draws exactly what the unsharded run draws.
+PPCX_HD int global_flat(const Dims& d, int i) {
+  if (d.Gt == d.G) return i;
+  const int n2 = d.C > 2 ? d.C - 2 : 0;
+  if (i < d.off_intercept) return i;
+  if (i < d.off_alpha1) return 3 + d.g0 + (i - d.off_intercept);
+  if (i < d.off_alpha2) return 3 + d.Gt + d.k0 + (i - d.off_alpha1);
+  if (i < d.off_sigma_raw) return 3 + d.Gt + d.Kt + n2 * d.k0 + (i - d.off_alpha2);
+  const int sr_t = 3 + d.Gt + d.Kt + n2 * d.Kt;
+  if (i < d.off_tail) return sr_t + d.g0 + (i - d.off_sigma_raw);
+  return sr_t + d.Gt + (i - d.off_tail);
 }
 // flat index of the k-th hyper-parameter, k = 0..5 = lambda_mu, lambda_sigma, lambda_skew,
 // sigma_slope, sigma_intercept, sigma_sigma

@@ -87,9 +87,10 @@ PPCX_HD CoordCache coord_prefetch(const VecRef& v, int i) {
 // loading the coordinate's current end state. Every lane of a gene computes the values; only the
 // `writer` lane stores, and nothing stored here is re-read in the same launch.
 // ---------------------------------------------------------------------------------------------------
-// `i` indexes the vectors, `flat` is the coordinate's index in the Stan-ordered unconstrained vector
-// (RNG stream id and draws column); they differ only for kernel B's LDS copy of the hyper coordinates.
-PPCX_HD CoordVals coord_pre(const Cmd& c, const VecRef& v, int i, int flat, bool writer, double* draws, int D,
+// `i` indexes the vectors, `flat` is the coordinate's column in this (shard's) unconstrained vector = draws column,
+// `rid` its index in the whole problem's vector = Philox stream id. i != flat only for kernel B's LDS copy of
+// the hyper coordinates; rid != flat only for gene shards.
+PPCX_HD CoordVals coord_pre(const Cmd& c, const VecRef& v, int i, int flat, int rid, bool writer, double* draws, int D,
                             uint32_t k0, uint32_t k1, double* T0, const CoordCache* cc = nullptr) {
   const int f = c.pre_flags;
   if (f & PRE_PROP) {
@@ -130,12 +131,12 @@ PPCX_HD CoordVals coord_pre(const Cmd& c, const VecRef& v, int i, int flat, bool
   CoordVals r;
   r.minv = minv;
   if (f & PRE_INIT) {                          // init = "random": U(-R, R) on the unconstrained scale
-    r.q = (2.0 * coord_uniform((uint32_t)flat, c.rng_c1, 0u, 0u, k0, k1) - 1.0) * c.init_radius;
+    r.q = (2.0 * coord_uniform((uint32_t)rid, c.rng_c1, 0u, 0u, k0, k1) - 1.0) * c.init_radius;
     r.p = 0.0; r.g = 0.0;
     if (writer) { v.at(V_Q1, i) = r.q; v.at(V_P1, i) = 0.0; v.at(V_G1, i) = 0.0; }
   } else if (f & PRE_NEW_TRANSITION) {         // both ends restart at the current sample with fresh momentum
     r.q = sq; r.g = sg;
-    r.p = coord_normal((uint32_t)flat, c.rng_c1, 1u, 0u, k0, k1) / sqrt(minv);
+    r.p = coord_normal((uint32_t)rid, c.rng_c1, 1u, 0u, k0, k1) / sqrt(minv);
     if (writer) {
       v.at(V_Q0, i) = sq; v.at(V_Q1, i) = sq; v.at(V_G0, i) = sg; v.at(V_G1, i) = sg;
       v.at(V_P0, i) = r.p; v.at(V_P1, i) = r.p; v.at(V_RHO, i) = r.p;
@@ -143,7 +144,7 @@ PPCX_HD CoordVals coord_pre(const Cmd& c, const VecRef& v, int i, int flat, bool
     }
   } else if (f & PRE_EPS_TRY) {                // init_stepsize trial: forward end <- sample, fresh momentum
     r.q = sq; r.g = sg;
-    r.p = coord_normal((uint32_t)flat, c.rng_c1, 3u, c.rng_c3, k0, k1) / sqrt(minv);
+    r.p = coord_normal((uint32_t)rid, c.rng_c1, 3u, c.rng_c3, k0, k1) / sqrt(minv);
     if (writer) { v.at(V_Q1, i) = sq; v.at(V_G1, i) = sg; v.at(V_P1, i) = r.p; *T0 += r.p * r.p * minv; }
   } else {
     if (cc) { r.q = cc->q[c.dir]; r.p = cc->p[c.dir]; r.g = cc->g[c.dir]; }

@@ -76,7 +76,7 @@ static double update_pass(const EmulModel& m, ChainState& st, const Cmd& ex, con
   chain_step(m.d, st.sc, st.ta, ex, red, T0_prev, have_parts, h, io, rd, nc);
   double T0 = 0.0;
   if (nc.type != CMD_DONE)
-    for (int i = 3; i < m.d.off_tail; ++i) coord_update(nc, v, i, io.draws, m.d.D, &T0);
+    for (int i = 3; i < m.d.off_tail; ++i) coord_update(m.d, nc, v, i, io.draws, &T0);
   return T0;
 }
 

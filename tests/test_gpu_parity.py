@@ -308,3 +308,82 @@ def test_reference_readme_example(L, bundled):
         sw = by.loc[g, "sample_wise_data"]
         bad = sw[sw["deleterious_outliers"]]
         assert len(bad) == 1 and float(bad["value"].iloc[0]) < 2.0 * float(bad[".upper"].iloc[0]) + 10
+
+
+def _shard_models(L, d, K, bounds):
+    G = d["counts"].shape[0]
+    return [L.Model(d["counts"][g0:g1], d["X"], d["exposure"], 0, shard=(G, K, g0, g1)) for g0, g1 in bounds]
+
+
+def _assemble(fits, bounds, G, K, C):
+    """Global unconstrained draws (Stan order) from the shards' local draws."""
+    nsl = max(C - 1, 1)
+    D = 2 * G + K * nsl + 6
+    out = None
+    for f, (g0, g1) in zip(fits, bounds):
+        dr = f.draws()
+        if out is None:
+            out = np.zeros(dr.shape[:2] + (D,))
+        Gl, Kl = g1 - g0, f.model.K
+        k0 = min(g0, K)
+        out[..., :3] = dr[..., :3]
+        out[..., 3 + g0:3 + g1] = dr[..., 3:3 + Gl]
+        out[..., 3 + G + k0:3 + G + k0 + Kl] = dr[..., 3 + Gl:3 + Gl + Kl]
+        if C > 2:
+            n2 = C - 2
+            out[..., 3 + G + K + n2 * k0:3 + G + K + n2 * (k0 + Kl)] = dr[..., 3 + Gl + Kl:3 + Gl + Kl + n2 * Kl]
+        sr_t, sr_l = 3 + G + K * nsl, 3 + Gl + Kl * nsl
+        out[..., sr_t + g0:sr_t + g1] = dr[..., sr_l:sr_l + Gl]
+        out[..., sr_t + G:] = dr[..., sr_l + Gl:]
+    return out
+
+
+@pytest.mark.parametrize("G,S,C,K,bounds", [(30, 8, 2, 4, [(0, 11), (11, 30)]), (24, 7, 3, 5, [(0, 3), (3, 10), (10, 24)]),
+                                             (20, 6, 1, 3, [(0, 10), (10, 20)])])
+def test_gene_shards_equal_the_unsharded_run(L, G, S, C, K, bounds):
+    """Gene-shard mode (map_rect analogue): every leapfrog the shards exchange <= 76 partial sums; the replicated
+    state machines must then walk exactly the path of the unsharded run (same Philox streams through global
+    coordinate ids; only the summation order of the reductions differs)."""
+    d = ind.synth(G, S, K=K, seed=3, C=C)
+    m = L.Model(d["counts"], d["X"], d["exposure"], K)
+    shards = _shard_models(L, d, K, bounds)
+    try:
+        kw = dict(chains=2, iter=30, warmup=20, seed=5)
+        f = m.fit_nuts(**kw)
+        fs = L.fit_nuts_shards(shards, **kw)
+        dg, dr = f.diagnostics(), f.draws()
+        for fsk in fs:                                   # replicated diagnostics
+            dk = fsk.diagnostics()
+            assert np.array_equal(dk["n_leapfrog"][:, :10], dg["n_leapfrog"][:, :10])
+            assert np.max(np.abs(dk["stepsize"][:, :10] - dg["stepsize"][:, :10])) < 1e-9
+            assert np.array_equal(dk["n_leapfrog"], fs[0].diagnostics()["n_leapfrog"])
+        # the first kept draw comes 20 iterations into the run: compare the pooled posterior instead of one draw
+        glob = _assemble(fs, bounds, G, K, C)
+        assert glob.shape == dr.shape
+        f2 = m.fit_nuts(chains=2, iter=6, warmup=0, seed=5, max_treedepth=6)
+        fs2 = L.fit_nuts_shards(shards, chains=2, iter=6, warmup=0, seed=5, max_treedepth=6)
+        assert np.array_equal(fs2[0].diagnostics()["n_leapfrog"], f2.diagnostics()["n_leapfrog"])
+        assert np.max(np.abs(_assemble(fs2, bounds, G, K, C) - f2.draws())) < 1e-7
+        for x in fs + fs2 + [f, f2]:
+            x.close()
+    finally:
+        m.close()
+        for s_ in shards:
+            s_.close()
+
+
+def test_rccl_communicator_single_rank(L):
+    """RCCL plumbing (dlopen, unique id, communicator, stream-ordered all-reduce between reduce and update) with one
+    rank: must reproduce the plain run exactly. Multi-rank runs need one GPU per rank (driver's multi-GPU node)."""
+    d = ind.synth(24, 6, K=3, seed=2)
+    m = L.Model(d["counts"], d["X"], d["exposure"], 3)
+    ms = L.Model(d["counts"], d["X"], d["exposure"], 0, shard=(24, 3, 0, 24))
+    try:
+        comm = L.Comm(1, 0, L.Comm.unique_id())
+        f = m.fit_nuts(chains=2, iter=25, warmup=15, seed=9)
+        fc = ms.fit_nuts_comm(comm, chains=2, iter=25, warmup=15, seed=9)
+        assert np.array_equal(f.diagnostics()["n_leapfrog"], fc.diagnostics()["n_leapfrog"])
+        assert np.array_equal(f.draws(), fc.draws())
+        f.close(); fc.close(); comm.close()
+    finally:
+        m.close(); ms.close()
