@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--nuts-warmup", type=int, default=150)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per gene override (0 = automatic)")
     ap.add_argument("--groups-per-wave", type=int, default=0)
+    ap.add_argument("--mode", choices=["chains", "shards"], default="chains",
+                    help="chains: BASELINE cfg3, chains partitioned over GPUs (default, weak scaling); shards: BASELINE cfg4 style, "
+                         "genes partitioned over GPUs with an RCCL all-reduce of the partial sums every leapfrog (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -71,7 +74,19 @@ def main():
     if dist_on:
         arrays = D.broadcast_arrays(arrays, device=dev)
     K = int(arrays["K"][0])
-    model = _lib.Model(arrays["counts"], arrays["X"], arrays["exposure"], K, device=dev_index)
+    comm = None
+    if args.mode == "shards":
+        # contiguous gene ranges; the communicator's id travels from rank 0 through torch.distributed
+        uid = [_lib.Comm.unique_id() if rank == 0 else None]
+        if dist_on:
+            import torch.distributed as dist
+            dist.broadcast_object_list(uid, src=0)
+        comm = _lib.Comm(world, rank, uid[0], device=dev_index)
+        g0, g1 = G * rank // world, G * (rank + 1) // world
+        model = _lib.Model(arrays["counts"][g0:g1], arrays["X"], arrays["exposure"], 0, device=dev_index,
+                           shard=(G, K, g0, g1))
+    else:
+        model = _lib.Model(arrays["counts"], arrays["X"], arrays["exposure"], K, device=dev_index)
     if args.lanes or args.groups_per_wave:
         model.set_launch(args.lanes, args.groups_per_wave)
     Dm = model.D
@@ -86,9 +101,10 @@ def main():
         torch.cuda.synchronize()
 
     def one_fit(step_seed):
-        fit = model.fit_nuts(chains=nch, iter=n_iter, warmup=args.nuts_warmup, seed=step_seed,
-                             chain_id_offset=D.chain_id_offset(rank, nch))
-        return fit
+        if comm is not None:                   # every rank runs the same chains on its genes
+            return model.fit_nuts_comm(comm, chains=nch, iter=n_iter, warmup=args.nuts_warmup, seed=step_seed)
+        return model.fit_nuts(chains=nch, iter=n_iter, warmup=args.nuts_warmup, seed=step_seed,
+                              chain_id_offset=D.chain_id_offset(rank, nch))
 
     for w in range(args.warmup):
         f = one_fit(1000 + w)
@@ -112,7 +128,7 @@ def main():
         kt = fit.kernel_times()
         lp = dg["lp"]
         ge = np.array([float(tm.grad_evals)])
-        if dist_on:
+        if dist_on and comm is None:
             hyp = D.all_gather_chains(hyp, device=dev)
             lp = D.all_gather_chains(lp, device=dev)
             ge = D.all_gather_chains(ge, device=dev)
@@ -135,6 +151,8 @@ def main():
         if kA_n > 0:
             ms = kA_ms / kA_n
             chains_per_launch = kA_chains / kA_n
+            if args.mode == "shards":
+                b_grad = b_grad / world              # each rank streams its share of the genes
             achieved = b_grad * chains_per_launch / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "ppcx_loglik_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
@@ -147,11 +165,14 @@ def main():
             "metric": "effective samples/sec (whole node) for NB hierarchical fit",
             "value": round(tot_ess / tot_time, 3), "unit": "ESS/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * tot_time / max(args.steps, 1), 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE cfg3: synthetic {G} genes x {S} samples (seed {seed_data}), C=2, K={K}; "
-                                   f"NUTS (Stan defaults) warm-up {args.nuts_warmup} + {args.draws_per_chain} kept draws/chain, "
-                                   f"{nch} chains per GPU (chains are the sharded unit)",
-                       "chains_total": nch * world, "lanes_per_gene": model.get_launch()[0], "blocks_per_chain": model.get_launch()[1],
+            "higher_is_better": True, "scaling": "weak" if args.mode == "chains" else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": (f"BASELINE cfg3: synthetic {G} genes x {S} samples (seed {seed_data}), C=2, K={K}; "
+                                    f"NUTS (Stan defaults) warm-up {args.nuts_warmup} + {args.draws_per_chain} kept draws/chain, "
+                                    f"{nch} chains per GPU (chains are the sharded unit)") if args.mode == "chains" else
+                                   (f"BASELINE cfg4 style: synthetic {G} genes x {S} samples (seed {seed_data}), C=2, K={K}, genes "
+                                    f"sharded over {world} GPU(s) with an RCCL all-reduce of the partial sums per leapfrog; NUTS "
+                                    f"(Stan defaults) warm-up {args.nuts_warmup} + {args.draws_per_chain} kept draws/chain, {nch} chains"),
+                       "mode": args.mode, "chains_total": nch * world if args.mode == "chains" else nch, "lanes_per_gene": model.get_launch()[0], "blocks_per_chain": model.get_launch()[1],
                        "ess_estimator": "rank-normalised split-chain bulk-ESS, min over 6 hyper-parameters and lp__",
                        "ess_last_step": [round(float(x), 1) for x in ess_detail],
                        "grad_evals": tot_grad, "mean_treedepth": round(float(np.mean(depth_mean)), 2),
