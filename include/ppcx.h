@@ -112,6 +112,18 @@ PPCX_API void ppcx_fit_free(ppcx_fit* f);
 PPCX_API void ppcx_do_inference_C(const int* dims, const int* counts, const double* X, const double* exposure_rate,
                          const int* excl, const double* reals, double* ci, double* slope, int* status);
 
+/* --- ADVI = rstan::vb(model, output_samples, iter = 50000, tol_rel_obj = 0.005) through vb_iterative
+ * (R/utilities.R:246-278, :1487-1494): mean-field Gaussian on the unconstrained scale, Stan defaults
+ * grad_samples 1, elbo_samples 100, eval_elbo 100, adapt_iter 50. The result is a one-chain fit holding
+ * output_samples draws of the approximation, so ppcx_fit_ppc / ppcx_fit_get_columns apply unchanged.          */
+typedef struct {
+  int output_samples, iter; double tol_rel_obj; int grad_samples, elbo_samples, eval_elbo, adapt_iter;
+  unsigned long long seed; double init_radius;
+} ppcx_advi_config;
+PPCX_API void ppcx_advi_config_default(ppcx_advi_config* cfg);
+PPCX_API int ppcx_fit_advi(ppcx_model* m, const ppcx_advi_config* cfg, ppcx_fit** out);
+PPCX_API int ppcx_fit_advi_info(const ppcx_fit* f, int* iterations, int* converged, double* elbo, double* eta);
+
 /* --- gene shards = the reference's map_rect over gene shards (inst/stan/negBinomial_MPI.stan:226-240;
  * round-robin gene->shard assignment R/utilities.R:130-136; here contiguous gene ranges). A shard model holds
  * genes [g0, g1) of a G_total-gene problem whose first K_total genes are the checked ones; the six

@@ -40,6 +40,12 @@ class _Cfg(C.Structure):
                 ("window", C.c_int), ("max_leapfrogs_total", C.c_int)]
 
 
+class _AdviCfg(C.Structure):
+    _fields_ = [("output_samples", C.c_int), ("iter", C.c_int), ("tol_rel_obj", C.c_double), ("grad_samples", C.c_int),
+                ("elbo_samples", C.c_int), ("eval_elbo", C.c_int), ("adapt_iter", C.c_int), ("seed", C.c_uint64),
+                ("init_radius", C.c_double)]
+
+
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
 
@@ -133,6 +139,17 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("oracle NUTS: initialisation failed")
         return NutsResult(metric=None, iters_done=None, **o)
+
+    def advi(self, m, output_samples=1000, iter=50000, tol_rel_obj=0.005, elbo_samples=100, eval_elbo=100, adapt_iter=50,
+             seed=1, init_radius=2.0):
+        D = self.dim(m.G, m.C, m.K)
+        cfg = _AdviCfg(output_samples, iter, tol_rel_obj, 1, elbo_samples, eval_elbo, adapt_iter, seed, init_radius)
+        draws = np.zeros((output_samples, D)); mu = np.zeros(D); om = np.zeros(D); info = np.zeros(4)
+        self.lib.ppco_advi.restype = C.c_int
+        rc = self.lib.ppco_advi(C.byref(m), C.byref(cfg), _p(draws, C.c_double), _p(mu, C.c_double), _p(om, C.c_double), _p(info, C.c_double))
+        if rc != 0:
+            raise RuntimeError(f"oracle ADVI failed ({rc})")
+        return dict(draws=draws, mu=mu, omega=om, iterations=int(info[0]), converged=bool(info[1]), elbo=info[2], eta=info[3])
 
     def nb2_log_rng(self, eta, phi, seed, cell, draw):
         return int(self.lib.ppco_nb2_log_rng(float(eta), float(phi), int(seed), int(cell), int(draw)))

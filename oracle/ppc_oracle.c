@@ -719,3 +719,109 @@ PPCO_EXPORT void ppco_summarise(const int32_t* x, int n_draws, int n_cells, doub
     free(col);
   }
 }
+
+/* ----------------------------------------------------------------------------------------------- */
+/* ADVI, mean-field (rstan::vb through vb_iterative, R/utilities.R:246-278,1487-1494): restatement */
+/* of Stan's published advi.hpp algorithm (third party, not in the container). Monte-Carlo draws   */
+/* use the project's Philox specification: key (seed32, 'ADVI'), counter (i>>1, draw_id, 6, 0),     */
+/* draw ids consumed in the order documented in DESIGN.md ("ADVI").                                 */
+/* ----------------------------------------------------------------------------------------------- */
+typedef struct { int output_samples, iter; double tol_rel_obj; int grad_samples, elbo_samples, eval_elbo, adapt_iter;
+                 uint64_t seed; double init_radius; } ppco_advi_cfg;
+
+static double advi_eta(uint32_t i, uint32_t draw, uint32_t k0) {
+  ppco_u4 r = ppco_philox4x32_10(i >> 1, draw, 6u, 0u, k0, 0x41445649u);
+  double u1 = ppco_u01(r.v[0], r.v[1]), u2 = ppco_u01(r.v[2], r.v[3]);
+  double rad = sqrt(-2.0 * log(u1)), t = 6.283185307179586476925 * u2;
+  return (i & 1) ? rad * sin(t) : rad * cos(t);
+}
+typedef struct { const ppco_model* m; int D; uint32_t k0; uint32_t draw_id; double *mu, *om, *hm, *ho, *zeta, *g; double lp_const; int elbo_samples; } advi_t;
+
+static double advi_calc_elbo(advi_t* a) {
+  double acc = 0; int ok = 0;
+  for (int s = 0; s < a->elbo_samples; ++s) {
+    uint32_t id = a->draw_id++;
+    for (int i = 0; i < a->D; ++i) a->zeta[i] = a->mu[i] + exp(a->om[i]) * advi_eta((uint32_t)i, id, a->k0);
+    double lp = ppco_log_prob_grad(a->m, a->zeta, NULL);
+    if (isfinite(lp)) { acc += lp + a->lp_const; ++ok; }
+  }
+  if (!ok) return -INFINITY;
+  double ent = 0.5 * a->D * (1.0 + 1.8378770664093454836);
+  for (int i = 0; i < a->D; ++i) ent += a->om[i];
+  return acc / a->elbo_samples + ent;
+}
+static void advi_grad_at(advi_t* a, uint32_t id) {
+  for (int i = 0; i < a->D; ++i) a->zeta[i] = a->mu[i] + exp(a->om[i]) * advi_eta((uint32_t)i, id, a->k0);
+  ppco_log_prob_grad(a->m, a->zeta, a->g);
+}
+static void advi_step(advi_t* a, double eta, int it, uint32_t* id) {
+  for (int i = 0; i < a->D; ++i) {
+    double e = advi_eta((uint32_t)i, *id, a->k0);
+    double gm = a->g[i], go = a->g[i] * e * exp(a->om[i]) + 1.0;
+    if (!(isfinite(gm) && isfinite(go))) continue;
+    a->hm[i] = it == 1 ? gm * gm : 0.1 * gm * gm + 0.9 * a->hm[i];
+    a->ho[i] = it == 1 ? go * go : 0.1 * go * go + 0.9 * a->ho[i];
+    double es = eta / sqrt((double)it);
+    a->mu[i] += es * gm / (1.0 + sqrt(a->hm[i]));
+    a->om[i] += es * go / (1.0 + sqrt(a->ho[i]));
+  }
+  *id = a->draw_id++;
+  advi_grad_at(a, *id);
+}
+static int cmp_d(const void* x, const void* y) { double a = *(const double*)x, b = *(const double*)y; return (a > b) - (a < b); }
+
+/* out_draws: [output_samples][D]; mu_out, omega_out: [D]; info: {iterations, converged, elbo, eta} */
+PPCO_EXPORT int ppco_advi(const ppco_model* m, const ppco_advi_cfg* cfg, double* out_draws, double* mu_out, double* omega_out, double* info) {
+  const int D = ppco_dim(m->G, m->C, m->K);
+  advi_t a; a.m = m; a.D = D; a.k0 = seed32(cfg->seed); a.draw_id = 1; a.elbo_samples = cfg->elbo_samples;
+  double* buf = calloc((size_t)D * 7, sizeof(double));
+  a.mu = buf; a.om = buf + D; a.hm = buf + 2 * D; a.ho = buf + 3 * D; a.zeta = buf + 4 * D; a.g = buf + 5 * D;
+  double* q0 = buf + 6 * D;
+  const double HL2PI = 0.91893853320467274178; const int n2 = m->C > 2 ? m->C - 2 : 0;
+  a.lp_const = -(6.0 + 2.0 * m->G + (double)n2 * m->K) * HL2PI - 5.0 * log(2.0) - (m->C >= 2 ? m->K * log(2.0) : 0.0) - (double)n2 * m->K * log(2.5);
+  int ok = 0;
+  for (uint32_t attempt = 0; attempt < 100 && !ok; ++attempt) {
+    for (int i = 0; i < D; ++i) { ppco_u4 r = ppco_philox4x32_10((uint32_t)i, attempt, 0u, 0u, a.k0, 0x41445649u); q0[i] = (2.0 * ppco_u01(r.v[0], r.v[1]) - 1.0) * cfg->init_radius; }
+    double lp = ppco_log_prob_grad(m, q0, a.g);
+    ok = isfinite(lp);
+    for (int i = 0; i < D && ok; ++i) ok = isfinite(a.g[i]);
+  }
+  if (!ok) { free(buf); return -3; }
+#define ADVI_RESET() do { memcpy(a.mu, q0, sizeof(double) * D); memset(a.om, 0, sizeof(double) * D); memset(a.hm, 0, sizeof(double) * D); memset(a.ho, 0, sizeof(double) * D); } while (0)
+  ADVI_RESET();
+  double elbo_init = advi_calc_elbo(&a), elbo_best = -INFINITY, eta_best = 0;
+  const double eta_seq[5] = {100, 10, 1, 0.1, 0.01};
+  int tuned = 0;
+  for (int e = 0; e < 5 && !tuned; ++e) {
+    uint32_t id = a.draw_id++; advi_grad_at(&a, id);
+    for (int it = 1; it <= cfg->adapt_iter; ++it) advi_step(&a, eta_seq[e], it, &id);
+    double elbo = advi_calc_elbo(&a); if (!isfinite(elbo)) elbo = -INFINITY;
+    if (elbo < elbo_best && elbo_best > elbo_init) tuned = 1;
+    else if (e < 4) { elbo_best = elbo; eta_best = eta_seq[e]; }
+    else { if (elbo > elbo_init) { eta_best = eta_seq[e]; tuned = 1; } else { free(buf); return -4; } }
+    ADVI_RESET();
+  }
+  int cb_size = (int)fmax(0.1 * cfg->iter / cfg->eval_elbo, 2.0), ncb = 0;
+  double* cb = calloc(cb_size, sizeof(double)); double* srt = calloc(cb_size, sizeof(double));
+  double elbo = 0, elbo_prev = -INFINITY; int converged = 0, iters = 0;
+  uint32_t id = a.draw_id++; advi_grad_at(&a, id);
+  for (int it = 1; it <= cfg->iter && !converged; ++it) {
+    advi_step(&a, eta_best, it, &id); iters = it;
+    if (it % cfg->eval_elbo == 0) {
+      elbo_prev = elbo; elbo = advi_calc_elbo(&a);
+      double delta = fabs((elbo - elbo_prev) / elbo);
+      if (ncb < cb_size) cb[ncb++] = delta; else { memmove(cb, cb + 1, sizeof(double) * (cb_size - 1)); cb[cb_size - 1] = delta; }
+      double mean = 0; for (int k = 0; k < ncb; ++k) mean += cb[k]; mean /= ncb;
+      memcpy(srt, cb, sizeof(double) * ncb); qsort(srt, ncb, sizeof(double), cmp_d);
+      double med = ncb % 2 ? srt[ncb / 2] : 0.5 * (srt[ncb / 2 - 1] + srt[ncb / 2]);
+      if (mean < cfg->tol_rel_obj || med < cfg->tol_rel_obj) converged = 1;
+      if (!converged) { id = a.draw_id++; advi_grad_at(&a, id); }
+    }
+  }
+  for (int r = 0; r < cfg->output_samples; ++r) { uint32_t d = a.draw_id++; for (int i = 0; i < D; ++i) out_draws[(size_t)r * D + i] = a.mu[i] + exp(a.om[i]) * advi_eta((uint32_t)i, d, a.k0); }
+  if (mu_out) memcpy(mu_out, a.mu, sizeof(double) * D);
+  if (omega_out) memcpy(omega_out, a.om, sizeof(double) * D);
+  if (info) { info[0] = iters; info[1] = converged; info[2] = elbo; info[3] = eta_best; }
+  free(cb); free(srt); free(buf);
+  return 0;
+}

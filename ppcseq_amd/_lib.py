@@ -20,7 +20,7 @@ EXPORTS = [
     "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
     "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_bench_gene_kernel",
     "ppcx_model_create_shard", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
-    "ppcx_fit_nuts_comm",
+    "ppcx_fit_nuts_comm", "ppcx_advi_config_default", "ppcx_fit_advi", "ppcx_fit_advi_info",
 ]
 
 
@@ -33,6 +33,12 @@ class NutsConfig(C.Structure):
                 ("adapt_delta", C.c_double), ("max_treedepth", C.c_int), ("init_radius", C.c_double),
                 ("stepsize0", C.c_double), ("init_buffer", C.c_int), ("term_buffer", C.c_int), ("window", C.c_int),
                 ("chain_id_offset", C.c_int)]
+
+
+class AdviConfig(C.Structure):
+    _fields_ = [("output_samples", C.c_int), ("iter", C.c_int), ("tol_rel_obj", C.c_double), ("grad_samples", C.c_int),
+                ("elbo_samples", C.c_int), ("eval_elbo", C.c_int), ("adapt_iter", C.c_int), ("seed", C.c_ulonglong),
+                ("init_radius", C.c_double)]
 
 
 _lib = None
@@ -70,6 +76,10 @@ def load() -> C.CDLL:
     lib.ppcx_fit_free.argtypes = [C.c_void_p]
     lib.ppcx_bench_gene_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.POINTER(C.c_int)]
     lib.ppcx_fit_free.restype = None
+    lib.ppcx_advi_config_default.argtypes = [C.POINTER(AdviConfig)]
+    lib.ppcx_advi_config_default.restype = None
+    lib.ppcx_fit_advi.argtypes = [C.c_void_p, C.POINTER(AdviConfig), C.POINTER(C.c_void_p)]
+    lib.ppcx_fit_advi_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ppcx_model_create_shard.argtypes = [C.c_int] * 7 + [ip, dp, dp, C.c_double, C.c_int, ip, C.POINTER(C.c_void_p)]
     lib.ppcx_fit_nuts_shards.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(NutsConfig), C.POINTER(C.c_void_p)]
     lib.ppcx_comm_unique_id.argtypes = [C.c_char_p]
@@ -157,6 +167,14 @@ class Model:
                          init_buffer, term_buffer, window, chain_id_offset)
         h = C.c_void_p()
         _check(load().ppcx_fit_nuts(self._h, C.byref(cfg), C.byref(h)))
+        return Fit(self, h)
+
+    def fit_advi(self, output_samples=1000, iter=50000, tol_rel_obj=0.005, elbo_samples=100, eval_elbo=100, adapt_iter=50,
+                 seed=1, init_radius=2.0) -> "Fit":
+        """Mean-field ADVI (rstan::vb); returns a one-chain Fit holding output_samples draws of the approximation."""
+        cfg = AdviConfig(output_samples, iter, tol_rel_obj, 1, elbo_samples, eval_elbo, adapt_iter, seed, init_radius)
+        h = C.c_void_p()
+        _check(load().ppcx_fit_advi(self._h, C.byref(cfg), C.byref(h)))
         return Fit(self, h)
 
     def fit_nuts_comm(self, comm: "Comm", **kw) -> "Fit":
@@ -264,6 +282,12 @@ class Fit:
         ge, ns = C.c_longlong(), C.c_longlong()
         _check(load().ppcx_fit_get_timing(self._h, C.byref(s), C.byref(ge), C.byref(ms), C.byref(ns), C.byref(cl)))
         return Timing(s.value, ge.value, ms.value, ns.value, cl.value)
+
+    def advi_info(self):
+        it, cv = C.c_int(), C.c_int()
+        el, et = C.c_double(), C.c_double()
+        _check(load().ppcx_fit_advi_info(self._h, C.byref(it), C.byref(cv), C.byref(el), C.byref(et)))
+        return dict(iterations=it.value, converged=bool(cv.value), elbo=el.value, eta=et.value)
 
     def kernel_times(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <chrono>
 #include <dlfcn.h>
 #include <stdlib.h>
@@ -48,6 +49,7 @@ struct ppcx_fit {
   double seconds = 0; long long grad_evals = 0;
   double kA_ms_mean = 0; long long kA_samples = 0; double kA_chain_launches_mean = 0;
   double kC_ms_mean = 0, kU_ms_mean = 0; long long launch_triples = 0;
+  double advi_elbo = 0, advi_eta = 0; int advi_converged = 0;
 };
 
 extern "C" int ppcx_version(void) { return 100; }
@@ -596,6 +598,191 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   return PPCX_OK;
 }
 
+// ---- ADVI: mean-field variational inference, the reference's default path (rstan::vb through vb_iterative,
+// R/utilities.R:246-278,1487-1494; Stan's advi.hpp algorithm restated: adapt_eta over {100,10,1,0.1,0.01},
+// stochastic gradient ascent with the running-squared-gradient step, ELBO every eval_elbo iterations from
+// elbo_samples draws, convergence when the mean or median of the relative ELBO changes drops below tol_rel_obj) ----
+struct AdviRun {
+  ppcx_model* m; Work* w; int nslot, nb_advi; uint32_t k0; uint32_t draw_id = 1; double* d_acc = nullptr; double* d_omega = nullptr;
+  double lp_const = 0, ent_const = 0; int elbo_samples = 100;
+};
+static int advi_launch(AdviRun& r, int op, int n_slots, double eta_scaled, int first_iter, uint32_t prev_draw, uint32_t draw_base,
+                       double* out_draws, int out_row0) {
+  AdviArgs a;
+  a.d = r.m->d; a.vecs = r.w->vecs; a.Dpad = r.w->Dpad; a.hyper = r.w->hyper_vecs[0]; a.cmds = r.w->cmds[0]; a.red = r.w->red;
+  a.op = op; a.n_slots = n_slots; a.first_iter = first_iter; a.eta_scaled = eta_scaled; a.k0 = r.k0; a.prev_draw = prev_draw;
+  a.draw_base = draw_base; a.out_draws = out_draws; a.out_row0 = out_row0; a.omega_part = r.d_omega;
+  hipError_t e = launch_advi_kernel(a, r.nb_advi, r.w->stream);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("advi kernel: ") + hipGetErrorString(e));
+  return PPCX_OK;
+}
+static int advi_eval(AdviRun& r, int n_slots) {      // gradient evaluation of the first n_slots slots
+  int rc = launch_loglik(r.m, *r.w, n_slots);
+  if (rc == PPCX_OK) rc = launch_close(r.m, *r.w, n_slots);
+  if (rc == PPCX_OK) rc = launch_reduce(r.m, *r.w, n_slots);
+  return rc;
+}
+static int advi_elbo(AdviRun& r, double* elbo) {     // Stan advi::calc_ELBO
+  HIPCHK(hipMemsetAsync(r.d_acc, 0, sizeof(double) * 4, r.w->stream));
+  int left = r.elbo_samples, rc;
+  while (left > 0) {
+    const int nb = left < r.nslot ? left : r.nslot;
+    if ((rc = advi_launch(r, ADVI_DRAW, nb, 0.0, 0, 0, r.draw_id, nullptr, 0)) != PPCX_OK) return rc;
+    r.draw_id += nb;
+    if ((rc = advi_eval(r, nb)) != PPCX_OK) return rc;
+    AdviElboArgs ea; ea.d = r.m->d; ea.cmds = r.w->cmds[0]; ea.red = r.w->red; ea.n_slots = nb; ea.acc = r.d_acc;
+    ea.omega_part = r.d_omega; ea.n_omega_parts = r.nb_advi;
+    hipError_t e = launch_advi_elbo_kernel(ea, r.w->stream);
+    if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("advi elbo kernel: ") + hipGetErrorString(e));
+    left -= nb;
+  }
+  double acc[4];
+  HIPCHK(hipMemcpyAsync(acc, r.d_acc, sizeof(acc), hipMemcpyDeviceToHost, r.w->stream));
+  HIPCHK(hipStreamSynchronize(r.w->stream));
+  if (acc[1] < 1.0) return fail(PPCX_ERR_INIT, "ADVI: every ELBO evaluation was non-finite");
+  *elbo = acc[0] / (double)r.elbo_samples + r.lp_const * (acc[1] / (double)r.elbo_samples) + r.ent_const + acc[3];
+  return PPCX_OK;
+}
+// draw the next gradient sample into slot 0 and evaluate it
+static int advi_fresh_grad(AdviRun& r, uint32_t* id) {
+  *id = r.draw_id++;
+  int rc = advi_launch(r, ADVI_DRAW, 1, 0.0, 0, 0, *id, nullptr, 0);
+  return rc != PPCX_OK ? rc : advi_eval(r, 1);
+}
+// one stochastic-gradient step (uses the gradient at draw *id), then draw + evaluate the next sample
+static int advi_step(AdviRun& r, double eta, int iter_counter, uint32_t* id) {
+  const uint32_t next = r.draw_id++;
+  int rc = advi_launch(r, ADVI_STEP, 1, eta / sqrt((double)iter_counter), iter_counter == 1, *id, next, nullptr, 0);
+  *id = next;
+  return rc != PPCX_OK ? rc : advi_eval(r, 1);
+}
+
+extern "C" void ppcx_advi_config_default(ppcx_advi_config* c) {
+  if (!c) return;
+  c->output_samples = 1000; c->iter = 50000; c->tol_rel_obj = 0.005; c->grad_samples = 1; c->elbo_samples = 100;
+  c->eval_elbo = 100; c->adapt_iter = 50; c->seed = 1; c->init_radius = 2.0;
+}
+
+extern "C" int ppcx_fit_advi(ppcx_model* m, const ppcx_advi_config* cfg, ppcx_fit** out) {
+  if (!m || !cfg || !out) return fail(PPCX_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  if (cfg->output_samples < 1 || cfg->iter < 1 || cfg->elbo_samples < 1 || cfg->eval_elbo < 1 || cfg->adapt_iter < 1 || !(cfg->tol_rel_obj > 0))
+    return fail(PPCX_ERR_ARG, "bad ADVI configuration");
+  if (cfg->grad_samples != 1) return fail(PPCX_ERR_LIMIT, "grad_samples must be 1 (the reference's value)");
+  HIPCHK(hipSetDevice(m->device));
+  const Dims& d = m->d;
+  const int D = d.D;
+  AdviRun r; r.m = m;
+  r.nslot = cfg->elbo_samples < 32 ? cfg->elbo_samples : 32;
+  choose_launch(m, r.nslot);
+  Work w; r.w = &w;
+  int rc = work_alloc(w, m, r.nslot);
+  if (rc != PPCX_OK) return rc;
+  r.nb_advi = (D + 255) / 256; if (r.nb_advi > 1024) r.nb_advi = 1024;
+  r.k0 = seed32(cfg->seed); r.elbo_samples = cfg->elbo_samples;
+  const double HL2PI = 0.91893853320467274178;
+  const int n2 = d.C > 2 ? d.C - 2 : 0;
+  r.lp_const = -(6.0 + 2.0 * d.G + (double)n2 * d.K) * HL2PI - 5.0 * log(2.0) - (d.C >= 2 ? d.K * log(2.0) : 0.0) - (double)n2 * d.K * log(2.5);
+  r.ent_const = 0.5 * (double)D * (1.0 + 2.0 * HL2PI);
+  struct Guard { double* a = nullptr; double* b = nullptr; ~Guard() { (void)hipFree(a); (void)hipFree(b); } } guard;
+  HIPCHK(hipMalloc(&guard.a, sizeof(double) * 4)); r.d_acc = guard.a;
+  HIPCHK(hipMalloc(&guard.b, sizeof(double) * r.nb_advi)); r.d_omega = guard.b;
+  hipStream_t st = w.stream;
+  // ---- initial point: init = "random" U(-R, R), retried until the density and gradient are finite
+  std::vector<double> q0(D), red(PT_COUNT);
+  bool ok = false;
+  for (int attempt = 0; attempt < 100 && !ok; ++attempt) {
+    for (int i = 0; i < D; ++i) q0[i] = (2.0 * coord_uniform((uint32_t)i, (uint32_t)attempt, 0u, 0u, r.k0, 0x41445649u) - 1.0) * cfg->init_radius;
+    Cmd c; cmd_clear(c); c.type = CMD_EVAL; c.dir = 1;
+    for (int k = 0; k < 6; ++k) c.hyp_q[k] = q0[hyper_index(d, k)];
+    c.hy = make_hyper(c.hyp_q, d.lambda_mu_mu);
+    HIPCHK(hipMemcpyAsync(w.vecs + (size_t)V_Q1 * w.Dpad, q0.data(), sizeof(double) * D, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(w.cmds[0], &c, sizeof(Cmd), hipMemcpyHostToDevice, st));
+    if ((rc = advi_eval(r, 1)) != PPCX_OK) return rc;
+    HIPCHK(hipMemcpyAsync(red.data(), w.red, sizeof(double) * PT_COUNT, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double g6[6];
+    const double lp = hyper_close(d, c.hy, c.hyp_q, red[PT_LP], red.data() + PT_H0, g6);
+    ok = isfinite(lp) && red[PT_NONFINITE] == 0.0;
+    for (int k = 0; k < 6; ++k) ok = ok && isfinite(g6[k]);
+  }
+  if (!ok) return fail(PPCX_ERR_INIT, "ADVI: no finite initial point after 100 attempts");
+  HIPCHK(hipMemcpyAsync(w.vecs + (size_t)V_Q0 * w.Dpad, q0.data(), sizeof(double) * D, hipMemcpyHostToDevice, st));
+  {
+    std::vector<double> hv((size_t)V_COUNT * 8, 0.0);
+    for (int k = 0; k < 8; ++k) hv[V_MINV * 8 + k] = 1.0;
+    for (int k = 0; k < 6; ++k) hv[V_Q0 * 8 + k] = q0[hyper_index(d, k)];
+    HIPCHK(hipMemcpy(w.hyper_vecs[0], hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice));
+  }
+  auto reset = [&]() { return advi_launch(r, ADVI_RESET, 0, 0.0, 0, 0, 0, nullptr, 0); };
+  if ((rc = reset()) != PPCX_OK) return rc;
+  // ---- adapt_eta
+  double elbo_init = 0, elbo_best = -INFINITY, eta_best = 0;
+  if ((rc = advi_elbo(r, &elbo_init)) != PPCX_OK) return rc;
+  const double eta_seq[5] = {100, 10, 1, 0.1, 0.01};
+  bool tuned = false;
+  for (int e = 0; e < 5 && !tuned; ++e) {
+    uint32_t id;
+    if ((rc = advi_fresh_grad(r, &id)) != PPCX_OK) return rc;
+    for (int it = 1; it <= cfg->adapt_iter; ++it) if ((rc = advi_step(r, eta_seq[e], it, &id)) != PPCX_OK) return rc;
+    double elbo = -INFINITY;
+    if (advi_elbo(r, &elbo) != PPCX_OK || !isfinite(elbo)) elbo = -INFINITY;
+    if (elbo < elbo_best && elbo_best > elbo_init) tuned = true;
+    else if (e < 4) { elbo_best = elbo; eta_best = eta_seq[e]; }
+    else { if (elbo > elbo_init) { eta_best = eta_seq[e]; tuned = true; } else return fail(PPCX_ERR_STEPSIZE, "ADVI: all proposed step-sizes failed"); }
+    if ((rc = reset()) != PPCX_OK) return rc;
+  }
+  // ---- stochastic gradient ascent
+  int cb_size = (int)fmax(0.1 * cfg->iter / cfg->eval_elbo, 2.0);
+  std::vector<double> cb;
+  double elbo = 0, elbo_prev = -INFINITY;
+  uint32_t id;
+  if ((rc = advi_fresh_grad(r, &id)) != PPCX_OK) return rc;
+  int iters_done = 0; bool converged = false;
+  for (int it = 1; it <= cfg->iter && !converged; ++it) {
+    if ((rc = advi_step(r, eta_best, it, &id)) != PPCX_OK) return rc;
+    iters_done = it;
+    if (it % cfg->eval_elbo == 0) {
+      elbo_prev = elbo;
+      if ((rc = advi_elbo(r, &elbo)) != PPCX_OK) return rc;
+      const double delta = fabs((elbo - elbo_prev) / elbo);
+      cb.push_back(delta); if ((int)cb.size() > cb_size) cb.erase(cb.begin());
+      double mean = 0; for (double x : cb) mean += x; mean /= cb.size();
+      std::vector<double> srt(cb); std::sort(srt.begin(), srt.end());
+      const double med = srt.size() % 2 ? srt[srt.size() / 2] : 0.5 * (srt[srt.size() / 2 - 1] + srt[srt.size() / 2]);
+      if (mean < cfg->tol_rel_obj || med < cfg->tol_rel_obj) converged = true;
+      if (!converged) { if ((rc = advi_fresh_grad(r, &id)) != PPCX_OK) return rc; }   // the ELBO draws used slot 0
+    }
+  }
+  // ---- output_samples draws from the fitted approximation (kept as a one-chain fit)
+  ppcx_fit* f = new ppcx_fit();
+  f->m = m; f->chains = 1; f->n_keep = cfg->output_samples; f->iter = iters_done;
+  memset(&f->cfg, 0, sizeof f->cfg);
+#define AHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ppcx_fit_free(f); return fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+  AHIP(hipMalloc(&f->d_draws, sizeof(double) * (size_t)cfg->output_samples * D));
+  AHIP(hipMalloc(&f->d_lp, sizeof(double) * (size_t)cfg->output_samples));
+  AHIP(hipMemset(f->d_lp, 0, sizeof(double) * (size_t)cfg->output_samples));
+  AHIP(hipMalloc(&f->d_stepsize, sizeof(double) * (size_t)(iters_done > 0 ? iters_done : 1)));
+  AHIP(hipMemset(f->d_stepsize, 0, sizeof(double) * (size_t)(iters_done > 0 ? iters_done : 1)));
+  for (int row = 0; row < cfg->output_samples; row += 64) {
+    const int nb = cfg->output_samples - row < 64 ? cfg->output_samples - row : 64;
+    if ((rc = advi_launch(r, ADVI_DRAW, nb, 0.0, 0, 0, r.draw_id, f->d_draws, row)) != PPCX_OK) { ppcx_fit_free(f); return rc; }
+    r.draw_id += nb;
+  }
+  AHIP(hipStreamSynchronize(st));
+  f->grad_evals = (long long)r.draw_id; f->seconds = 0; f->advi_elbo = elbo; f->advi_eta = eta_best; f->advi_converged = converged ? 1 : 0;
+  *out = f;
+  return PPCX_OK;
+}
+extern "C" int ppcx_fit_advi_info(const ppcx_fit* f, int* iterations, int* converged, double* elbo, double* eta) {
+  if (!f) return fail(PPCX_ERR_ARG, "fit is NULL");
+  if (iterations) *iterations = f->iter;
+  if (converged) *converged = f->advi_converged;
+  if (elbo) *elbo = f->advi_elbo;
+  if (eta) *eta = f->advi_eta;
+  return PPCX_OK;
+}
+
 // ---- gene shards (second mode; the reference's map_rect over gene shards, .stan:226-240) ---------
 extern "C" int ppcx_model_create_shard(int device, int G_total, int S, int C, int K_total, int g0, int g1,
                                        const int32_t* counts_shard, const double* X, const double* exposure,
@@ -765,10 +952,10 @@ extern "C" int ppcx_fit_get_diagnostics(ppcx_fit* f, double* lp, double* stepsiz
   const size_t ni = (size_t)f->chains * f->iter, nk = (size_t)f->chains * f->n_keep;
   if (lp && nk) HIPCHK(hipMemcpy(lp, f->d_lp, sizeof(double) * nk, hipMemcpyDeviceToHost));
   if (stepsize) HIPCHK(hipMemcpy(stepsize, f->d_stepsize, sizeof(double) * ni, hipMemcpyDeviceToHost));
-  if (treedepth) HIPCHK(hipMemcpy(treedepth, f->d_treedepth, sizeof(int) * ni, hipMemcpyDeviceToHost));
-  if (n_leapfrog) HIPCHK(hipMemcpy(n_leapfrog, f->d_nleap, sizeof(int) * ni, hipMemcpyDeviceToHost));
-  if (divergent) HIPCHK(hipMemcpy(divergent, f->d_div, sizeof(int) * ni, hipMemcpyDeviceToHost));
-  if (accept) HIPCHK(hipMemcpy(accept, f->d_accept, sizeof(double) * ni, hipMemcpyDeviceToHost));
+  if (treedepth && f->d_treedepth) HIPCHK(hipMemcpy(treedepth, f->d_treedepth, sizeof(int) * ni, hipMemcpyDeviceToHost));
+  if (n_leapfrog && f->d_nleap) HIPCHK(hipMemcpy(n_leapfrog, f->d_nleap, sizeof(int) * ni, hipMemcpyDeviceToHost));
+  if (divergent && f->d_div) HIPCHK(hipMemcpy(divergent, f->d_div, sizeof(int) * ni, hipMemcpyDeviceToHost));
+  if (accept && f->d_accept) HIPCHK(hipMemcpy(accept, f->d_accept, sizeof(double) * ni, hipMemcpyDeviceToHost));
   return PPCX_OK;
 }
 extern "C" int ppcx_fit_get_kernel_times(ppcx_fit* f, double* loglik_ms, double* close_ms, double* update_ms,

@@ -55,6 +55,21 @@ struct UpdateArgs {
   int* done;                    // [chains]
 };
 
+enum AdviOp : int { ADVI_DRAW = 0, ADVI_RESET = 1, ADVI_STEP = 2 };
+struct AdviArgs {
+  Dims d;
+  double* vecs; long Dpad;      // slot c = evaluation slot c; slot 0 also stores mu/omega/history/initial point
+  double* hyper;                // slot 0 hyper vectors [V_COUNT][8]
+  Cmd* cmds;                    // [n_slots]
+  const double* red;            // reduced sums of slot 0 (ADVI_STEP)
+  int op, n_slots, first_iter;
+  double eta_scaled;
+  uint32_t k0, prev_draw, draw_base;
+  double* out_draws; int out_row0;   // non-null: write the draws to [row][D] instead of the evaluation slots
+  double* omega_part;           // [nblocks]
+};
+struct AdviElboArgs { Dims d; const Cmd* cmds; const double* red; int n_slots; double* acc; const double* omega_part; int n_omega_parts; };
+
 struct PpcArgs {
   Dims d;
   const double* draws;          // [n_draws][D]
@@ -72,6 +87,8 @@ hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int ncha
 hipError_t launch_reduce_kernel(const ReduceArgs& a, int nchains, hipStream_t st);
 hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st);
 hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st);
+hipError_t launch_advi_kernel(const AdviArgs& a, int nblocks, hipStream_t st);
+hipError_t launch_advi_elbo_kernel(const AdviElboArgs& a, hipStream_t st);
 hipError_t launch_ppc_kernel(const PpcArgs& a, hipStream_t st);
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st);
 hipError_t launch_fill_kernel(double* p, long n, double val, hipStream_t st);

@@ -297,6 +297,105 @@ __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
 }
 
 // -----------------------------------------------------------------------------------------------------
+// ADVI (mean-field; rstan::vb of R/utilities.R:246-278,1487-1494). The variational parameters live in spare
+// vectors of slot 0: mu = V_SQ, omega = V_SG, running squared gradients = V_WM / V_WM2, initial point = V_Q0.
+// One launch (a) applies the stochastic-gradient step that uses the gradient the loglik/close/reduce kernels
+// just evaluated at the previous draw, and (b) writes the next Monte-Carlo draws zeta_c = mu + exp(omega) eta_c
+// into the evaluation slots (V_Q1 of slot c, hyper-parameters into that slot's command).
+// -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double advi_eta(uint32_t rid, uint32_t draw, uint32_t k0) {
+  return coord_normal(rid, draw, 6u, 0u, k0, 0x41445649u);
+}
+__device__ __forceinline__ void advi_coord(const AdviArgs& a, double* mu, double* om, double* hm, double* ho,
+                                            double mu0, double g, uint32_t rid) {
+  if (a.op == ADVI_RESET) { *mu = mu0; *om = 0.0; *hm = 0.0; *ho = 0.0; }
+  if (a.op == ADVI_STEP) {                     // Stan advi::stochastic_gradient_ascent / adapt_eta
+    const double eta = advi_eta(rid, a.prev_draw, a.k0);
+    const double gm = g, go = g * eta * exp(*om) + 1.0;
+    if (isfinite(gm) && isfinite(go)) {        // Stan raises on a non-finite gradient; a kernel cannot: skip the draw
+      *hm = a.first_iter ? gm * gm : 0.1 * gm * gm + 0.9 * *hm;
+      *ho = a.first_iter ? go * go : 0.1 * go * go + 0.9 * *ho;
+      *mu += a.eta_scaled * gm / (1.0 + sqrt(*hm));
+      *om += a.eta_scaled * go / (1.0 + sqrt(*ho));
+    }
+  }
+}
+__global__ __launch_bounds__(256) void ppcx_advi_kernel(AdviArgs a) {
+  __shared__ double s_g6[6];
+  __shared__ double s_om[256];
+  const Dims& d = a.d;
+  const int tid = threadIdx.x;
+  const VecRef v0{a.vecs, a.Dpad};
+  if (a.op == ADVI_STEP && tid == 0 && blockIdx.x == 0) {   // hyper-parameter gradient of the evaluated draw
+    // (only workgroup 0 owns the hyper-parameters; it rewrites cmds[] below, after the barrier)
+    const Cmd& c = a.cmds[0];
+    const double* r = a.red;
+    double g6[6];
+    (void)hyper_close(d, c.hy, c.hyp_q, r[PT_LP], r + PT_H0, g6);
+    for (int k = 0; k < 6; ++k) s_g6[k] = g6[k];
+  }
+  __syncthreads();
+  double om_sum = 0.0;
+  for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) {
+    double mu = v0.at(V_SQ, i), om = v0.at(V_SG, i), hm = v0.at(V_WM, i), ho = v0.at(V_WM2, i);
+    const uint32_t rid = (uint32_t)global_flat(d, i);
+    const double g = a.op == ADVI_STEP ? v0.at(V_G1, i) : 0.0;
+    advi_coord(a, &mu, &om, &hm, &ho, v0.at(V_Q0, i), g, rid);
+    if (a.op != ADVI_DRAW) { v0.at(V_SQ, i) = mu; v0.at(V_SG, i) = om; v0.at(V_WM, i) = hm; v0.at(V_WM2, i) = ho; }
+    om_sum += om;
+    const double sd = exp(om);
+    for (int c = 0; c < a.n_slots; ++c) {
+      const double z = mu + sd * advi_eta(rid, a.draw_base + c, a.k0);
+      if (a.out_draws) a.out_draws[(long)(a.out_row0 + c) * d.D + i] = z;
+      else a.vecs[((long)c * V_COUNT + V_Q1) * a.Dpad + i] = z;
+    }
+  }
+  if (blockIdx.x == 0 && tid < 6) {            // the six hyper-parameters (slot 0 of the hyper vectors)
+    const int k = tid, col = hyper_index(d, k);
+    double* h = a.hyper;
+    double mu = h[V_SQ * 8 + k], om = h[V_SG * 8 + k], hm = h[V_WM * 8 + k], ho = h[V_WM2 * 8 + k];
+    const uint32_t rid = (uint32_t)global_flat(d, col);
+    advi_coord(a, &mu, &om, &hm, &ho, h[V_Q0 * 8 + k], a.op == ADVI_STEP ? s_g6[k] : 0.0, rid);
+    if (a.op != ADVI_DRAW) { h[V_SQ * 8 + k] = mu; h[V_SG * 8 + k] = om; h[V_WM * 8 + k] = hm; h[V_WM2 * 8 + k] = ho; }
+    om_sum += om;
+    const double sd = exp(om);
+    for (int c = 0; c < a.n_slots; ++c) {
+      const double z = mu + sd * advi_eta(rid, a.draw_base + c, a.k0);
+      if (a.out_draws) a.out_draws[(long)(a.out_row0 + c) * d.D + col] = z;
+      else a.cmds[c].hyp_q[k] = z;
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0 && !a.out_draws) {
+    for (int c = 0; c < a.n_slots; ++c) {
+      Cmd& cm = a.cmds[c];
+      cm.type = CMD_EVAL; cm.dir = 1; cm.eps = 0.0; cm.pre_flags = 0; cm.n_merge = 0; cm.subtree_complete = 0; cm.leaf_n = 0;
+      cm.hy = make_hyper(cm.hyp_q, d.lambda_mu_mu);
+    }
+  }
+  s_om[tid] = om_sum;
+  __syncthreads();
+  for (int stp = 128; stp > 0; stp >>= 1) { if (tid < stp) s_om[tid] += s_om[tid + stp]; __syncthreads(); }
+  if (tid == 0) a.omega_part[blockIdx.x] = s_om[0];
+}
+
+// ELBO accumulation: adds log p(zeta_c) of the evaluated slots (acc[0]), their count (acc[1]) and the number of
+// non-finite evaluations dropped (acc[2]); acc[3] = sum of omega (entropy term) from the last advi launch.
+__global__ void ppcx_advi_elbo_kernel(AdviElboArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int c = 0; c < a.n_slots; ++c) {
+    const Cmd& cm = a.cmds[c];
+    const double* r = a.red + (long)c * PT_COUNT;
+    double g6[6];
+    const double lp = hyper_close(a.d, cm.hy, cm.hyp_q, r[PT_LP], r + PT_H0, g6);
+    if (isfinite(lp)) { a.acc[0] += lp; a.acc[1] += 1.0; } else a.acc[2] += 1.0;
+  }
+  double s = 0.0;
+  for (int b = 0; b < a.n_omega_parts; ++b) s += a.omega_part[b];
+  a.acc[3] = s;
+}
+
+// -----------------------------------------------------------------------------------------------------
 // posterior-predictive draws + credible intervals, one workgroup per (gene <= K, sample) cell
 // -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ppcx_ppc_kernel(PpcArgs a) {
@@ -424,6 +523,14 @@ hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st) {
 }
 hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st) {
   hipLaunchKernelGGL(ppcx_update_kernel, dim3(nblocks, nchains), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_advi_kernel(const AdviArgs& a, int nblocks, hipStream_t st) {
+  hipLaunchKernelGGL(ppcx_advi_kernel, dim3(nblocks), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_advi_elbo_kernel(const AdviElboArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(ppcx_advi_elbo_kernel, dim3(1), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_ppc_kernel(const PpcArgs& a, hipStream_t st) {

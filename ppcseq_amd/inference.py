@@ -100,8 +100,6 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *,
                       or an int array of 0-based cell ids g*S+s
     Returns an InferenceResult.
     """
-    if approximate_posterior_inference:
-        raise NotImplementedError("ADVI (rstan::vb, R/utilities.R:1487-1494) is a 'next' row; use NUTS")
     counts = np.asarray(counts)
     if counts.ndim != 2:
         # R/utilities.R:1360-1361
@@ -126,7 +124,12 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *,
         model = _lib.Model(counts, X, exposure_rate, K, lambda_mu_mu=lambda_mu_mu, excl=excl, device=device)
     else:
         model.set_exclusions(excl)
-    fit = model.fit_nuts(chains=chains, iter=n_iter, warmup=warmup, seed=seed)
+    if approximate_posterior_inference:
+        # vb_iterative(model, output_samples = draws_practical, iter = 50000, tol_rel_obj = 0.005)
+        # (R/utilities.R:1487-1494; the reference passes no seed to vb -- here the run is seeded and reproducible)
+        fit = model.fit_advi(output_samples=int(draws_practical), iter=50000, tol_rel_obj=0.005, seed=seed)
+    else:
+        fit = model.fit_nuts(chains=chains, iter=n_iter, warmup=warmup, seed=seed)
     try:
         p = float(adj_prob_theshold)
         if approximate_posterior_analysis:
@@ -144,7 +147,7 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *,
         res = _post_process(counts[:K], ci, slope, X)
         res.total_draws = S * K * int(how_many_posterior_draws)   # R/utilities.R:1544
         res.chains, res.iter = chains, n_iter
-        res.diagnostics = fit.diagnostics()
+        res.diagnostics = fit.advi_info() if approximate_posterior_inference else fit.diagnostics()
         res.counts_rng = rng
         if pass_fit:
             res.fit = fit

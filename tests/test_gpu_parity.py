@@ -387,3 +387,48 @@ def test_rccl_communicator_single_rank(L):
         f.close(); fc.close(); comm.close()
     finally:
         m.close(); ms.close()
+
+
+def test_advi_follows_oracle(L, oracle):
+    """Mean-field ADVI (the reference's default path, rstan::vb): same algorithm, same Philox draws => the device
+    run reaches the oracle's variational parameters (stochastic gradient ascent contracts rounding differences)."""
+    d = ind.synth(40, 10, K=4, seed=21)
+    mo = oracle.model(d["counts"], d["X"], d["exposure"], 4, n_threads=4)
+    ro = oracle.advi(mo, output_samples=400, seed=3)
+    m = L.Model(d["counts"], d["X"], d["exposure"], 4)
+    try:
+        f = m.fit_advi(output_samples=400, seed=3)
+        info = f.advi_info()
+        dr = f.draws()[0]
+        assert info["eta"] == ro["eta"] and info["converged"] and ro["converged"]
+        assert info["iterations"] == ro["iterations"]
+        assert abs(info["elbo"] - ro["elbo"]) < 1e-5 * abs(ro["elbo"])
+        assert np.max(np.abs(dr - ro["draws"]) / (1 + np.abs(ro["draws"]))) < 5e-4      # 2900 SGD steps of accumulated rounding
+        # and the approximation sits on the NUTS posterior (means; mean-field sd is known to be narrower)
+        nu = oracle.nuts_model(mo, oracle.cfg(chains=4, iter=400, warmup=150, seed=3)).draws.reshape(-1, dr.shape[1])
+        assert np.corrcoef(dr[:, 3:43].mean(0), nu[:, 3:43].mean(0))[0, 1] > 0.995
+        ci = f.ppc(1.0, 0.05, 0.95, seed=4)
+        assert np.isfinite(ci).all()
+        f.close()
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("approx_analysis", [True, False])
+def test_reference_tests_through_the_vb_path(L, bundled, approx_analysis):
+    """tests/testthat/test-ppcSeq.R:7-32 ("VB post approx no correction") and :34-57 ("VB post full") as written:
+    approximate_posterior_inference = TRUE, 3 checked genes + 50 controls, pfp = 1 => c(0, 1, 0)."""
+    import pandas as pd
+    from ppcseq_amd.methods import identify_outliers
+    genes = [str(g) for g in bundled["genes"]]
+    samples = [str(s) for s in bundled["samples"]]
+    G, S = len(genes), len(samples)
+    df = pd.DataFrame({
+        "symbol": np.repeat(genes, S), "sample": np.tile(samples, G), "value": bundled["value"].reshape(-1),
+        "PValue": np.repeat(bundled["PValue"], S), "Label": np.tile(bundled["Label"].astype(str), G)})
+    df["is_significant"] = df["symbol"].isin(["SLC16A12", "CYP1A1", "ART3"])
+    res = identify_outliers(df, formula="~ Label", sample="sample", transcript="symbol", abundance="value",
+                            significance="PValue", do_check="is_significant", percent_false_positive_genes=1,
+                            approximate_posterior_inference=True, approximate_posterior_analysis=approx_analysis,
+                            how_many_negative_controls=50, cores=1, seed=11)
+    assert res["tot_deleterious_outliers"].tolist() == [0, 1, 0]

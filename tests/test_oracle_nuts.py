@@ -49,3 +49,17 @@ def test_rng_is_counter_based_and_reproducible(oracle):
     assert abs(x.mean() - 50) < 1.0 and abs(x.var() - 675) < 60
     y = np.array([oracle.nb2_log_rng(np.log(3.0), 0.5, 1, 1, d) for d in range(20000)], dtype=float)
     assert abs(y.mean() - 3) < 0.15 and abs(y.var() - (3 + 9 / 0.5)) < 3.0
+
+
+def test_oracle_advi_sits_on_the_nuts_posterior(oracle):
+    """The ADVI restatement (rstan::vb, mean-field) converges and its means agree with the NUTS posterior means;
+    mean-field standard deviations are narrower, as expected."""
+    from oracle import independent as ind
+    d = ind.synth(40, 10, K=4, seed=21)
+    m = oracle.model(d["counts"], d["X"], d["exposure"], 4, n_threads=4)
+    r = oracle.advi(m, output_samples=300, seed=3)
+    assert r["converged"] and r["iterations"] % 100 == 0 and r["eta"] in (100, 10, 1, 0.1, 0.01)
+    x = oracle.nuts_model(m, oracle.cfg(chains=4, iter=400, warmup=150, seed=3)).draws.reshape(-1, r["mu"].size)
+    assert np.corrcoef(r["mu"][3:43], x[:, 3:43].mean(0))[0, 1] > 0.995
+    ratio = np.exp(r["omega"][3:43]) / x[:, 3:43].std(0)
+    assert 0.6 < np.median(ratio) < 1.15
