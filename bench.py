@@ -180,6 +180,7 @@ def main():
                        "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
                        "us_per_grad_eval_per_chain": round(1e6 * tot_time * world * nch / max(tot_grad, 1), 2)},
             "roofline": roof, "cpu_baseline": cpu,
+            "concordance": None if args.no_cpu_baseline else outlier_concordance(),
         }
         print(json.dumps(out))
     model.close()
@@ -187,6 +188,46 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def outlier_concordance():
+    """Second half of the BASELINE metric: outlier-call concordance. The reference's test configuration (bundled
+    `counts`: SLC16A12 / CYP1A1 / ART3 + 50 negative controls, ~ Label, pfp = 1; tests/testthat/test-ppcSeq.R:11-24),
+    discovery pass (3 chains, 150 + 334 iterations, 5 %/95 % interval): flags from the GPU path vs flags from the CPU
+    oracle (restatement of the Stan path; no rstan on this box) at the same seed."""
+    fx = os.path.join(ROOT, "tests", "golden", "counts_bundled.npz")
+    if not os.path.exists(fx):
+        return None
+    from oracle.oracle import Oracle
+    from ppcseq_amd.inference import do_inference, _post_process
+    from ppcseq_amd.methods import get_scaled_counts_bulk
+    z = np.load(fx)
+    genes = [str(g) for g in z["genes"]]
+    checked = [genes.index(g) for g in ("SLC16A12", "CYP1A1", "ART3")]
+    others = [i for i in range(len(genes)) if i not in checked]
+    ctrl = set(sorted(others, key=lambda i: z["PValue"][i])[-50:])
+    sel = checked + [i for i in others if i in ctrl]
+    counts = z["value"][sel].astype(np.int32)
+    lab = z["Label"].astype(str)
+    X = np.stack([np.ones(len(lab)), (lab == sorted(set(lab))[1]).astype(float)], axis=1)
+    mult, _ = get_scaled_counts_bulk(counts, list(range(counts.shape[1])))
+    expo = -np.log(np.array([mult[s] for s in range(counts.shape[1])]))
+    seed, p = 42, 0.05
+    g = do_inference(counts, X, expo, 3, cores=1, adj_prob_theshold=p, how_many_posterior_draws=1000, seed=seed)
+    O = Oracle()
+    mo = O.model(counts, X, expo, 3, n_threads=4)
+    r = O.nuts_model(mo, O.cfg(chains=3, iter=g.iter, warmup=150, seed=seed))
+    dr = r.draws.reshape(-1, r.draws.shape[-1])
+    ci = O.summarise(O.generated_quantities(mo, dr, 1.0, seed=seed), p, 1 - p)
+    off = 3 + counts.shape[0]
+    o = _post_process(counts[:3], ci, dr[:, off:off + 3].mean(0), X)
+    same_ppc = float(np.mean(g.ppc == o.ppc))
+    same_del = float(np.mean(g.deleterious_outliers == o.deleterious_outliers))
+    return {"config": "bundled counts, 3 checked genes + 50 controls, ~Label, discovery pass, 3 chains x (150+334), seed 42",
+            "cells": int(g.ppc.size), "ppc_identical": same_ppc, "deleterious_outliers_identical": same_del,
+            "gpu_tot_deleterious": [int(v) for v in g.deleterious_outliers.sum(1)],
+            "cpu_tot_deleterious": [int(v) for v in o.deleterious_outliers.sum(1)],
+            "max_upper_ci_rel_diff": float(np.max(np.abs(g.upper - o.upper) / (1 + o.upper)))}
 
 
 def cpu_baseline(arrays, K, gpu_ess, gpu_grad, args):

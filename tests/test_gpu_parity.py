@@ -432,3 +432,13 @@ def test_reference_tests_through_the_vb_path(L, bundled, approx_analysis):
                             approximate_posterior_inference=True, approximate_posterior_analysis=approx_analysis,
                             how_many_negative_controls=50, cores=1, seed=11)
     assert res["tot_deleterious_outliers"].tolist() == [0, 1, 0]
+
+
+def test_outlier_call_concordance_with_cpu_path():
+    """BASELINE metric, second half: identical outlier calls (GPU path vs CPU oracle path) at a fixed seed on the
+    bundled counts' test configuration."""
+    import bench
+    c = bench.outlier_concordance()
+    assert c["ppc_identical"] == 1.0 and c["deleterious_outliers_identical"] == 1.0
+    assert c["gpu_tot_deleterious"] == [0, 1, 0] == c["cpu_tot_deleterious"]
+    assert c["max_upper_ci_rel_diff"] < 0.5           # interval ends: two independent 1002-draw estimates of a heavy NB tail
