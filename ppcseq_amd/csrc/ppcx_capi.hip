@@ -250,22 +250,29 @@ struct RunIO {                  // output buffers of a run (device pointers, may
   double *lp = nullptr, *stepsize = nullptr, *accept = nullptr; int *treedepth = nullptr, *nleap = nullptr, *div = nullptr;
 };
 
-static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
+// step kernel: reduce (+ optional) advance. After an ADVANCE launch the "current" buffers are the ones it wrote.
+static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int phases) {
   const int in = (int)(w.launches & 1), out = in ^ 1;
+  StepArgs sa;
+  sa.d = m->d; sa.phases = phases;
+  sa.states_in = w.states[in]; sa.states_out = w.states[out];
+  sa.cmds_in = w.cmds[in]; sa.cmds_out = w.cmds[out];
+  sa.hyper_in = w.hyper_vecs[in]; sa.hyper_out = w.hyper_vecs[out];
+  sa.partials = w.partials; sa.nblocks_close = w.nb_close; sa.t0 = w.t0[0]; sa.nblocks_update = w.nb_update; sa.red = w.red;
+  sa.draws = io.draws; sa.draws_chain_stride = io.draws_stride; sa.n_keep = io.n_keep; sa.iter = io.iter;
+  sa.out_lp = io.lp; sa.out_stepsize = io.stepsize; sa.out_treedepth = io.treedepth; sa.out_n_leapfrog = io.nleap;
+  sa.out_divergent = io.div; sa.out_accept = io.accept; sa.done = w.done;
+  hipError_t e = launch_step_kernel(sa, nchains, w.stream);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("step kernel: ") + hipGetErrorString(e));
+  if (phases & STEP_ADVANCE) w.launches++;
+  return PPCX_OK;
+}
+static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
   UpdateArgs ua;
-  ua.d = m->d;
-  ua.states_in = w.states[in]; ua.states_out = w.states[out];
-  ua.cmds_in = w.cmds[in]; ua.cmds_out = w.cmds[out];
-  ua.hyper_in = w.hyper_vecs[in]; ua.hyper_out = w.hyper_vecs[out];
-  ua.t0_out = w.t0[out];
-  ua.red = w.red;
-  ua.vecs = w.vecs; ua.Dpad = w.Dpad;
-  ua.draws = io.draws; ua.draws_chain_stride = io.draws_stride; ua.n_keep = io.n_keep; ua.iter = io.iter;
-  ua.out_lp = io.lp; ua.out_stepsize = io.stepsize; ua.out_treedepth = io.treedepth; ua.out_n_leapfrog = io.nleap;
-  ua.out_divergent = io.div; ua.out_accept = io.accept; ua.done = w.done;
+  ua.d = m->d; ua.cmds = w.cmds[w.launches & 1]; ua.vecs = w.vecs; ua.Dpad = w.Dpad;
+  ua.draws = io.draws; ua.draws_chain_stride = io.draws_stride; ua.t0_out = w.t0[0];
   hipError_t e = launch_update_kernel(ua, w.nb_update, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("update kernel: ") + hipGetErrorString(e));
-  w.launches++;
   return PPCX_OK;
 }
 static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
@@ -282,14 +289,6 @@ static int launch_close(ppcx_model* m, Work& w, int nchains) {
   ca.sums = w.sums; ca.vecs = w.vecs; ca.Dpad = w.Dpad; ca.cmds = w.cmds[w.launches & 1]; ca.partials = w.partials;
   hipError_t e = launch_close_kernel(m->CM, ca, w.nb_close, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("close kernel: ") + hipGetErrorString(e));
-  return PPCX_OK;
-}
-static int launch_reduce(ppcx_model* m, Work& w, int nchains) {
-  ReduceArgs ra;
-  ra.cmds = w.cmds[w.launches & 1]; ra.partials = w.partials; ra.nblocks_close = w.nb_close;
-  ra.t0 = w.t0[w.launches & 1]; ra.nblocks_update = w.nb_update; ra.red = w.red;
-  hipError_t e = launch_reduce_kernel(ra, nchains, w.stream);
-  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("reduce kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
 }
 static int launch_gene(ppcx_model* m, Work& w, int nchains) {   // one gradient evaluation = loglik + close
@@ -340,7 +339,10 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
   const int ns = (int)sh.size();
   hipStream_t st = sh[0].w->stream;
   int rc = PPCX_OK;
-  for (int k = 0; k < ns; ++k) if ((rc = launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;   // PH_START
+  for (int k = 0; k < ns; ++k) {                                   // PH_START: first command, then its coordinate work
+    if ((rc = launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_REDUCE | STEP_ADVANCE)) != PPCX_OK) return rc;
+    if ((rc = launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;
+  }
   const int batch = 32, sample_every = 16;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   if (time_kernels) { HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1)); HIPCHK(hipEventCreate(&ev2)); HIPCHK(hipEventCreate(&ev3)); }
@@ -353,9 +355,11 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       if (smp) HIPCHK(hipEventRecord(ev0, st));
       for (int k = 0; k < ns; ++k) if ((rc = launch_loglik(sh[k].m, *sh[k].w, nchains)) != PPCX_OK) return rc;
       if (smp) { HIPCHK(hipEventRecord(ev1, st)); sampled = true; }
+      const bool exchange = ns > 1 || (comm && comm->comm);
       for (int k = 0; k < ns; ++k) {
         if ((rc = launch_close(sh[k].m, *sh[k].w, nchains)) != PPCX_OK) return rc;
-        if ((rc = launch_reduce(sh[k].m, *sh[k].w, nchains)) != PPCX_OK) return rc;
+        if (smp && k == ns - 1) HIPCHK(hipEventRecord(ev2, st));
+        if ((rc = launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, exchange ? STEP_REDUCE : (STEP_REDUCE | STEP_ADVANCE))) != PPCX_OK) return rc;
       }
       if (ns > 1) {
         ShardSumArgs sa; sa.n_shards = ns; sa.n = nchains * PT_COUNT;
@@ -367,8 +371,10 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
         const int e = g_rccl.AllReduce(w0.red, w0.red, (size_t)nchains * PT_COUNT, /*ncclDouble*/ 8, /*ncclSum*/ 0, comm->comm, st);
         if (e != 0) return fail(PPCX_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"));
       }
-      if (smp) HIPCHK(hipEventRecord(ev2, st));
-      for (int k = 0; k < ns; ++k) if ((rc = launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;
+      for (int k = 0; k < ns; ++k) {
+        if (exchange && (rc = launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_ADVANCE)) != PPCX_OK) return rc;
+        if ((rc = launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;
+      }
       if (smp) HIPCHK(hipEventRecord(ev3, st));
     }
     HIPCHK(hipMemcpyAsync(w0.done_host, w0.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
@@ -467,10 +473,11 @@ extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs
   HIPCHK(hipMemcpyAsync(w.states[0], states.data(), sizeof(ChainState) * nchains, hipMemcpyHostToDevice, m->stream));
   RunIO io; io.iter = nc.iter;
   hipStream_t st = m->stream;
+  if ((rc = launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE)) != PPCX_OK) return rc;
   if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
   for (int i = 0; i < warm_pairs; ++i) {
     if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
-    if ((rc = launch_reduce(m, w, nchains)) != PPCX_OK) return rc;
+    if ((rc = launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE)) != PPCX_OK) return rc;
     if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
   }
   HIPCHK(hipStreamSynchronize(st));
@@ -487,7 +494,7 @@ extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) if ((rc = (which == 1 ? launch_close(m, w, nchains) : (which == 2 ? launch_gene(m, w, nchains) : (which == 3 ? launch_update(m, w, nchains, io) : launch_loglik(m, w, nchains))))) != PPCX_OK) return rc;
+  for (int i = 0; i < reps; ++i) if ((rc = (which == 1 ? launch_close(m, w, nchains) : (which == 2 ? launch_gene(m, w, nchains) : (which == 3 ? launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE) : (which == 4 ? launch_update(m, w, nchains, io) : launch_loglik(m, w, nchains)))))) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
@@ -619,7 +626,7 @@ static int advi_launch(AdviRun& r, int op, int n_slots, double eta_scaled, int f
 static int advi_eval(AdviRun& r, int n_slots) {      // gradient evaluation of the first n_slots slots
   int rc = launch_loglik(r.m, *r.w, n_slots);
   if (rc == PPCX_OK) rc = launch_close(r.m, *r.w, n_slots);
-  if (rc == PPCX_OK) rc = launch_reduce(r.m, *r.w, n_slots);
+  if (rc == PPCX_OK) { RunIO io; rc = launch_step(r.m, *r.w, n_slots, io, STEP_REDUCE); }
   return rc;
 }
 static int advi_elbo(AdviRun& r, double* elbo) {     // Stan advi::calc_ELBO

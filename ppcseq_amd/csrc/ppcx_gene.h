@@ -140,47 +140,89 @@ struct ChainIO {
   double* draws;                 // this chain's [n_keep][D] or null
   ChainOut out;
 };
-PPCX_HD void chain_step(const Dims& d, ChainScalars& st, TreeArrays& ta, const Cmd& ex, const double* red,
-                        double T0_genes, bool have_parts, const VecRef& hv, const ChainIO& io, Reduced& rd, Cmd& nc) {
+// How the six hyper coordinates are spread over the cooperating lanes. SerialLanes: one thread does all six
+// (host emulation, tests). The device uses eight lanes of one wavefront (kernels.hip: WaveLanes): lane k < 6 owns
+// hyper coordinate k, sums cross the lanes by xor shuffles, and every lane runs the scalar logic redundantly on
+// identical inputs so no broadcast of the decisions is needed.
+struct SerialLanes {
+  static constexpr int kPerLane = 6;           // coordinates one lane owns (sizes the per-lane scratch arrays)
+  PPCX_HD int k_begin() const { return 0; }
+  PPCX_HD int k_end() const { return 6; }
+  PPCX_HD bool leader() const { return true; }
+  PPCX_HD double sum(double v) const { return v; }
+  PPCX_HD double pick(const double* own, int k) const { return own[k]; }   // value held by the owner of coordinate k
+};
+
+// `red` holds the sums of the executed command over all gene coordinates (all shards); `rd` is scratch (LDS on the
+// device) that ends up holding those sums plus the hyper coordinates' own terms.
+template <class Lanes>
+PPCX_HD void chain_step(const Lanes& ln, const Dims& d, ChainScalars& st, TreeArrays& ta, const Cmd& ex,
+                        const double* red, bool have_parts, const VecRef& hv, const ChainIO& io, Reduced& rd, Cmd& nc) {
   double lp = 0.0; bool finite = true;
   if (have_parts && ex.type != CMD_FLUSH) {
-    rd.lp_genes = red[PT_LP];
-    for (int k = 0; k < 6; ++k) rd.hsum[k] = red[PT_H0 + k];
-    rd.T0 = T0_genes + st.T0h; rd.T1 = red[PT_T1]; rd.nonfinite = red[PT_NONFINITE];
-    for (int l = 0; l < kLev; ++l) for (int k = 0; k < 6; ++k) rd.dots[l][k] = red[PT_DOTS + 6 * l + k];
-    for (int k = 0; k < 6; ++k) rd.top[k] = red[PT_TOP + k];
-    double g6[6];
-    lp = hyper_close(d, ex.hy, ex.hyp_q, rd.lp_genes, rd.hsum, g6);
-    finite = rd.nonfinite == 0.0;
-    for (int k = 0; k < 6; ++k) {              // second half kick of the hyper coordinates + tree terms
-      finite = finite && isfinite(g6[k]);
+    double g6[6], hs[6];
+    for (int k = 0; k < 6; ++k) hs[k] = red[PT_H0 + k];
+    lp = hyper_close(d, ex.hy, ex.hyp_q, red[PT_LP], hs, g6);
+    double T1h = 0.0, bad = 0.0;
+    constexpr int NK = Lanes::kPerLane;
+    const int kb = ln.k_begin();
+    double pn_k[NK], mv_k[NK];                 // indexed by k - k_begin
+    for (int k = ln.k_begin(); k < ln.k_end(); ++k) {   // second half kick of the hyper coordinates
       const double minv = hv.at(V_MINV, k);
       const double pn = hv.at(V_P0 + 3 * ex.dir, k) + 0.5 * ex.eps * g6[k];
       hv.at(V_P0 + 3 * ex.dir, k) = pn; hv.at(V_G0 + 3 * ex.dir, k) = g6[k];
-      rd.T1 += pn * pn * minv;
-      if (ex.type == CMD_LEAF) {
-        NodeVals nv{pn, pn};
-        for (int l = 0; l < ex.n_merge; ++l) coord_merge_dots(hv, k, l, pn, minv, &nv, rd.dots[l]);
-        if (!ex.subtree_complete) coord_store_slot(hv, k, ex.n_merge, pn, nv);
-        else coord_top_dots(hv, k, ex.dir, pn, minv, nv, rd.top);
+      T1h += pn * pn * minv;
+      bad += isfinite(g6[k]) ? 0.0 : 1.0;
+      pn_k[k - kb] = pn; mv_k[k - kb] = minv;
+    }
+    T1h = ln.sum(T1h); bad = ln.sum(bad);
+    finite = red[PT_NONFINITE] == 0.0 && bad == 0.0;
+    if (ln.leader()) {
+      rd.lp_genes = red[PT_LP];
+      for (int k = 0; k < 6; ++k) rd.hsum[k] = hs[k];
+      rd.T0 = red[PT_T0] + st.T0h; rd.T1 = red[PT_T1] + T1h; rd.nonfinite = red[PT_NONFINITE];
+    }
+    if (ex.type == CMD_LEAF) {                 // tree terms of the hyper coordinates, level by level
+      NodeVals nv[NK];
+      for (int k = ln.k_begin(); k < ln.k_end(); ++k) nv[k - kb] = NodeVals{pn_k[k - kb], pn_k[k - kb]};
+      for (int l = 0; l < ex.n_merge; ++l) {
+        double dots[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = ln.k_begin(); k < ln.k_end(); ++k) coord_merge_dots(hv, k, l, pn_k[k - kb], mv_k[k - kb], &nv[k - kb], dots);
+        for (int j = 0; j < 6; ++j) { const double t = ln.sum(dots[j]); if (ln.leader()) rd.dots[l][j] = red[PT_DOTS + 6 * l + j] + t; }
+      }
+      if (!ex.subtree_complete) {
+        for (int k = ln.k_begin(); k < ln.k_end(); ++k) coord_store_slot(hv, k, ex.n_merge, pn_k[k - kb], nv[k - kb]);
+      } else {
+        double top[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = ln.k_begin(); k < ln.k_end(); ++k) coord_top_dots(hv, k, ex.dir, pn_k[k - kb], mv_k[k - kb], nv[k - kb], top);
+        for (int j = 0; j < 6; ++j) { const double t = ln.sum(top[j]); if (ln.leader()) rd.top[j] = red[PT_TOP + j] + t; }
       }
     }
   }
-  chain_advance(st, ta, ex, rd, lp, finite, io.out, nc);
+  ChainOut out = io.out;
+  if (!ln.leader()) { out.lp = nullptr; out.stepsize = nullptr; out.treedepth = nullptr; out.n_leapfrog = nullptr; out.divergent = nullptr; out.accept = nullptr; }
+  chain_advance(st, ta, ex, rd, lp, finite, out, nc);       // every lane: same inputs, same decisions
   nc.k0 = st.k0; nc.k1 = st.k1;
   if (nc.type != CMD_DONE) {
-    double T0h = 0.0;
-    for (int k = 0; k < 6; ++k) {
+    constexpr int NK2 = Lanes::kPerLane;
+    const int kb2 = ln.k_begin();
+    double T0h = 0.0, hq[NK2];
+    for (int j = 0; j < NK2; ++j) hq[j] = 0.0;
+    for (int k = ln.k_begin(); k < ln.k_end(); ++k) {
       const int hcol = hyper_index(d, k);
       const CoordVals cv = coord_pre(nc, hv, k, hcol, global_flat(d, hcol), true, io.draws, d.D, st.k0, st.k1, &T0h);
+      hq[k - kb2] = cv.q;
       if (nc.type != CMD_FLUSH) {
         const double ph = cv.p + 0.5 * nc.eps * cv.g;
-        const double qn = cv.q + nc.eps * cv.minv * ph;
-        hv.at(V_Q0 + 3 * nc.dir, k) = qn; hv.at(V_P0 + 3 * nc.dir, k) = ph;
-        nc.hyp_q[k] = qn;
+        hq[k - kb2] = cv.q + nc.eps * cv.minv * ph;
+        hv.at(V_Q0 + 3 * nc.dir, k) = hq[k - kb2]; hv.at(V_P0 + 3 * nc.dir, k) = ph;
       }
     }
-    st.T0h = T0h;
+    st.T0h = ln.sum(T0h);
+    if (nc.type != CMD_FLUSH) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) nc.hyp_q[k] = ln.pick(hq, k);
+    }
     nc.hy = make_hyper(nc.hyp_q, d.lambda_mu_mu);
   }
 }

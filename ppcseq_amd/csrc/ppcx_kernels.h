@@ -31,11 +31,20 @@ struct CloseArgs {
   double* partials;             // [chains][nblocks_close][PT_COUNT]
 };
 
-struct ReduceArgs {
-  const Cmd* cmds;
-  const double* partials; int nblocks_close;   // [chains][nblocks_close][PT_COUNT]
-  const double* t0; int nblocks_update;        // [chains][nblocks_update]
-  double* red;                                  // [chains][PT_COUNT]
+enum StepPhase : int { STEP_REDUCE = 1, STEP_ADVANCE = 2 };
+struct StepArgs {
+  Dims d;
+  int phases;                   // STEP_REDUCE | STEP_ADVANCE (one launch), or the two halves around a shard exchange
+  const ChainState* states_in; ChainState* states_out;   // double-buffered between rounds
+  const Cmd* cmds_in; Cmd* cmds_out;
+  const double* hyper_in; double* hyper_out;             // [chains][V_COUNT][8]
+  const double* partials; int nblocks_close;             // [chains][nblocks_close][PT_COUNT]
+  const double* t0; int nblocks_update;                  // [chains][nblocks_update]
+  double* red;                                           // [chains][PT_COUNT]
+  double* draws; long draws_chain_stride;
+  int n_keep, iter;
+  double* out_lp; double* out_stepsize; int* out_treedepth; int* out_n_leapfrog; int* out_divergent; double* out_accept;
+  int* done;                    // [chains]
 };
 
 constexpr int kMaxShards = 16;
@@ -43,16 +52,10 @@ struct ShardSumArgs { double* bufs[kMaxShards]; int n_shards; int n; };
 
 struct UpdateArgs {
   Dims d;
-  const ChainState* states_in; ChainState* states_out;   // double-buffered between launches
-  const Cmd* cmds_in; Cmd* cmds_out;
-  const double* hyper_in; double* hyper_out;             // [chains][V_COUNT][8]
-  double* t0_out;                                        // [chains][nblocks_update]
-  const double* red;                                     // [chains][PT_COUNT] reduced sums of this leapfrog
+  const Cmd* cmds;              // the commands the step kernel just wrote
   double* vecs; long Dpad;
   double* draws; long draws_chain_stride;
-  int n_keep, iter;
-  double* out_lp; double* out_stepsize; int* out_treedepth; int* out_n_leapfrog; int* out_divergent; double* out_accept;
-  int* done;                    // [chains]
+  double* t0_out;               // [chains][nblocks_update]
 };
 
 enum AdviOp : int { ADVI_DRAW = 0, ADVI_RESET = 1, ADVI_STEP = 2 };
@@ -84,7 +87,7 @@ struct PpcArgs {
 
 hipError_t launch_loglik_kernel(int L, int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st);
-hipError_t launch_reduce_kernel(const ReduceArgs& a, int nchains, hipStream_t st);
+hipError_t launch_step_kernel(const StepArgs& a, int nchains, hipStream_t st);
 hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st);
 hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_advi_kernel(const AdviArgs& a, int nblocks, hipStream_t st);

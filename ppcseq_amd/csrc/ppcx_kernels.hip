@@ -161,39 +161,121 @@ __global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
 }
 
 // -----------------------------------------------------------------------------------------------------
-// reduce step: one workgroup per chain folds the close kernel's slab (and the T0 slab of the previous update
-// launch) into PT_COUNT sums in a fixed order. For gene shards these per-shard sums are then added across
-// shards (RCCL all-reduce between processes, ppcx_sum_shards_kernel inside one process).
+// step kernel: one workgroup per chain.
+//  phase REDUCE: fold the close kernel's slab (and the T0 slab of the previous update launch) into PT_COUNT sums in
+//                a fixed order. For gene shards these per-shard sums are then added across shards (RCCL all-reduce
+//                between processes, ppcx_sum_shards_kernel inside one process) before phase STEP runs.
+//  phase STEP  : eight lanes of wavefront 0 run the NUTS / adaptation state machine (chain_step): lane k < 6 owns
+//                hyper-parameter k, the scalar logic runs redundantly in registers, run-time-indexed arrays in LDS.
 // -----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ppcx_reduce_kernel(ReduceArgs a) {
+struct WaveLanes {                              // cooperating lanes 0..7 of one wavefront
+  static constexpr int kPerLane = 1;
+  int lane;
+  __device__ __forceinline__ int k_begin() const { return lane; }
+  __device__ __forceinline__ int k_end() const { return lane < 6 ? lane + 1 : lane; }
+  __device__ __forceinline__ bool leader() const { return lane == 0; }
+  __device__ __forceinline__ double sum(double v) const {
+    v += __shfl_xor(v, 1, 8); v += __shfl_xor(v, 2, 8); v += __shfl_xor(v, 4, 8);
+    return v;
+  }
+  __device__ __forceinline__ double pick(const double* own, int k) const { return __shfl(own[0], k, 8); }
+};
+
+__global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   __shared__ double sm[8][32];
   __shared__ double sT0[256];
+  __shared__ double red[PT_COUNT];
+  __shared__ double hv[V_COUNT * 8];           // the six hyper coordinates of every per-coordinate vector
+  __shared__ Cmd s_ex;
+  __shared__ ChainState s_st;
+  __shared__ Reduced s_rd;
   const int chain = blockIdx.x, tid = threadIdx.x;
-  const Cmd& ex = a.cmds[chain];
-  double* out = a.red + (long)chain * PT_COUNT;
-  const int np = (ex.type == CMD_DONE || ex.type == CMD_FLUSH) ? 0 : parts_used(ex);
-  const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
-  for (int v0 = 0; v0 < PT_COUNT; v0 += 32) {
-    const int vv = v0 + (tid & 31), ch = tid >> 5;
-    double s = 0.0;
-    if (vv < np) for (int b = ch; b < a.nblocks_close; b += 8) s += slab[(long)b * PT_COUNT + vv];
-    sm[ch][tid & 31] = s;
+  const ChainState* st_in = a.states_in + chain;
+  const bool done = st_in->sc.phase == PH_DONE;
+  double* rg = a.red + (long)chain * PT_COUNT;
+  if (a.phases & STEP_REDUCE) {
+    const Cmd& exg = a.cmds_in[chain];
+    const int np = (done || exg.type == CMD_DONE || exg.type == CMD_FLUSH) ? 0 : parts_used(exg);
+    const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
+    for (int i = tid; i < PT_COUNT; i += 256) red[i] = 0.0;
     __syncthreads();
-    if (tid < 32 && v0 + tid < PT_COUNT) {
-      double t = 0.0;
+    for (int v0 = 0; v0 < np; v0 += 32) {        // only the sums this command produced (np is uniform)
+      const int vv = v0 + (tid & 31), ch = tid >> 5;
+      double s = 0.0;
+      if (vv < np) for (int b = ch; b < a.nblocks_close; b += 8) s += slab[(long)b * PT_COUNT + vv];
+      sm[ch][tid & 31] = s;
+      __syncthreads();
+      if (tid < 32 && v0 + tid < np) {
+        double t = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += sm[k][tid];
-      if (v0 + tid != PT_T0) out[v0 + tid] = t;
+        for (int k = 0; k < 8; ++k) t += sm[k][tid];
+        if (v0 + tid != PT_T0) red[v0 + tid] = t;
+      }
+      __syncthreads();
+    }
+    // kinetic energy of freshly drawn momenta: only commands that drew momenta left something in the T0 slab
+    const bool fresh = !done && (exg.pre_flags & (PRE_NEW_TRANSITION | PRE_EPS_TRY)) != 0;
+    if (fresh) {
+      const double* t0s = a.t0 + (long)chain * a.nblocks_update;
+      double s = 0.0;
+      for (int b = tid; b < a.nblocks_update; b += 256) s += t0s[b];
+      sT0[tid] = s;
+      __syncthreads();
+      for (int stp = 128; stp > 0; stp >>= 1) { if (tid < stp) sT0[tid] += sT0[tid + stp]; __syncthreads(); }
+      if (tid == 0) red[PT_T0] = sT0[0];
     }
     __syncthreads();
+    if (!(a.phases & STEP_ADVANCE)) { for (int i = tid; i < PT_COUNT; i += 256) rg[i] = red[i]; return; }
+  } else {
+    for (int i = tid; i < PT_COUNT; i += 256) red[i] = rg[i];     // sums completed by the shard exchange
+    __syncthreads();
   }
-  const double* t0s = a.t0 + (long)chain * a.nblocks_update;
-  double s = 0.0;
-  for (int b = tid; b < a.nblocks_update; b += 256) s += t0s[b];
-  sT0[tid] = s;
+  // ---- phase STEP
+  if (done) {                                  // finished chain: carry its final state across the double buffer
+    if (tid == 0) { a.states_out[chain] = *st_in; a.cmds_out[chain] = a.cmds_in[chain]; }
+    const double* hi = a.hyper_in + (long)chain * V_COUNT * 8;
+    double* ho = a.hyper_out + (long)chain * V_COUNT * 8;
+    for (int i = tid; i < V_COUNT * 8; i += 256) ho[i] = hi[i];
+    return;
+  }
+  {
+    const int* src = reinterpret_cast<const int*>(a.cmds_in + chain); int* dst = reinterpret_cast<int*>(&s_ex);
+    for (int i = tid; i < (int)(sizeof(Cmd) / sizeof(int)); i += 256) dst[i] = src[i];
+    const int* s2 = reinterpret_cast<const int*>(st_in); int* d2 = reinterpret_cast<int*>(&s_st);
+    for (int i = tid; i < (int)(sizeof(ChainState) / sizeof(int)); i += 256) d2[i] = s2[i];
+    const double* hvg = a.hyper_in + (long)chain * V_COUNT * 8;
+    for (int i = tid; i < V_COUNT * 8; i += 256) hv[i] = hvg[i];
+  }
   __syncthreads();
-  for (int stp = 128; stp > 0; stp >>= 1) { if (tid < stp) sT0[tid] += sT0[tid + stp]; __syncthreads(); }
-  if (tid == 0) out[PT_T0] = sT0[0];
+  const bool have_parts = s_st.sc.phase != PH_START;
+  Cmd* nc_out = a.cmds_out + chain;
+  if (tid < 8) {
+    ChainScalars st = s_st.sc;                 // scalars in registers; the run-time-indexed arrays stay in LDS
+    ChainIO io;
+    io.draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
+    io.out.lp = a.out_lp ? a.out_lp + (long)chain * a.n_keep : nullptr;
+    io.out.stepsize = a.out_stepsize ? a.out_stepsize + (long)chain * a.iter : nullptr;
+    io.out.treedepth = a.out_treedepth ? a.out_treedepth + (long)chain * a.iter : nullptr;
+    io.out.n_leapfrog = a.out_n_leapfrog ? a.out_n_leapfrog + (long)chain * a.iter : nullptr;
+    io.out.divergent = a.out_divergent ? a.out_divergent + (long)chain * a.iter : nullptr;
+    io.out.accept = a.out_accept ? a.out_accept + (long)chain * a.iter : nullptr;
+    Cmd nc;
+#ifndef PPCX_ABLATE_NOSTEP
+    chain_step(WaveLanes{tid}, a.d, st, s_st.ta, s_ex, red, have_parts, VecRef{hv, 8}, io, s_rd, nc);
+#else
+    if (have_parts) nc = s_ex; else chain_step(WaveLanes{tid}, a.d, st, s_st.ta, s_ex, red, have_parts, VecRef{hv, 8}, io, s_rd, nc);
+#endif
+    if (tid == 0) {
+      s_st.sc = st;
+      *nc_out = nc;
+      if (st.phase == PH_DONE) a.done[chain] = 1 + st.error;
+    }
+  }
+  __syncthreads();
+  double* hvo = a.hyper_out + (long)chain * V_COUNT * 8;
+  for (int i = tid; i < V_COUNT * 8; i += 256) hvo[i] = hv[i];
+  const int* s2 = reinterpret_cast<const int*>(&s_st); int* d2 = reinterpret_cast<int*>(a.states_out + chain);
+  for (int i = tid; i < (int)(sizeof(ChainState) / sizeof(int)); i += 256) d2[i] = s2[i];
 }
 
 // in-process gene shards: every shard ends with the sum over shards (fixed order => identical bits everywhere)
@@ -206,89 +288,20 @@ __global__ void ppcx_sum_shards_kernel(ShardSumArgs a) {
 }
 
 // -----------------------------------------------------------------------------------------------------
-// kernel B: reduce A's partial sums, advance the chain (redundantly per workgroup), update coordinates
+// update kernel: apply the command the step kernel just issued to every gene-owned coordinate -- proposal / sample
+// copies, draw storage, Welford / metric updates, momentum refresh (Philox per coordinate), first half kick and
+// drift of the next leapfrog -- and leave the kinetic energy of fresh momenta as per-workgroup partial sums.
 // -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
-  __shared__ double red[PT_COUNT];
-  __shared__ double hv[V_COUNT * 8];           // the six hyper coordinates of every per-coordinate vector
   __shared__ double sT0[256];
-  __shared__ Cmd s_nc, s_ex;                   // the state machine works on LDS copies: no scratch, no global latency
-  __shared__ ChainState s_st;
-  __shared__ Reduced s_rd;
   const int chain = blockIdx.y, tid = threadIdx.x;
-  const ChainState* st_in = a.states_in + chain;
-  if (st_in->sc.phase == PH_DONE) {            // finished chain: carry its final state across the double buffer
-    if (blockIdx.x == 0) {
-      if (tid == 0) { a.states_out[chain] = *st_in; a.cmds_out[chain] = a.cmds_in[chain]; }
-      const double* hi = a.hyper_in + (long)chain * V_COUNT * 8;
-      double* ho = a.hyper_out + (long)chain * V_COUNT * 8;
-      for (int i = tid; i < V_COUNT * 8; i += 256) ho[i] = hi[i];
-    }
-    return;
-  }
-  {
-    const int* src = reinterpret_cast<const int*>(a.cmds_in + chain); int* dst = reinterpret_cast<int*>(&s_ex);
-    for (int i = tid; i < (int)(sizeof(Cmd) / sizeof(int)); i += 256) dst[i] = src[i];
-    const int* s2 = reinterpret_cast<const int*>(st_in); int* d2 = reinterpret_cast<int*>(&s_st);
-    for (int i = tid; i < (int)(sizeof(ChainState) / sizeof(int)); i += 256) d2[i] = s2[i];
-  }
-  const Cmd& ex = s_ex;
+  const Cmd& nc = a.cmds[chain];
   const Dims& d = a.d;
-  // this thread's first coordinate is fetched now; its latency hides behind the reduction and the state machine
-  const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
-  const int i_first = 3 + blockIdx.x * 256 + tid;
-  CoordCache cache;
-  if (i_first < d.off_tail) cache = coord_prefetch(v, i_first);
-  const double* hvg = a.hyper_in + (long)chain * V_COUNT * 8;
-  for (int i = tid; i < V_COUNT * 8; i += 256) hv[i] = hvg[i];
-  for (int i = tid; i < PT_COUNT; i += 256) red[i] = 0.0;
-  const bool have_parts = st_in->sc.phase != PH_START;
-  __syncthreads();
-  double T0g = 0.0;
-  if (have_parts) {                              // sums of this leapfrog, already reduced (and, for gene shards,
-    const double* rg = a.red + (long)chain * PT_COUNT;          // summed over the shards) by the reduce step
-    for (int i = tid; i < PT_COUNT; i += 256) red[i] = rg[i];
-    __syncthreads();
-    T0g = red[PT_T0];
-  }
-  if (tid == 0) {
-    ChainScalars st = s_st.sc;                   // scalars in registers; the run-time-indexed arrays stay in LDS
-    ChainIO io;
-    const bool lead = blockIdx.x == 0;           // only one workgroup writes the outputs
-    io.draws = (lead && a.draws) ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
-    io.out.lp = (lead && a.out_lp) ? a.out_lp + (long)chain * a.n_keep : nullptr;
-    io.out.stepsize = (lead && a.out_stepsize) ? a.out_stepsize + (long)chain * a.iter : nullptr;
-    io.out.treedepth = (lead && a.out_treedepth) ? a.out_treedepth + (long)chain * a.iter : nullptr;
-    io.out.n_leapfrog = (lead && a.out_n_leapfrog) ? a.out_n_leapfrog + (long)chain * a.iter : nullptr;
-    io.out.divergent = (lead && a.out_divergent) ? a.out_divergent + (long)chain * a.iter : nullptr;
-    io.out.accept = (lead && a.out_accept) ? a.out_accept + (long)chain * a.iter : nullptr;
-#ifndef PPCX_ABLATE_NOSTEP
-    chain_step(d, st, s_st.ta, ex, red, T0g, have_parts, VecRef{hv, 8}, io, s_rd, s_nc);
-#else
-    if (have_parts) s_nc = ex; else chain_step(d, st, s_st.ta, ex, red, T0g, have_parts, VecRef{hv, 8}, io, s_rd, s_nc);
-#endif
-    s_st.sc = st;
-    if (lead && st.phase == PH_DONE) a.done[chain] = 1 + st.error;
-  }
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    double* hvo = a.hyper_out + (long)chain * V_COUNT * 8;
-    for (int i = tid; i < V_COUNT * 8; i += 256) hvo[i] = hv[i];
-    const int* src = reinterpret_cast<const int*>(&s_nc); int* dst = reinterpret_cast<int*>(a.cmds_out + chain);
-    for (int i = tid; i < (int)(sizeof(Cmd) / sizeof(int)); i += 256) dst[i] = src[i];
-    const int* s2 = reinterpret_cast<const int*>(&s_st); int* d2 = reinterpret_cast<int*>(a.states_out + chain);
-    for (int i = tid; i < (int)(sizeof(ChainState) / sizeof(int)); i += 256) d2[i] = s2[i];
-  }
-  // per-coordinate work of the new command for this workgroup's slice of the gene-owned coordinates
-  const Cmd& nc = s_nc;
   double T0 = 0.0;
   if (nc.type != CMD_DONE) {
+    const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
     double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
-#ifndef PPCX_ABLATE_NOCOORD
-    if (i_first < d.off_tail) coord_update(d, nc, v, i_first, draws, &T0, &cache);
-#endif
-    for (int i = i_first + gridDim.x * 256; i < d.off_tail; i += gridDim.x * 256)
-      coord_update(d, nc, v, i, draws, &T0);
+    for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, nc, v, i, draws, &T0);
   }
   sT0[tid] = T0;
   __syncthreads();
@@ -513,8 +526,8 @@ hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int ncha
   else hipLaunchKernelGGL((ppcx_close_kernel<8>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
-hipError_t launch_reduce_kernel(const ReduceArgs& a, int nchains, hipStream_t st) {
-  hipLaunchKernelGGL(ppcx_reduce_kernel, dim3(nchains), dim3(256), 0, st, a);
+hipError_t launch_step_kernel(const StepArgs& a, int nchains, hipStream_t st) {
+  hipLaunchKernelGGL(ppcx_step_kernel, dim3(nchains), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st) {

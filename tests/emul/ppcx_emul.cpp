@@ -73,7 +73,9 @@ static void gene_pass_dispatch(const EmulModel& m, const Cmd& c, const VecRef& v
 static double update_pass(const EmulModel& m, ChainState& st, const Cmd& ex, const double* red, double T0_prev,
                           bool have_parts, const VecRef& v, const VecRef& h, const ChainIO& io, Cmd& nc) {
   Reduced rd;
-  chain_step(m.d, st.sc, st.ta, ex, red, T0_prev, have_parts, h, io, rd, nc);
+  std::vector<double> r2(red, red + PT_COUNT);
+  r2[PT_T0] = T0_prev;
+  chain_step(SerialLanes{}, m.d, st.sc, st.ta, ex, r2.data(), have_parts, h, io, rd, nc);
   double T0 = 0.0;
   if (nc.type != CMD_DONE)
     for (int i = 3; i < m.d.off_tail; ++i) coord_update(m.d, nc, v, i, io.draws, &T0);
