@@ -1,4 +1,4 @@
-"""Kernel-level timing of the loglik / close kernels (development aid)."""
+"""Kernel-level timing of the loglik kernel over launch geometries (development aid)."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,13 +8,9 @@ G, S = int(os.environ.get("G", 20000)), int(os.environ.get("S", 200))
 d = synth(G, S, seed=20253); K = d["K"]
 m = L.Model(d["counts"], d["X"], d["exposure"], K)
 bgrad = 4.0 * G * S + 16.0 * 3 * G + 8.0 * S * 3
-for chains in [int(x) for x in os.environ.get("CHAINS", "1,4").split(",")]:
+for chains in [int(x) for x in os.environ.get("CHAINS", "4").split(",")]:
     for lanes in [int(x) for x in os.environ.get("LANES", "8,16").split(",")]:
         for gpw in [int(x) for x in os.environ.get("GPW", "0").split(",")]:
             m.set_launch(lanes, gpw)
-            out = []
-            for which, name in [(0, "loglik"), (1, "close"), (2, "both")]:
-                ms, t = m.bench_gene_kernel(chains, 40, 30, 100 * which + 1)
-                out.append(f"{name} {1e3*ms/chains:.1f}")
             ms, t = m.bench_gene_kernel(chains, 40, 30, 1)
-            print(f"chains {chains} L {lanes} gpw {gpw} launch {m.get_launch()} type {t}: us/chain-grad: {' | '.join(out)} ; loglik {bgrad*chains/ms/1e6:.0f} GB/s", flush=True)
+            print(f"chains {chains} L {lanes} gpw {gpw} launch {m.get_launch()} type {t}: loglik {1e3*ms/chains:.2f} us/chain-grad ; {bgrad*chains/ms/1e6:.0f} GB/s", flush=True)
