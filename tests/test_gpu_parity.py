@@ -443,3 +443,61 @@ def test_outlier_call_concordance_with_cpu_path():
     assert c["deleterious_outliers_identical"] == 1.0 and c["ppc_identical"] >= 0.9
     assert c["gpu_tot_deleterious"] == [0, 1, 0] == c["cpu_tot_deleterious"]
     assert c["max_upper_ci_rel_diff"] < 0.5           # interval ends: two independent 1002-draw estimates of a heavy NB tail
+
+
+def test_dot_C_entry_point_matches_handle_api(L):
+    """`ppcx_do_inference_C` is the all-pointer / void entry point an R `.C()` call binds: it must give
+    what the handle-level sequence model_create -> fit_nuts -> fit_ppc -> columns gives."""
+    import ctypes as C
+    d = ind.synth(30, 8, K=4, seed=3)
+    G, S, Cc, K = 30, 8, 2, 4
+    counts = np.ascontiguousarray(d["counts"], np.int32)
+    X = np.asfortranarray(d["X"])
+    expo = np.ascontiguousarray(d["exposure"])
+    excl = np.array([5, 17], np.int32)
+    chains, iter_, warmup, seed = 3, 120, 80, 13
+    dims = np.array([0, G, S, Cc, K, excl.size, chains, iter_, warmup, 0, 0], np.int32)
+    reals = np.array([5.612671, 0.7352941, 0.01, 0.99, float(seed)])
+    ci = np.zeros((K, S, 4)); slope = np.zeros(K); status = np.array([99], np.int32)
+    lib = L.load()
+    lib.ppcx_do_inference_C.restype = None
+    lib.ppcx_do_inference_C(dims.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), X.ctypes.data_as(C.c_void_p),
+                            expo.ctypes.data_as(C.c_void_p), excl.ctypes.data_as(C.c_void_p), reals.ctypes.data_as(C.c_void_p),
+                            ci.ctypes.data_as(C.c_void_p), slope.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p))
+    assert status[0] == 0
+    m = L.Model(counts, X, expo, K, excl=excl)
+    try:
+        f = m.fit_nuts(chains=chains, iter=iter_, warmup=warmup, seed=seed)
+        ci2 = f.ppc(0.7352941, 0.01, 0.99, seed=seed)
+        slope2 = f.columns(np.arange(3 + G, 3 + G + K)).reshape(-1, K).mean(0)
+        f.close()
+    finally:
+        m.close()
+    assert np.array_equal(ci, ci2) and np.allclose(slope, slope2, rtol=0, atol=1e-14)
+    # bad arguments come back as a status, never as an exception across the boundary
+    dims[1] = 0
+    lib.ppcx_do_inference_C(dims.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), X.ctypes.data_as(C.c_void_p),
+                            expo.ctypes.data_as(C.c_void_p), excl.ctypes.data_as(C.c_void_p), reals.ctypes.data_as(C.c_void_p),
+                            ci.ctypes.data_as(C.c_void_p), slope.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p))
+    assert status[0] == -1
+
+
+def test_degenerate_shapes(L, oracle):
+    """No checked genes (K = 0: nothing to predict), a single gene, a single sample: the sampler still runs and the
+    density still matches the oracle."""
+    for (G, S, K) in [(6, 3, 0), (1, 5, 1), (4, 1, 2)]:
+        d = ind.synth(G, S, K=K, seed=G + S)
+        mo = oracle.model(d["counts"], d["X"], d["exposure"], K)
+        m = L.Model(d["counts"], d["X"], d["exposure"], K)
+        try:
+            u = np.random.default_rng(1).uniform(-1, 1, m.D)
+            lp, g = m.log_prob_grad(u)
+            lpo, go = oracle.log_prob_grad(mo, u)
+            assert abs(lp - lpo) <= 1e-11 * max(1.0, abs(lpo)) and np.max(np.abs(g - go) / (1 + np.abs(go))) < 1e-10
+            f = m.fit_nuts(chains=2, iter=30, warmup=20, seed=3)
+            assert f.draws().shape == (2, 10, m.D) and np.isfinite(f.draws()).all()
+            ci = f.ppc(1.0, 0.05, 0.95, seed=1)
+            assert ci.shape == (K, S, 4) and np.isfinite(ci).all()
+            f.close()
+        finally:
+            m.close()

@@ -102,3 +102,24 @@ def test_test_config_selection(bundled):
     assert genes[3:8] == ["AATF", "ABCA9", "ABT1", "BHLHE40", "C1orf174"]
     assert int(counts.sum()) == 2080390 and int(counts.max()) == 24912
     assert X[:, 1].sum() == 11                                               # 10 High / 11 Neoadjuvant
+
+
+def test_identify_outliers_argument_validation():
+    """Error behaviour of identify_outliers mirrors R/methods.R:108-153 (raised before any GPU work)."""
+    import pandas as pd
+    base = pd.DataFrame({"sample": ["a", "b"] * 2, "symbol": ["g1", "g1", "g2", "g2"], "value": [1, 2, 3, 4],
+                         "PValue": [0.1, 0.1, 0.9, 0.9], "chk": [True, True, False, False]})
+    kw = dict(formula="~ 1", sample="sample", transcript="symbol", abundance="value", significance="PValue", do_check="chk")
+    with pytest.raises(ValueError):                      # missing column (check_columns_exist)
+        meth.identify_outliers(base.drop(columns=["PValue"]), **kw)
+    with pytest.raises(ValueError):                      # NA in a used column (check_if_any_NA)
+        meth.identify_outliers(base.assign(PValue=[0.1, None, 0.9, 0.9]), **kw)
+    with pytest.raises(ValueError):                      # percent_false_positive_genes outside 0..100
+        meth.identify_outliers(base, percent_false_positive_genes=101, **kw)
+    with pytest.raises(TypeError):                       # abundance must be integer (R/methods.R:146-153)
+        meth.identify_outliers(base.assign(value=[1.0, 2.0, 3.0, 4.0]), **kw)
+    with pytest.raises(ValueError):                      # VB + save_generated_quantities (R/methods.R:131-132)
+        meth.identify_outliers(base, approximate_posterior_inference=True, save_generated_quantities=True, **kw)
+    with pytest.warns(UserWarning):                      # nothing to check -> empty result (R/methods.R:117-127)
+        out = meth.identify_outliers(base.assign(chk=False), **kw)
+    assert len(out) == 0 and list(out.columns)[0] == "symbol"
