@@ -159,7 +159,7 @@ def main():
                     "algorithmic_bytes_per_launch": b_grad * chains_per_launch, "avg_launch_ms": round(ms, 5),
                     "timed_launches": int(kA_n)}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # reported at N = 1 only (rank 0's host cores)
             cpu = cpu_baseline(arrays, K, tot_ess, tot_grad, args)
         out = {
             "metric": "effective samples/sec (whole node) for NB hierarchical fit",
@@ -180,7 +180,7 @@ def main():
                        "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
                        "us_per_grad_eval_per_chain": round(1e6 * tot_time * world * nch / max(tot_grad, 1), 2)},
             "roofline": roof, "cpu_baseline": cpu,
-            "concordance": None if args.no_cpu_baseline else outlier_concordance(),
+            "concordance": None if (args.no_cpu_baseline or world > 1) else outlier_concordance(),
         }
         print(json.dumps(out))
     model.close()
