@@ -501,3 +501,48 @@ def test_degenerate_shapes(L, oracle):
             f.close()
         finally:
             m.close()
+
+
+def test_posterior_and_intervals_match_cpu_path_within_monte_carlo_error(L, oracle):
+    """north_star: "posterior draws and credible-interval outlier flags match the reference CPU fit within Monte-Carlo
+    tolerance". Medium problem (500 genes x 40 samples), reference-default chains/iterations; GPU fit vs the CPU oracle
+    fit (independent realisations: the chains separate through floating-point chaos). Hyper-parameter means are
+    compared with z-scores built from each run's own bulk-ESS; predictive intervals of the checked genes with the
+    spread expected for two independent 1002-draw quantile estimates; outlier flags must coincide except on cells
+    whose count lies within that spread of the interval end."""
+    from ppcseq_amd.ess import ess_bulk
+    d = ind.synth(500, 40, K=25, seed=77)
+    K = d["K"]
+    mo = oracle.model(d["counts"], d["X"], d["exposure"], K, n_threads=8)
+    r = oracle.nuts_model(mo, oracle.cfg(chains=3, iter=484, warmup=150, seed=5))
+    m = L.Model(d["counts"], d["X"], d["exposure"], K)
+    try:
+        f = m.fit_nuts(chains=3, iter=484, warmup=150, seed=5)
+        D = f.D
+        cols = [0, 1, 2, D - 3, D - 2, D - 1]
+        g = f.columns(cols)                                   # [3, 334, 6]
+        ci_g = f.ppc(1.0, 0.05, 0.95, seed=9)
+        dg = f.diagnostics()
+        f.close()
+    finally:
+        m.close()
+    c = r.draws[..., cols]
+    for j in range(6):
+        eg, ec = ess_bulk(g[..., j]), ess_bulk(c[..., j])
+        se = np.sqrt(g[..., j].var() / eg + c[..., j].var() / ec)
+        assert abs(g[..., j].mean() - c[..., j].mean()) < 4.5 * se, (j, eg, ec)
+        assert 0.6 < g[..., j].std() / c[..., j].std() < 1.6
+    assert dg["divergent"][:, 150:].mean() < 0.01 and abs(dg["treedepth"][:, 150:].mean() - r.treedepth[:, 150:].mean()) < 1.0
+    ci_c = oracle.summarise(oracle.generated_quantities(mo, r.draws.reshape(-1, D), 1.0, seed=9), 0.05, 0.95)
+    rel_up = np.abs(ci_g[..., 3] - ci_c[..., 3]) / (1 + ci_c[..., 3])
+    assert np.median(rel_up) < 0.08 and np.quantile(rel_up, 0.99) < 0.5
+    y = d["counts"][:K].astype(float)
+    flag_g = (y < ci_g[..., 2]) | (y > ci_g[..., 3])
+    flag_c = (y < ci_c[..., 2]) | (y > ci_c[..., 3])
+    differ = flag_g != flag_c
+    margin = np.minimum(np.abs(y - ci_c[..., 3]) / (1 + ci_c[..., 3]), np.abs(y - ci_c[..., 2]) / (1 + ci_c[..., 2]))
+    assert differ.mean() < 0.03 and np.all(margin[differ] < 0.35)
+    # every injected gross outlier is flagged by both paths
+    for (gi, si) in d["injected"]:
+        if flag_c[gi, si]:
+            assert flag_g[gi, si]
