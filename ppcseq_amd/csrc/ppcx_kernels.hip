@@ -260,11 +260,7 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
     io.out.divergent = a.out_divergent ? a.out_divergent + (long)chain * a.iter : nullptr;
     io.out.accept = a.out_accept ? a.out_accept + (long)chain * a.iter : nullptr;
     Cmd nc;
-#ifndef PPCX_ABLATE_NOSTEP
     chain_step(WaveLanes{tid}, a.d, st, s_st.ta, s_ex, red, have_parts, VecRef{hv, 8}, io, s_rd, nc);
-#else
-    if (have_parts) nc = s_ex; else chain_step(WaveLanes{tid}, a.d, st, s_st.ta, s_ex, red, have_parts, VecRef{hv, 8}, io, s_rd, nc);
-#endif
     if (tid == 0) {
       s_st.sc = st;
       *nc_out = nc;
