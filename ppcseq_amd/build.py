@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppcx.so")
 SOURCES = ["ppcx_kernels.hip", "ppcx_capi.hip"]
-HEADERS = ["ppcx_math.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_kernels.h", os.path.join("..", "..", "include", "ppcx.h")]
+HEADERS = ["ppcx_math.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h", "ppcx_kernels.h", os.path.join("..", "..", "include", "ppcx.h")]
 
 
 def _stale() -> bool:

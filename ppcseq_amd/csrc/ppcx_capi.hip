@@ -35,7 +35,8 @@ struct ppcx_model {
   std::vector<double> X_host, expo_host;
   int* d_counts = nullptr;
   double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_ncell = nullptr, *d_Lg1 = nullptr;
-  LogTabEntry* d_logtab = nullptr;
+  double* d_logtab = nullptr;
+  int* d_order = nullptr;        // gene_order: position in the log-likelihood kernel's launch -> gene
   hipStream_t stream = nullptr;
 };
 
@@ -99,6 +100,25 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
     }
     Sy[g] = sy; SyE[g] = sye; ncell[g] = nc; Lg1[g] = lg1;
   }
+  // gene_order: the log-likelihood kernel picks its lgamma/digamma regime per wavefront from the smallest
+  // y + phi among its lanes (ppcx_model.h cell_eval), and runs the generic and the intercept-only cell paths one
+  // after the other when a wavefront holds genes of both kinds. So neighbours in the launch should be alike:
+  // genes with slopes first, then by smallest count -- the expensive wavefronts start first, the cheap ones fill the tail.
+  {
+    std::vector<int> ord(G), miny(G);
+    for (int g = 0; g < G; ++g) {
+      int mn = INT32_MAX;
+      for (int s = 0; s < S; ++s) { const int y = cnt[(size_t)g * S + s]; if (y >= 0 && y < mn) mn = y; }
+      miny[g] = mn; ord[g] = g;
+    }
+    const int K = m->d.K;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+      const bool sa = a < K && C >= 2, sb = b < K && C >= 2;
+      if (sa != sb) return sa;
+      return miny[a] < miny[b];
+    });
+    HIPCHK(hipMemcpy(m->d_order, ord.data(), sizeof(int) * (size_t)G, hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMemcpy(m->d_counts, cnt.data(), sizeof(int32_t) * cnt.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_Sy, Sy.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_SyE, SyE.data(), sizeof(double) * G, hipMemcpyHostToDevice));
@@ -147,8 +167,9 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   MHIP(hipMalloc(&m->d_SyX, sizeof(double) * (size_t)C * G));
   MHIP(hipMalloc(&m->d_ncell, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_Lg1, sizeof(double) * G));
-  MHIP(hipMalloc(&m->d_logtab, sizeof(LogTabEntry) * kLogTabSize));
-  { LogTabEntry tab[kLogTabSize]; fill_log_table(tab); MHIP(hipMemcpy(m->d_logtab, tab, sizeof(tab), hipMemcpyHostToDevice)); }
+  MHIP(hipMalloc(&m->d_logtab, sizeof(double) * 2 * kLogTabSize));
+  { double tab[2 * kLogTabSize]; fill_log_table(tab); MHIP(hipMemcpy(m->d_logtab, tab, sizeof(tab), hipMemcpyHostToDevice)); }
+  MHIP(hipMalloc(&m->d_order, sizeof(int) * (size_t)G));
   MHIP(hipMemcpy(m->d_E, E.data(), sizeof(double) * S, hipMemcpyHostToDevice));
   MHIP(hipMemcpy(m->d_expo, exposure, sizeof(double) * S, hipMemcpyHostToDevice));
   MHIP(hipMemcpy(m->d_X, X, sizeof(double) * (size_t)S * C, hipMemcpyHostToDevice));
@@ -182,7 +203,7 @@ extern "C" void ppcx_model_destroy(ppcx_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipFree(m->d_counts); (void)hipFree(m->d_E); (void)hipFree(m->d_expo); (void)hipFree(m->d_X);
-  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab);
+  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_order);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -278,7 +299,7 @@ static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
 static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
   LoglikArgs la;
   la.d = m->d; la.counts = m->d_counts; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
-  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab;
+  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order;
   hipError_t e = launch_loglik_kernel(m->L, m->CM, la, m->nblocks, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("loglik kernel: ") + hipGetErrorString(e));
   return PPCX_OK;

@@ -55,7 +55,7 @@ PPCX_HD void gene_consts(GeneCtx<CM>& x) {
 // the cells s = sub, sub+L, ... of the gene's row of counts. Excluded cells (count < 0) are skipped.
 template <int CM>
 PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, const double* sE, const double* sExpo,
-                        const double* sX, const LogTabEntry* tab, int sub, int L, CellAcc<CM>& acc) {
+                        const double* sX, const double* tab, int sub, int L, CellAcc<CM>& acc) {
   const int S = d.S, C = d.C;
   const GeneParams<CM>& gp = x.gp;
   if (!x.active) return;

@@ -15,7 +15,8 @@ struct LoglikArgs {
   long Dpad;
   const Cmd* cmds;              // [chains]
   double* sums;                 // [chains][5+CM][G]
-  const LogTabEntry* logtab;    // 128 entries (device)
+  const double* logtab;         // 2 x 256 doubles (device), ppcx_math.h table_log
+  const int* order;             // [G] launch position -> gene (host: gene_order)
 };
 
 struct CloseArgs {

@@ -40,12 +40,12 @@ __global__ __launch_bounds__(256, 4) void ppcx_loglik_kernel(LoglikArgs a) {
   if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
   const Dims& d = a.d;
   const int S = d.S, C = d.C;
-  LogTabEntry* stab = reinterpret_cast<LogTabEntry*>(lds);   // 128 x {1/c, log c}: 2 KB, 16-byte aligned at the LDS base
+  double* stab = lds;                          // log table: 256 x 1/c then 256 x log c (4 KB)
   double* sE = lds + 2 * kLogTabSize;          // exp(exposure_s)
   double* sExpo = sE + S;
   double* sX = sExpo + S;                      // S x C column-major
   const int tid = threadIdx.x;
-  for (int i = tid; i < kLogTabSize; i += 256) stab[i] = a.logtab[i];
+  for (int i = tid; i < 2 * kLogTabSize; i += 256) stab[i] = a.logtab[i];
   const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
   for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
   if (any_generic) {
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256, 4) void ppcx_loglik_kernel(LoglikArgs a) {
   const int ngroups = (d.G + GPW - 1) / GPW;
   for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
     GeneCtx<CM> x;
-    gene_load<CM>(d, c, v, grp * GPW + gl, x);
+    const int pos = grp * GPW + gl;
+    gene_load<CM>(d, c, v, pos < d.G ? a.order[pos] : d.G, x);
     gene_consts<CM>(x);
     CellAcc<CM> acc; acc.zero();
     gene_cells<CM>(d, x, a.counts + (long)x.gg * S, sE, sExpo, sX, stab, sub, L, acc);

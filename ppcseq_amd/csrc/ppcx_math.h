@@ -62,14 +62,16 @@ PPCX_HD double fast_log(double x) {
 
 // ---------------------------------------------------------------------------------------------
 // Table-driven fp64 logarithm for the cell loop (no division, no frexp, no selects): for x = 2^e m,
-// m in [1,2), the top 7 mantissa bits j pick c_j = 1 + (j + 1/2)/128; with r = m/c_j - 1 (one FMA with the
-// tabulated 1/c_j, |r| < 2^-8)  log x = e ln2 + log c_j + log1p(r), log1p by its degree-6 Taylor polynomial
-// (truncation < r^7/7 ~ 2e-18). The 128 x {1/c_j, log c_j} table (2 KB) lives in LDS on the device.
+// m in [1,2), the top 8 mantissa bits j pick c_j = 1 + (j + 1/2)/256; with r = m/c_j - 1 (one FMA with the
+// tabulated 1/c_j, |r| < 2^-9)  log x = e ln2 + log c_j + log1p(r), log1p by its degree-5 Taylor polynomial
+// (truncation < r^6/6 ~ 9e-18). The table is two arrays of 256 doubles, tab[j] = 1/c_j and tab[256 + j] =
+// log c_j (4 KB), in LDS on the device: two 8-byte reads, whose 64-bank mapping spreads the lanes' random j
+// over 32 bank pairs (one 16-byte {1/c, log c} read maps them to 8 bank quads and serialises 4-5 deep).
 // Valid for finite normal x > 0; inf/NaN inputs give finite garbage, which the callers catch through the
 // non-finite gradient that accompanies them (u = inf makes u/w NaN).
 // ---------------------------------------------------------------------------------------------
-struct LogTabEntry { double cinv, logc; };
-constexpr int kLogTabSize = 128;
+constexpr int kLogTabSize = 256;          // entries; the table holds 2 * kLogTabSize doubles
+constexpr int kLogTabBits = 8;
 
 PPCX_HD unsigned long long dbl_bits(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -85,26 +87,25 @@ PPCX_HD double bits_dbl(unsigned long long b) {
   double x; __builtin_memcpy(&x, &b, 8); return x;
 #endif
 }
-inline void fill_log_table(LogTabEntry* t) {          // host: exact-to-rounding entries
+inline void fill_log_table(double* t /* 2 * kLogTabSize */) {          // host: exact-to-rounding entries
   for (int j = 0; j < kLogTabSize; ++j) {
     const long double c = 1.0L + ((long double)j + 0.5L) / (long double)kLogTabSize;
-    t[j].cinv = (double)(1.0L / c);
-    t[j].logc = (double)logl(1.0L / (long double)t[j].cinv);   // log of the reciprocal actually stored
+    t[j] = (double)(1.0L / c);
+    t[kLogTabSize + j] = (double)logl(1.0L / (long double)t[j]);   // log of the reciprocal actually stored
   }
 }
-PPCX_HD double table_log(double x, const LogTabEntry* tab) {
+PPCX_HD double table_log(double x, const double* tab) {
   const unsigned long long b = dbl_bits(x);
   const int e = (int)(b >> 52) - 1023;
-  const int j = (int)(b >> 45) & (kLogTabSize - 1);
+  const int j = (int)(b >> (52 - kLogTabBits)) & (kLogTabSize - 1);
   const double m = bits_dbl((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
-  const LogTabEntry t = tab[j];
-  const double r = fma(m, t.cinv, -1.0);
-  double p = fma(r, -1.0 / 6.0, 0.2);
-  p = fma(r, p, -0.25);
+  const double cinv = tab[j], logc = tab[kLogTabSize + j];
+  const double r = fma(m, cinv, -1.0);
+  double p = fma(r, 0.2, -0.25);
   p = fma(r, p, 1.0 / 3.0);
   p = fma(r, p, -0.5);
   p = fma(r, p, 1.0);
-  return fma((double)e, 6.93147180559945286227e-01, fma(r, p, t.logc));
+  return fma((double)e, 6.93147180559945286227e-01, fma(r, p, logc));
 }
 
 // exp(x) for |x| < 700 by x = k ln2 + r, |r| <= ln2/2 and the rational form of Sun's fdlibm e_exp.c

@@ -103,10 +103,14 @@ struct CellAcc {
 #endif
 
 // One valid cell (y >= 0) once u = exp(t) is known. The per-lane work is free of selects and divisions in
-// the common case: the three regimes of the Stirling evaluation are chosen per WAVEFRONT (device) / per cell
-// (host emulation): every lane has y+phi >= 32 (4-term tails), every lane >= 8 (7-term tails), or some lane
-// needs the shift-by-8 recurrence. y == 0 contributes lgamma(phi) - lgamma(phi) = 0 up to rounding.
-PPCX_HD void cell_eval(int y, double u, double phi, double lgphi, double dgphi, const LogTabEntry* tab,
+// the common case: the three regimes of lgamma(y+phi) - lgamma(phi) and its digamma counterpart are chosen per
+// WAVEFRONT (device) / per cell (host emulation): every lane has y+phi >= 32 (4-term Stirling tails), every lane
+// >= 8 (7-term tails), or some lane has y+phi < 8. Such a lane has y <= 7, so the differences are the exact
+// recurrences  log prod_{k<y}(phi+k)  and  P'/P  -- no Stirling series, no cancellation; the other lanes of
+// that wavefront use the 7-term tails. Every regime costs one logarithm and one reciprocal per cell.
+// The host orders the genes by their smallest count (ppcx_capi.hip, gene_order) so that the lanes of a
+// wavefront mostly agree on the regime.
+PPCX_HD void cell_eval(int y, double u, double phi, double lgphi, double dgphi, const double* tab,
                        double* T1, double* SP, double* T3, double* T4, double* xsig) {
   const double x = (double)y + phi;
   const double w = 1.0 + u;
@@ -114,28 +118,35 @@ PPCX_HD void cell_eval(int y, double u, double phi, double lgphi, double dgphi, 
   *xsig = x * (u * fast_rcp(w));
   *T1 = fma(x, sp, *T1);
   *SP += sp;
-  double lg, dg;
+  double dl, dd;                 // lgamma(y+phi) - lgamma(phi), digamma(y+phi) - digamma(phi)
   if (PPCX_WAVE_ALL(x >= 32.0)) {
+    double lg, dg;
     lgamma_digamma_stirling4(x, table_log(x, tab), fast_rcp(x), &lg, &dg);
+    dl = lg - lgphi; dd = dg - dgphi;
   } else if (PPCX_WAVE_ALL(x >= 8.0)) {
+    double lg, dg;
     lgamma_digamma_stirling(x, table_log(x, tab), fast_rcp(x), &lg, &dg);
+    dl = lg - lgphi; dd = dg - dgphi;
   } else {
-    const bool big = x >= 8.0;
-    const double xe = big ? x : x + 8.0;
-    lgamma_digamma_stirling(xe, table_log(xe, tab), fast_rcp(xe), &lg, &dg);
-    double P = x, dP = 1.0;
+    const bool small = x < 8.0;
+    double P = 1.0, dP = 0.0;    // P = prod_{k<y}(phi+k), dP = dP/dphi  (y = 0: P = 1, dP = 0)
 #pragma unroll
-    for (int k = 1; k < 8; ++k) {
-      const double f = x + (double)k;
-      dP = fma(dP, f, P);
-      P = P * f;
+    for (int k = 0; k < 7; ++k) {
+      if (small && k < y) {
+        const double f = phi + (double)k;
+        dP = fma(dP, f, P);
+        P = P * f;
+      }
     }
-    const double lP = table_log(P, tab), qP = dP * fast_rcp(P);
-    lg -= big ? 0.0 : lP;
-    dg -= big ? 0.0 : qP;
+    const double arg = small ? P : x;
+    const double la = table_log(arg, tab), ra = fast_rcp(arg);
+    double lg, dg;
+    lgamma_digamma_stirling(x, la, ra, &lg, &dg);        // meaningful for the lanes with x >= 8 only
+    dl = small ? la : lg - lgphi;
+    dd = small ? dP * ra : dg - dgphi;
   }
-  *T3 += lg - lgphi;
-  *T4 += dg - dgphi;
+  *T3 += dl;
+  *T4 += dd;
 }
 
 // everything a gene's lanes need that does not depend on the sample

@@ -10,7 +10,7 @@
 
 using namespace ppcx;
 
-static const LogTabEntry* log_table() { static LogTabEntry t[kLogTabSize]; static bool init = false; if (!init) { fill_log_table(t); init = true; } return t; }
+static const double* log_table() { static double t[2 * kLogTabSize]; static bool init = false; if (!init) { fill_log_table(t); init = true; } return t; }
 
 struct EmulModel {
   Dims d; int CM;
