@@ -478,7 +478,7 @@ extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, 
 // same work.
 extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs, int reps, int n_merge,
                                       double* ms_per_launch, int* cmd_type) {
-  const int which = n_merge >= 100 ? (n_merge / 100) : 0;      // 0 loglik, 1 close, 2 both, 3 update (development aid)
+  const int which = n_merge >= 100 ? (n_merge / 100) : 0;      // 0 loglik, 1 close, 2 both, 3 step, 4 update, 5 step:reduce, 6 step:advance (development aid)
   if (n_merge >= 100) n_merge %= 100;
   if (!m || nchains < 1 || reps < 1 || !ms_per_launch) return fail(PPCX_ERR_ARG, "bad arguments");
   HIPCHK(hipSetDevice(m->device));
@@ -515,7 +515,7 @@ extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) if ((rc = (which == 1 ? launch_close(m, w, nchains) : (which == 2 ? launch_gene(m, w, nchains) : (which == 3 ? launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE) : (which == 4 ? launch_update(m, w, nchains, io) : launch_loglik(m, w, nchains)))))) != PPCX_OK) return rc;
+  for (int i = 0; i < reps; ++i) if ((rc = (which == 1 ? launch_close(m, w, nchains) : (which == 2 ? launch_gene(m, w, nchains) : (which == 3 ? launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE) : (which == 4 ? launch_update(m, w, nchains, io) : (which == 5 ? launch_step(m, w, nchains, io, STEP_REDUCE) : (which == 6 ? launch_step(m, w, nchains, io, STEP_ADVANCE) : launch_loglik(m, w, nchains)))))))) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));

@@ -7,6 +7,10 @@
 #pragma once
 #include "ppcx_nuts.h"
 
+#ifndef PPCX_PREFETCH
+#define PPCX_PREFETCH 1
+#endif
+
 namespace ppcx {
 
 template <int CM>
@@ -60,6 +64,24 @@ PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, con
   const GeneParams<CM>& gp = x.gp;
   if (!x.active) return;
   if (x.fast) {
+#if PPCX_PREFETCH
+    // the count and the sample constant of the next cell are requested before this cell is evaluated
+    int s = sub;
+    int yn = s < S ? row[s] : -1;
+    double en = s < S ? sE[s] : 0.0;
+    while (s < S) {
+      const int y = yn;
+      const double e = en;
+      const int s2 = s + L;
+      if (s2 < S) { yn = row[s2]; en = sE[s2]; }
+      if (y >= 0) {
+        double xsig;
+        cell_eval(y, e * gp.A, gp.phi, gp.lgphi, gp.dgphi, tab, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
+        acc.T2u += xsig;
+      }
+      s = s2;
+    }
+#else
     for (int s = sub; s < S; s += L) {
       const int y = row[s];
       if (y >= 0) {
@@ -68,6 +90,7 @@ PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, con
         acc.T2u += xsig;
       }
     }
+#endif
   } else {
     for (int s = sub; s < S; s += L) {
       const int y = row[s];

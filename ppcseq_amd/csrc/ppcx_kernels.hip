@@ -30,8 +30,11 @@ __device__ __forceinline__ double wave_xor_add(double v, int mask) { return v + 
 // T1 = sum x log w, SP = sum log w, T2u = sum x u/w, T3 = sum [lgamma(y+phi) - lgamma(phi)],
 // T4 = sum [psi(y+phi) - psi(phi)] (+ T2x[c] = sum X_sc x u/w for genes with slopes).
 // -----------------------------------------------------------------------------------------------------
+#ifndef PPCX_LOGLIK_OCC
+#define PPCX_LOGLIK_OCC 4
+#endif
 template <int L, int CM>
-__global__ __launch_bounds__(256, 4) void ppcx_loglik_kernel(LoglikArgs a) {
+__global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(LoglikArgs a) {
   constexpr int GPW = 64 / L;                 // genes per wavefront
   constexpr int NS = GeneSums<CM>::N;
   extern __shared__ double lds[];
