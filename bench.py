@@ -40,7 +40,7 @@ def main():
                     help="chains: BASELINE cfg3, chains partitioned over GPUs (default, weak scaling); shards: BASELINE cfg4 style, "
                          "genes partitioned over GPUs with an RCCL all-reduce of the partial sums every leapfrog (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
     import torch

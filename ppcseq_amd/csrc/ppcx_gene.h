@@ -51,8 +51,8 @@ PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, Gene
 }
 // the per-gene constants of the cell loop
 template <int CM>
-PPCX_HD void gene_consts(GeneCtx<CM>& x) {
-  lgamma_digamma(x.gp.phi, &x.gp.lgphi, &x.gp.dgphi);
+PPCX_HD void gene_consts(GeneCtx<CM>& x, const double* tab) {
+  lgamma_digamma_tab(x.gp.phi, tab, &x.gp.lgphi, &x.gp.dgphi);
   x.gp.A = fast_exp(x.gp.coef[0] + x.gp.sigma_raw);
 }
 

@@ -48,6 +48,14 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
   double* sExpo = sE + S;
   double* sX = sExpo + S;                      // S x C column-major
   const int tid = threadIdx.x;
+  const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
+  double* sums = a.sums + (long)chain * NS * d.G;
+  const int wave = tid >> 6, lane = tid & 63, sub = lane % L, gl = lane / L;
+  const int ngroups = (d.G + GPW - 1) / GPW;
+  int grp = blockIdx.x * 4 + wave;
+  GeneCtx<CM> x;
+  // the first group's coordinates are requested before the LDS fill, so that the two round trips overlap
+  if (grp < ngroups) { const int pos = grp * GPW + gl; gene_load<CM>(d, c, v, pos < d.G ? a.order[pos] : d.G, x); }
   for (int i = tid; i < 2 * kLogTabSize; i += 256) stab[i] = a.logtab[i];
   const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
   for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
@@ -56,15 +64,9 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
     for (int i = tid; i < S * C; i += 256) sX[i] = a.X[i];
   }
   __syncthreads();
-  const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
-  double* sums = a.sums + (long)chain * NS * d.G;
-  const int wave = tid >> 6, lane = tid & 63, sub = lane % L, gl = lane / L;
-  const int ngroups = (d.G + GPW - 1) / GPW;
-  for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
-    GeneCtx<CM> x;
-    const int pos = grp * GPW + gl;
-    gene_load<CM>(d, c, v, pos < d.G ? a.order[pos] : d.G, x);
-    gene_consts<CM>(x);
+  for (; grp < ngroups; grp += gridDim.x * 4) {
+    if (grp != blockIdx.x * 4 + wave) { const int pos = grp * GPW + gl; gene_load<CM>(d, c, v, pos < d.G ? a.order[pos] : d.G, x); }
+    gene_consts<CM>(x, stab);
     CellAcc<CM> acc; acc.zero();
     gene_cells<CM>(d, x, a.counts + (long)x.gg * S, sE, sExpo, sX, stab, sub, L, acc);
     // L-lane butterfly: every lane of the gene ends with the gene totals

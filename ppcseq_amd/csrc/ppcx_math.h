@@ -187,6 +187,26 @@ PPCX_HD void lgamma_digamma(double x, double* lg, double* dg) {
   }
 }
 
+// the same with the table-driven logarithm (normal finite x > 0; the product of the shift stays normal for x > 1e-300)
+PPCX_HD void lgamma_digamma_tab(double x, const double* tab, double* lg, double* dg) {
+  if (x >= 8.0) {
+    lgamma_digamma_stirling(x, table_log(x, tab), fast_rcp(x), lg, dg);
+  } else {
+    double P = x, dP = 1.0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const double f = x + (double)k;
+      dP = dP * f + P;
+      P = P * f;
+    }
+    const double xs = x + 8.0;
+    double l8, d8;
+    lgamma_digamma_stirling(xs, table_log(xs, tab), fast_rcp(xs), &l8, &d8);
+    *lg = l8 - table_log(P, tab);
+    *dg = d8 - dP * fast_rcp(P);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // log erfc(x) and  R(x) = exp(-x^2)/erfc(x)  (the inverse Mills-type ratio the skew-normal
 // gradient needs). Written as Stan Math's skew_normal_lpdf evaluates it -- log(erfc(.)) directly --

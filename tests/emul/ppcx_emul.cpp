@@ -45,7 +45,7 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
     // log-likelihood kernel (one lane per gene here)
     GeneCtx<CM> x;
     gene_load<CM>(d, c, v, g, x);
-    gene_consts<CM>(x);
+    gene_consts<CM>(x, log_table());
     CellAcc<CM> acc; acc.zero();
     gene_cells<CM>(d, x, m.counts.data() + (size_t)g * d.S, m.E.data(), m.expo.data(), m.X.data(), log_table(), 0, 1, acc);
     // close kernel
