@@ -17,6 +17,7 @@ struct LoglikArgs {
   double* sums;                 // [chains][5+CM][G]
   const double* logtab;         // 2 x 256 doubles (device), ppcx_math.h table_log
   const int* order;             // [G] launch position -> gene (host: gene_order)
+  int gene_blocks;              // workgroups per chain (set by the launcher; the grid is padded to a multiple of 8)
 };
 
 struct CloseArgs {

@@ -38,7 +38,14 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
   constexpr int GPW = 64 / L;                 // genes per wavefront
   constexpr int NS = GeneSums<CM>::N;
   extern __shared__ double lds[];
-  const int chain = blockIdx.y;
+  // grid = (chains, gene blocks): the chain is the fast index, so the dispatch order is the host's gene order
+  // (expensive genes first) for all chains together, and the tail of the launch consists of cheap workgroups
+  // and workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids c*8 + (gblock & 7) inside every run
+  // of 8 gene blocks x chains put the chains of one gene block on ONE XCD, so its L2 fetches the rows once
+  const int nch = gridDim.x, ngblocks = a.gene_blocks;
+  const int lin = blockIdx.y * nch + blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
+  const int chain = r >> 3, gblock = run * 8 + (r & 7);
+  if (gblock >= ngblocks) return;
   const Cmd& c = a.cmds[chain];
   if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
   const Dims& d = a.d;
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
   double* sums = a.sums + (long)chain * NS * d.G;
   const int wave = tid >> 6, lane = tid & 63, sub = lane % L, gl = lane / L;
   const int ngroups = (d.G + GPW - 1) / GPW;
-  int grp = blockIdx.x * 4 + wave;
+  int grp = gblock * 4 + wave;
   GeneCtx<CM> x;
   // the first group's coordinates are requested before the LDS fill, so that the two round trips overlap
   if (grp < ngroups) { const int pos = grp * GPW + gl; gene_load<CM>(d, c, v, pos < d.G ? a.order[pos] : d.G, x); }
@@ -64,8 +71,8 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
     for (int i = tid; i < S * C; i += 256) sX[i] = a.X[i];
   }
   __syncthreads();
-  for (; grp < ngroups; grp += gridDim.x * 4) {
-    if (grp != blockIdx.x * 4 + wave) { const int pos = grp * GPW + gl; gene_load<CM>(d, c, v, pos < d.G ? a.order[pos] : d.G, x); }
+  for (; grp < ngroups; grp += ngblocks * 4) {
+    if (grp != gblock * 4 + wave) { const int pos = grp * GPW + gl; gene_load<CM>(d, c, v, pos < d.G ? a.order[pos] : d.G, x); }
     gene_consts<CM>(x, stab);
     CellAcc<CM> acc; acc.zero();
     gene_cells<CM>(d, x, a.counts + (long)x.gg * S, sE, sExpo, sX, stab, sub, L, acc);
@@ -516,10 +523,11 @@ static hipError_t launch_loglik_l(int L, const LoglikArgs& a, dim3 grid, size_t 
 }
 hipError_t launch_loglik_kernel(int L, int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st) {
   const size_t lds_bytes = sizeof(double) * (2 * kLogTabSize + (size_t)a.d.S * (2 + a.d.C));
-  const dim3 grid(nblocks, nchains);
-  if (CM <= 2) return launch_loglik_l<2>(L, a, grid, lds_bytes, st);
-  if (CM <= 4) return launch_loglik_l<4>(L, a, grid, lds_bytes, st);
-  return launch_loglik_l<8>(L, a, grid, lds_bytes, st);
+  LoglikArgs b = a; b.gene_blocks = nblocks;
+  const dim3 grid(nchains, (nblocks + 7) / 8 * 8);
+  if (CM <= 2) return launch_loglik_l<2>(L, b, grid, lds_bytes, st);
+  if (CM <= 4) return launch_loglik_l<4>(L, b, grid, lds_bytes, st);
+  return launch_loglik_l<8>(L, b, grid, lds_bytes, st);
 }
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st) {
   const dim3 grid(nblocks, nchains);
