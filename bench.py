@@ -229,7 +229,8 @@ def outlier_concordance():
             "cells": int(g.ppc.size), "ppc_identical": same_ppc, "deleterious_outliers_identical": same_del,
             "gpu_tot_deleterious": [int(v) for v in g.deleterious_outliers.sum(1)],
             "cpu_tot_deleterious": [int(v) for v in o.deleterious_outliers.sum(1)],
-            "max_upper_ci_rel_diff": float(np.max(np.abs(g.upper - o.upper) / (1 + o.upper)))}
+            "max_upper_ci_rel_diff": float(np.max(np.abs(g.upper - o.upper) / (1 + o.upper))),
+            "median_upper_ci_rel_diff": float(np.median(np.abs(g.upper - o.upper) / (1 + o.upper)))}
 
 
 def cpu_baseline(arrays, K, gpu_ess, gpu_grad, args):

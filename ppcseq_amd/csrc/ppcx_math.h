@@ -88,17 +88,22 @@ PPCX_HD double bits_dbl(unsigned long long b) {
 #endif
 }
 inline void fill_log_table(double* t /* 2 * kLogTabSize */) {          // host: exact-to-rounding entries
+  // entries for the mantissa m' = frexp(x) in [1/2, 1):  t[j] = 2/c_j (so r = m' t[j] - 1), t[256 + j] = log(1/t[j]) = log(c_j/2)
   for (int j = 0; j < kLogTabSize; ++j) {
     const long double c = 1.0L + ((long double)j + 0.5L) / (long double)kLogTabSize;
-    t[j] = (double)(1.0L / c);
+    t[j] = (double)(2.0L / c);
     t[kLogTabSize + j] = (double)logl(1.0L / (long double)t[j]);   // log of the reciprocal actually stored
   }
 }
 PPCX_HD double table_log(double x, const double* tab) {
-  const unsigned long long b = dbl_bits(x);
-  const int e = (int)(b >> 52) - 1023;
-  const int j = (int)(b >> (52 - kLogTabBits)) & (kLogTabSize - 1);
-  const double m = bits_dbl((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+  const int j = (int)(dbl_bits(x) >> (52 - kLogTabBits)) & (kLogTabSize - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double m = __builtin_amdgcn_frexp_mant(x);      // v_frexp_mant_f64 / v_frexp_exp_i32_f64: [1/2, 1) x 2^e
+  const int e = __builtin_amdgcn_frexp_exp(x);
+#else
+  int e;
+  const double m = frexp(x, &e);
+#endif
   const double cinv = tab[j], logc = tab[kLogTabSize + j];
   const double r = fma(m, cinv, -1.0);
   double p = fma(r, 0.2, -0.25);

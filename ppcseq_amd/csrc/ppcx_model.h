@@ -115,17 +115,21 @@ PPCX_HD void cell_eval(int y, double u, double phi, double lgphi, double dgphi, 
   const double x = (double)y + phi;
   const double w = 1.0 + u;
   const double sp = table_log(w, tab);
-  *xsig = x * (u * fast_rcp(w));
   *T1 = fma(x, sp, *T1);
   *SP += sp;
   double dl, dd;                 // lgamma(y+phi) - lgamma(phi), digamma(y+phi) - digamma(phi)
+  // 1/w and 1/arg from ONE hardware reciprocal: q = 1/(w arg), 1/w = q arg, 1/arg = q w (v_rcp_f64 is quarter rate)
   if (PPCX_WAVE_ALL(x >= 32.0)) {
+    const double q = fast_rcp(w * x), rx = q * w;
+    *xsig = x * (u * (q * x));
     double lg, dg;
-    lgamma_digamma_stirling4(x, table_log(x, tab), fast_rcp(x), &lg, &dg);
+    lgamma_digamma_stirling4(x, table_log(x, tab), rx, &lg, &dg);
     dl = lg - lgphi; dd = dg - dgphi;
   } else if (PPCX_WAVE_ALL(x >= 8.0)) {
+    const double q = fast_rcp(w * x), rx = q * w;
+    *xsig = x * (u * (q * x));
     double lg, dg;
-    lgamma_digamma_stirling(x, table_log(x, tab), fast_rcp(x), &lg, &dg);
+    lgamma_digamma_stirling(x, table_log(x, tab), rx, &lg, &dg);
     dl = lg - lgphi; dd = dg - dgphi;
   } else {
     const bool small = x < 8.0;
@@ -139,7 +143,9 @@ PPCX_HD void cell_eval(int y, double u, double phi, double lgphi, double dgphi, 
       }
     }
     const double arg = small ? P : x;
-    const double la = table_log(arg, tab), ra = fast_rcp(arg);
+    const double q = fast_rcp(w * arg), ra = q * w;
+    *xsig = x * (u * (q * arg));
+    const double la = table_log(arg, tab);
     double lg, dg;
     lgamma_digamma_stirling(x, la, ra, &lg, &dg);        // meaningful for the lanes with x >= 8 only
     dl = small ? la : lg - lgphi;
