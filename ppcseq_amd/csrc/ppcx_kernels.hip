@@ -195,36 +195,57 @@ struct WaveLanes {                              // cooperating lanes 0..7 of one
 };
 
 __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
-  __shared__ double sm[8][32];
+  __shared__ double sm[3][8][32];
   __shared__ double sT0[256];
   __shared__ double red[PT_COUNT];
   __shared__ double hv[V_COUNT * 8];           // the six hyper coordinates of every per-coordinate vector
   __shared__ Cmd s_ex;
   __shared__ ChainState s_st;
   __shared__ Reduced s_rd;
+  constexpr int NST = (int)(sizeof(ChainState) / sizeof(int)), NCMD = (int)(sizeof(Cmd) / sizeof(int)), NHV = V_COUNT * 8;
+  static_assert(NST <= 4 * 256 && NCMD <= 256 && NHV <= 2 * 256 && PT_COUNT <= 96, "step kernel staging sizes");
   const int chain = blockIdx.x, tid = threadIdx.x;
   const ChainState* st_in = a.states_in + chain;
   const bool done = st_in->sc.phase == PH_DONE;
   double* rg = a.red + (long)chain * PT_COUNT;
+  // the chain's command, state and hyper vectors are requested now and parked in registers, so that their round trip
+  // overlaps the reduction below
+  int r_st[4], r_cmd = 0; double r_hv[2];
+  {
+    const int* s2 = reinterpret_cast<const int*>(st_in);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r_st[k] = tid + 256 * k < NST ? s2[tid + 256 * k] : 0;
+    if (tid < NCMD) r_cmd = reinterpret_cast<const int*>(a.cmds_in + chain)[tid];
+    const double* hvg = a.hyper_in + (long)chain * NHV;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) r_hv[k] = tid + 256 * k < NHV ? hvg[tid + 256 * k] : 0.0;
+  }
   if (a.phases & STEP_REDUCE) {
     const Cmd& exg = a.cmds_in[chain];
     const int np = (done || exg.type == CMD_DONE || exg.type == CMD_FLUSH) ? 0 : parts_used(exg);
     const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
-    for (int i = tid; i < PT_COUNT; i += 256) red[i] = 0.0;
-    __syncthreads();
-    for (int v0 = 0; v0 < np; v0 += 32) {        // only the sums this command produced (np is uniform)
-      const int vv = v0 + (tid & 31), ch = tid >> 5;
-      double s = 0.0;
-      if (vv < np) for (int b = ch; b < a.nblocks_close; b += 8) s += slab[(long)b * PT_COUNT + vv];
-      sm[ch][tid & 31] = s;
-      __syncthreads();
-      if (tid < 32 && v0 + tid < np) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += sm[k][tid];
-        if (v0 + tid != PT_T0) red[v0 + tid] = t;
+    // one pass: thread (c, ch) sums rows ch, ch+8, ... of columns c, c+32, c+64 (only the sums this command produced;
+    // np is uniform), loads of several rows in flight; then column v = sum over the eight row groups in a fixed order
+    {
+      const int c = tid & 31, ch = tid >> 5;
+      const bool u0 = c < np, u1 = c + 32 < np, u2 = c + 64 < np;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+      for (int b = ch; b < a.nblocks_close; b += 8) {
+        const double* row = slab + (long)b * PT_COUNT;
+        const double v0 = u0 ? row[c] : 0.0, v1 = u1 ? row[c + 32] : 0.0, v2 = u2 ? row[c + 64] : 0.0;
+        s0 += v0; s1 += v1; s2 += v2;
       }
-      __syncthreads();
+      sm[0][ch][c] = s0; sm[1][ch][c] = s1; sm[2][ch][c] = s2;
+    }
+    __syncthreads();
+    if (tid < PT_COUNT) {
+      double t = 0.0;
+      if (tid < np && tid != PT_T0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[tid >> 5][k][tid & 31];
+      }
+      red[tid] = t;
     }
     // kinetic energy of freshly drawn momenta: only commands that drew momenta left something in the T0 slab
     const bool fresh = !done && (exg.pre_flags & (PRE_NEW_TRANSITION | PRE_EPS_TRY)) != 0;
@@ -252,12 +273,12 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
     return;
   }
   {
-    const int* src = reinterpret_cast<const int*>(a.cmds_in + chain); int* dst = reinterpret_cast<int*>(&s_ex);
-    for (int i = tid; i < (int)(sizeof(Cmd) / sizeof(int)); i += 256) dst[i] = src[i];
-    const int* s2 = reinterpret_cast<const int*>(st_in); int* d2 = reinterpret_cast<int*>(&s_st);
-    for (int i = tid; i < (int)(sizeof(ChainState) / sizeof(int)); i += 256) d2[i] = s2[i];
-    const double* hvg = a.hyper_in + (long)chain * V_COUNT * 8;
-    for (int i = tid; i < V_COUNT * 8; i += 256) hv[i] = hvg[i];
+    int* d2 = reinterpret_cast<int*>(&s_st);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (tid + 256 * k < NST) d2[tid + 256 * k] = r_st[k];
+    if (tid < NCMD) reinterpret_cast<int*>(&s_ex)[tid] = r_cmd;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) if (tid + 256 * k < NHV) hv[tid + 256 * k] = r_hv[k];
   }
   __syncthreads();
   const bool have_parts = s_st.sc.phase != PH_START;
