@@ -157,7 +157,7 @@ def main():
                 b_grad = b_grad / world              # each rank streams its share of the genes
             achieved = b_grad * chains_per_launch / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "ppcx_loglik_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(chains_per_launch),
                     "algorithmic_bytes_per_launch": b_grad * chains_per_launch, "avg_launch_ms": round(ms, 5),
                     "timed_launches": int(kA_n)}
         cpu = None
@@ -190,6 +190,25 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(chains_per_launch):
+    """HBM-side bytes per launch of the log-likelihood kernel from the latest committed PMC passes (profiles/rNN_pmc.json,
+    written by scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs). PMC counters
+    cannot be read inside this process, so the figure belongs to the profiled run of this same command; it is reported
+    only when that run had the same number of chains per launch, else null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fh:
+            p = json.load(fh)
+        if int(p.get("chains_per_launch", 0)) != int(round(chains_per_launch)):
+            return None
+        return round((p["fetch_size_kib_per_launch"] + p["write_size_kib_per_launch"]) * 1024.0, 1)
+    except Exception:
+        return None
 
 
 def outlier_concordance():

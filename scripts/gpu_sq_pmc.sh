@@ -12,12 +12,12 @@ for i in $PASSES; do
   rocprofv3 --pmc ${P[$i]} --kernel-trace --output-format csv -d $OUT/p$i -- python3 scripts/gpu_kbench.py > $OUT/p$i.log 2> $OUT/p$i.err || echo "pass $i failed"
 done
 python3 - $OUT <<'PY'
-import csv, glob, collections, sys
+import csv, glob, collections, sys, os
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "loglik" not in row.get("Kernel_Name", ""): continue
+        if os.environ.get("KERNEL", "loglik") not in row.get("Kernel_Name", ""): continue
         a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
 with open(out + "/summary.txt", "w") as o:
     for k, (s, n) in sorted(acc.items()):
