@@ -57,25 +57,29 @@ extern "C" int ppcx_version(void) { return 100; }
 extern "C" int ppcx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" const char* ppcx_last_error(void) { return g_err.c_str(); }
 
-// choose lanes-per-gene L and blocks per chain: maximise (lane utilisation) x (SIMD balance)
+// choose lanes-per-gene L and workgroups per chain: minimise (duration of one wavefront) x (rounds of resident
+// wavefronts the launch needs). A wavefront executes ~350 instructions of per-gene overhead plus, per cell of a lane,
+// ~85 and ~2 more per doubling of the genes that share the wavefront (they must agree on the lgamma regime) -- the
+// measured instruction counts of the kernel (SQ_INSTS_VALU vs S, profiles/). 1024 SIMDs x 4 resident wavefronts make a
+// round; a launch that does not fill one takes a wavefront's duration whatever L is, and because workgroups leave and
+// enter one by one a partly filled last round costs about half of what strict rounds would.
 static void choose_launch(ppcx_model* m, int nchains) {
   const int G = m->d.G, S = m->d.S;
-  const double slots = 1024.0;                 // SIMDs: waves are spread evenly when they are all resident
-  int bestL = 64; double best = -1.0;
+  const double slots = 4096.0;
+  int bestL = 64; double best = 1e300;
   for (int L = 1; L <= 64; L <<= 1) {
     const int iters = (S + L - 1) / L;
-    const double util = (double)S / ((double)iters * L);
-    const double waves = ceil((double)G * L / 64.0) * nchains;
-    const double bal = waves / (ceil(waves / slots) * slots);
-    const double coal = 1.0 + 0.01 * log2((double)L);    // mild preference for wider contiguous reads
-    const double score = util * bal * coal;
-    if (score > best) { best = score; bestL = L; }
+    const double wave_time = 350.0 + iters * (85.0 + 2.0 * log2(64.0 / L));
+    const double rounds = ceil((double)G * L / 64.0) * nchains / slots;
+    const double eff_rounds = rounds <= 1.0 ? 1.0 : 0.5 * rounds + 0.5 * ceil(rounds);
+    const double t = wave_time * eff_rounds;
+    if (t < best) { best = t; bestL = L; }
   }
   m->L = m->L_override > 0 ? m->L_override : bestL;
   const int gpw = 64 / m->L;
   const int ngroups = (G + gpw - 1) / gpw;
   int r = m->gpw_override > 0 ? m->gpw_override : 1;
-  const int cap = 640;
+  const int cap = 65528;                       // grid.y limit (the launcher pads to a multiple of 8)
   int nb = (ngroups + 4 * r - 1) / (4 * r);
   while (nb > cap) { ++r; nb = (ngroups + 4 * r - 1) / (4 * r); }
   m->groups_per_wave = r;
