@@ -27,6 +27,35 @@ def test_density_and_gradient(oracle, emul, G, S, C, K, seed):
     assert np.max(np.abs(g - g2) / (1 + np.abs(g))) < 1e-10
 
 
+def _low_count_case(seed):
+    """Counts 0..40 around the regime boundaries of the cell loop (y + phi < 8: exact recurrences; < 32: 7-term tails;
+    else 4-term) with phi from 0.01 to 100, some rows all zero, some cells excluded."""
+    rng = np.random.default_rng(seed)
+    G, S, K = 48, 23, 6
+    counts = rng.poisson(rng.choice([0.3, 2.0, 6.0, 9.0, 30.0], size=(G, 1)), size=(G, S)).astype(np.int32)
+    counts[5] = 0
+    counts[7, :] = 7
+    counts[8, :] = 8
+    X = np.stack([np.ones(S), (np.arange(S) % 2).astype(float)], axis=1)
+    expo = rng.normal(0, 0.2, S)
+    D = 2 * G + K + 6
+    u = rng.uniform(-1, 1, D)
+    u[3:3 + G] = np.log(counts.mean(1) + 0.5) + rng.normal(0, 0.3, G)
+    u[3 + G + K:3 + G + K + G] = rng.uniform(-4.6, 4.6, G)          # sigma_raw: phi = exp(-sigma_raw) in (0.01, 100)
+    excl = np.array([3, 5 * S + 1, 7 * S, 8 * S + 2], dtype=np.int32)
+    return counts, X, expo, K, u, excl
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_low_counts_across_the_lgamma_regimes(oracle, emul, seed):
+    counts, X, expo, K, u, excl = _low_count_case(seed)
+    m = oracle.model(counts, X, expo, K, excl=excl)
+    lp, g = oracle.log_prob_grad(m, u)
+    lp2, g2 = emul_lp(emul, counts, X, expo, K, u, excl)
+    assert abs(lp2 - lp) <= 1e-11 * max(1.0, abs(lp))
+    assert np.max(np.abs(g - g2) / (1 + np.abs(g))) < 1e-10
+
+
 def test_design_without_unit_intercept_column(oracle, emul):
     """X[,1] != 1 disables the E_s * A_g factorisation: the generic per-cell exp path must agree too."""
     d = ind.synth(10, 6, K=3, seed=2, C=2)

@@ -54,6 +54,25 @@ def test_log_prob_grad_matches_oracle(L, oracle, G, S, C, K, seed):
         m.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_low_counts_across_the_lgamma_regimes(L, oracle, seed):
+    """Counts around the regime boundaries of the cell loop (y + phi < 8 / < 32 / >= 32), phi from 0.01 to 100,
+    all-zero rows, excluded cells: the wavefront-level regime choice and the exact recurrences for y <= 7."""
+    from tests.test_emul_vs_oracle import _low_count_case
+    counts, X, expo, K, u, excl = _low_count_case(seed)
+    mo = oracle.model(counts, X, expo, K, excl=excl)
+    lp, g = oracle.log_prob_grad(mo, u)
+    m = L.Model(counts, X, expo, K, excl=excl)
+    try:
+        for lanes in (0, 1, 8, 64):
+            m.set_launch(lanes, 0)
+            lp2, g2 = m.log_prob_grad(u[None, :])
+            assert abs(lp2[0] - lp) <= 1e-11 * max(1.0, abs(lp)), lanes
+            assert np.max(np.abs(g - g2[0]) / (1 + np.abs(g))) < 1e-10, lanes
+    finally:
+        m.close()
+
+
 def test_extreme_counts_zero_rows_and_generic_design(L, oracle):
     """Zeros, the bundled maximum 2,580,228, an all-zero gene, and a design whose first column is not 1
     (no E_s*A_g factorisation)."""
