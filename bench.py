@@ -92,6 +92,7 @@ def main():
     if args.lanes or args.groups_per_wave:
         model.set_launch(args.lanes, args.groups_per_wave)
     Dm = model.D
+    model_G = (g1 - g0) if args.mode == "shards" else G
     hyper_cols = [0, 1, 2, Dm - 3, Dm - 2, Dm - 1]
     nch = args.chains_per_gpu
     n_iter = args.nuts_warmup + args.draws_per_chain
@@ -135,6 +136,11 @@ def main():
             lp = D.all_gather_chains(lp, device=dev)
             ge = D.all_gather_chains(ge, device=dev)
         per = [ess_bulk(hyp[:, :, j]) for j in range(6)] + [ess_bulk(lp)]
+        # also the median over gene-level parameters (a sample of 128 intercepts and 128 sigma_raw; this rank's chains)
+        gsel = np.unique(np.linspace(0, model_G - 1, 128).astype(int))
+        gcols = [3 + int(g) for g in gsel] + [Dm - 3 - model_G + int(g) for g in gsel]
+        gene_draws = fit.columns(gcols)
+        ess_gene_median = float(np.median([ess_bulk(gene_draws[:, :, j]) for j in range(gene_draws.shape[2])]))
         tot_ess += float(np.nanmin(per))
         ess_detail = per
         tot_time += dt
@@ -177,6 +183,7 @@ def main():
                        "mode": args.mode, "chains_total": nch * world if args.mode == "chains" else nch, "lanes_per_gene": model.get_launch()[0], "blocks_per_chain": model.get_launch()[1],
                        "ess_estimator": "rank-normalised split-chain bulk-ESS, min over 6 hyper-parameters and lp__",
                        "ess_last_step": [round(float(x), 1) for x in ess_detail],
+                       "ess_median_intercept_sigma_raw_rank0_chains": round(ess_gene_median, 1),
                        "grad_evals": tot_grad, "mean_treedepth": round(float(np.mean(depth_mean)), 2),
                        "divergent_after_warmup": div_total,
                        "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
