@@ -1019,8 +1019,8 @@ extern "C" int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double 
   if (m->d.K < 1) return PPCX_OK;
   if (n_gen <= 0) n_gen = (int)n_draws;
   if (!resample && n_gen > n_draws) return fail(PPCX_ERR_ARG, "n_gen exceeds the kept draws (use resample)");
-  int n_pad = 2; while (n_pad < n_gen) n_pad <<= 1;
-  if (n_pad > 32768) return fail(PPCX_ERR_LIMIT, "more than 32768 predictive draws per cell: use the approximated analysis with fewer draws");
+  // a cell's draws live in LDS (160 KB per CU; 2 KB of it is the kernel's static scratch)
+  if (n_gen > 39936) return fail(PPCX_ERR_LIMIT, "more than 39936 predictive draws per cell: use the approximated analysis with fewer draws");
   if (!(p_lo >= 0.0 && p_hi <= 1.0 && p_lo <= p_hi)) return fail(PPCX_ERR_ARG, "need 0 <= p_lo <= p_hi <= 1");
   HIPCHK(hipSetDevice(m->device));
   const int n_cells = m->d.K * m->d.S;
@@ -1033,7 +1033,7 @@ extern "C" int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double 
   PpcArgs pa;
   pa.d = m->d; pa.draws = f->d_draws; pa.n_draws = n_draws; pa.exposure = m->d_expo; pa.X = m->d_X;
   pa.truncation_compensation = truncation_compensation; pa.p_lo = p_lo; pa.p_hi = p_hi; pa.k0 = seed32(seed);
-  pa.n_gen = n_gen; pa.n_pad = n_pad; pa.resample = resample ? 1 : 0; pa.n_cells = n_cells; pa.ci = d_ci; pa.counts_rng = d_rng;
+  pa.n_gen = n_gen; pa.resample = resample ? 1 : 0; pa.n_cells = n_cells; pa.ci = d_ci; pa.counts_rng = d_rng;
   hipError_t e = launch_ppc_kernel(pa, m->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
   if (e == hipSuccess) e = hipMemcpy(ci, d_ci, sizeof(double) * (size_t)n_cells * 4, hipMemcpyDeviceToHost);

@@ -82,7 +82,7 @@ struct PpcArgs {
   const double* exposure; const double* X;
   double truncation_compensation, p_lo, p_hi;
   uint32_t k0;
-  int n_gen, n_pad, resample, n_cells;
+  int n_gen, resample, n_cells;
   double* ci;                   // [K*S][4] mean, sd, lower, upper
   int* counts_rng;              // [n_gen][K*S] or null
 };

@@ -8,8 +8,8 @@
 //   ppcx_update_kernel      "kernel B": reduction of A's block partials, hyper-parameters, NUTS/adaptation
 //                           state machine (ppcx_nuts.h) and the per-coordinate updates of the next command.
 //   ppcx_ppc_kernel         generated quantities (.stan:259-266) + credible-interval summary
-//                           (R/utilities.R:685-703 / :733-784): NB draws straight into LDS, bitonic
-//                           sort, type-7 quantiles, mean, sd.
+//                           (R/utilities.R:685-703 / :733-784): NB draws straight into LDS, order
+//                           statistics by bisection on the value, type-7 quantiles, mean, sd.
 //   ppcx_gather_kernel      column gather of the retained draws.
 //
 // Work decomposition of kernel A1 (DESIGN.md "lp/grad kernel"): a gene is owned by L lanes of one
@@ -441,33 +441,69 @@ __global__ void ppcx_advi_elbo_kernel(AdviElboArgs a) {
 // -----------------------------------------------------------------------------------------------------
 // posterior-predictive draws + credible intervals, one workgroup per (gene <= K, sample) cell
 // -----------------------------------------------------------------------------------------------------
+// number of the workgroup's draws that are <= v (every thread gets the total; two barriers)
+__device__ __forceinline__ int block_count_le(const int* vals, int n, int v, int* s_cnt, int tid) {
+  int c = 0;
+  for (int j = tid; j < n; j += 256) c += vals[j] <= v ? 1 : 0;
+#pragma unroll
+  for (int msk = 1; msk < 64; msk <<= 1) c += __shfl_xor(c, msk, 64);
+  if ((tid & 63) == 0) s_cnt[tid >> 6] = c;
+  __syncthreads();
+  const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  __syncthreads();
+  return tot;
+}
+// order statistics r and r+1 (0-based, r+1 < n or equal to r when r = n-1) of the non-negative draws by bisection on the
+// value: the smallest v with #{draws <= v} >= r+1. Exact for integers; ~log2(max) counting passes instead of a sort.
+__device__ __forceinline__ void block_select_pair(const int* vals, int n, int r, int vmax, int* s_cnt, int tid, int* v_r, int* v_r1) {
+  int lo = 0, hi = vmax;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (block_count_le(vals, n, mid, s_cnt, tid) >= r + 1) hi = mid; else lo = mid + 1;
+  }
+  *v_r = lo;
+  // the next order statistic: the same value if it occurs again at rank r+1, else the smallest draw above it
+  int nxt = lo;
+  if (r + 1 < n && block_count_le(vals, n, lo, s_cnt, tid) < r + 2) {
+    int mn = 2147483647;
+    for (int j = tid; j < n; j += 256) { const int x = vals[j]; mn = (x > lo && x < mn) ? x : mn; }
+#pragma unroll
+    for (int msk = 1; msk < 64; msk <<= 1) { const int o = __shfl_xor(mn, msk, 64); mn = o < mn ? o : mn; }
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = mn;
+    __syncthreads();
+    nxt = min(min(s_cnt[0], s_cnt[1]), min(s_cnt[2], s_cnt[3]));
+    __syncthreads();
+  }
+  *v_r1 = nxt;
+}
+
 __global__ __launch_bounds__(256) void ppcx_ppc_kernel(PpcArgs a) {
   extern __shared__ int ldsi[];
   __shared__ double sred[256];
+  __shared__ int s_cnt[4];
   const Dims& d = a.d;
   const int cell = blockIdx.x;                 // g * S + s
   const int g = cell / d.S, s = cell % d.S;
   const int tid = threadIdx.x;
   int* vals = ldsi;
-  const int n = a.n_gen, npad = a.n_pad;
+  const int n = a.n_gen;
   double sum = 0.0;
-  for (int j = tid; j < npad; j += 256) {
-    int val = 2147483647;                      // padding sorts to the end
-    if (j < n) {
-      long src = j;
-      if (a.resample) {                        // R/utilities.R:760: sample(draws, n, replace = TRUE)
-        const double u = coord_uniform((uint32_t)j, (uint32_t)cell, 5u, 0u, a.k0, 0x50504331u);
-        src = (long)(u * (double)a.n_draws); if (src >= a.n_draws) src = a.n_draws - 1;
-      }
-      const double* u_ = a.draws + src * (long)d.D;
-      double eta = a.exposure[s] + a.X[s] * u_[d.off_intercept + g];
-      if (d.C >= 2) eta += a.X[(long)d.S + s] * u_[d.off_alpha1 + g];
-      for (int cc = 2; cc < d.C; ++cc) eta += a.X[(long)cc * d.S + s] * u_[coef_index(d, cc, g)];
-      const double phi = exp(-u_[d.off_sigma_raw + g]) * a.truncation_compensation;
-      val = nb2_log_rng(eta, phi, a.k0, (uint32_t)cell, (uint32_t)j);
-      sum += (double)val;
-      if (a.counts_rng) a.counts_rng[(long)j * a.n_cells + cell] = val;
+  int vmax = 0;
+  for (int j = tid; j < n; j += 256) {
+    long src = j;
+    if (a.resample) {                          // R/utilities.R:760: sample(draws, n, replace = TRUE)
+      const double u = coord_uniform((uint32_t)j, (uint32_t)cell, 5u, 0u, a.k0, 0x50504331u);
+      src = (long)(u * (double)a.n_draws); if (src >= a.n_draws) src = a.n_draws - 1;
     }
+    const double* u_ = a.draws + src * (long)d.D;
+    double eta = a.exposure[s] + a.X[s] * u_[d.off_intercept + g];
+    if (d.C >= 2) eta += a.X[(long)d.S + s] * u_[d.off_alpha1 + g];
+    for (int cc = 2; cc < d.C; ++cc) eta += a.X[(long)cc * d.S + s] * u_[coef_index(d, cc, g)];
+    const double phi = exp(-u_[d.off_sigma_raw + g]) * a.truncation_compensation;
+    const int val = nb2_log_rng(eta, phi, a.k0, (uint32_t)cell, (uint32_t)j);
+    sum += (double)val;
+    vmax = val > vmax ? val : vmax;
+    if (a.counts_rng) a.counts_rng[(long)j * a.n_cells + cell] = val;
     vals[j] = val;
   }
   // mean (fixed-order block reduction)
@@ -482,29 +518,27 @@ __global__ __launch_bounds__(256) void ppcx_ppc_kernel(PpcArgs a) {
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) { if (tid < st) sred[tid] += sred[tid + st]; __syncthreads(); }
   const double sd = n > 1 ? sqrt(sred[0] / (double)(n - 1)) : NAN;
-  // bitonic sort of the padded array in LDS
-  for (int k = 2; k <= npad; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      __syncthreads();
-      for (int i = tid; i < npad; i += 256) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const int x = vals[i], y = vals[ixj];
-          const bool up = (i & k) == 0;
-          if ((x > y) == up) { vals[i] = y; vals[ixj] = x; }
-        }
-      }
-    }
-  }
   __syncthreads();
-  if (tid == 0) {                              // type-7 quantiles (R quantile default; rstan::summary)
-    double q[2];
-    const double pr[2] = {a.p_lo, a.p_hi};
-    for (int k = 0; k < 2; ++k) {
-      const double h = (double)(n - 1) * pr[k];
-      const int lo = (int)floor(h);
-      q[k] = lo >= n - 1 ? (double)vals[n - 1] : (double)vals[lo] + (h - (double)lo) * ((double)vals[lo + 1] - (double)vals[lo]);
-    }
+  // largest draw of the workgroup (upper end of the bisections)
+#pragma unroll
+  for (int msk = 1; msk < 64; msk <<= 1) { const int o = __shfl_xor(vmax, msk, 64); vmax = o > vmax ? o : vmax; }
+  if ((tid & 63) == 0) s_cnt[tid >> 6] = vmax;
+  __syncthreads();
+  vmax = max(max(s_cnt[0], s_cnt[1]), max(s_cnt[2], s_cnt[3]));
+  __syncthreads();
+  // type-7 quantiles (R quantile default; rstan::summary) from the two order statistics around (n-1) p
+  double q[2];
+  const double pr[2] = {a.p_lo, a.p_hi};
+  for (int k = 0; k < 2; ++k) {
+    const double h = (double)(n - 1) * pr[k];
+    int lo = (int)floor(h);
+    if (lo > n - 1) lo = n - 1;
+    if (lo < 0) lo = 0;
+    int v0, v1;
+    block_select_pair(vals, n, lo, vmax, s_cnt, tid, &v0, &v1);
+    q[k] = lo >= n - 1 ? (double)v0 : (double)v0 + (h - (double)lo) * ((double)v1 - (double)v0);
+  }
+  if (tid == 0) {
     double* o = a.ci + (long)cell * 4;
     o[0] = mean; o[1] = sd; o[2] = q[0]; o[3] = q[1];
   }
@@ -578,7 +612,7 @@ hipError_t launch_advi_elbo_kernel(const AdviElboArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_ppc_kernel(const PpcArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(ppcx_ppc_kernel, dim3(a.n_cells), dim3(256), sizeof(int) * (size_t)a.n_pad, st, a);
+  hipLaunchKernelGGL(ppcx_ppc_kernel, dim3(a.n_cells), dim3(256), sizeof(int) * (size_t)a.n_gen, st, a);
   return hipGetLastError();
 }
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st) {
