@@ -1019,8 +1019,8 @@ extern "C" int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double 
   if (m->d.K < 1) return PPCX_OK;
   if (n_gen <= 0) n_gen = (int)n_draws;
   if (!resample && n_gen > n_draws) return fail(PPCX_ERR_ARG, "n_gen exceeds the kept draws (use resample)");
-  // a cell's draws live in LDS (160 KB per CU; 2 KB of it is the kernel's static scratch)
-  if (n_gen > 39936) return fail(PPCX_ERR_LIMIT, "more than 39936 predictive draws per cell: use the approximated analysis with fewer draws");
+  // a cell's draws live in LDS (160 KB per CU; 4 KB of it is the kernel's static scratch)
+  if (n_gen > 39680) return fail(PPCX_ERR_LIMIT, "more than 39680 predictive draws per cell: use the approximated analysis with fewer draws");
   if (!(p_lo >= 0.0 && p_hi <= 1.0 && p_lo <= p_hi)) return fail(PPCX_ERR_ARG, "need 0 <= p_lo <= p_hi <= 1");
   HIPCHK(hipSetDevice(m->device));
   const int n_cells = m->d.K * m->d.S;

@@ -441,15 +441,19 @@ __global__ void ppcx_advi_elbo_kernel(AdviElboArgs a) {
 // -----------------------------------------------------------------------------------------------------
 // posterior-predictive draws + credible intervals, one workgroup per (gene <= K, sample) cell
 // -----------------------------------------------------------------------------------------------------
+constexpr int kPpcThreads = 512;              // 8 wavefronts share the cell's draws in LDS (2 per SIMD; the kernel needs 233 VGPRs)
+constexpr int kPpcWaves = kPpcThreads / 64;
 // number of the workgroup's draws that are <= v (every thread gets the total; two barriers)
 __device__ __forceinline__ int block_count_le(const int* vals, int n, int v, int* s_cnt, int tid) {
   int c = 0;
-  for (int j = tid; j < n; j += 256) c += vals[j] <= v ? 1 : 0;
+  for (int j = tid; j < n; j += kPpcThreads) c += vals[j] <= v ? 1 : 0;
 #pragma unroll
   for (int msk = 1; msk < 64; msk <<= 1) c += __shfl_xor(c, msk, 64);
   if ((tid & 63) == 0) s_cnt[tid >> 6] = c;
   __syncthreads();
-  const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  int tot = 0;
+#pragma unroll
+  for (int w = 0; w < kPpcWaves; ++w) tot += s_cnt[w];
   __syncthreads();
   return tot;
 }
@@ -466,21 +470,23 @@ __device__ __forceinline__ void block_select_pair(const int* vals, int n, int r,
   int nxt = lo;
   if (r + 1 < n && block_count_le(vals, n, lo, s_cnt, tid) < r + 2) {
     int mn = 2147483647;
-    for (int j = tid; j < n; j += 256) { const int x = vals[j]; mn = (x > lo && x < mn) ? x : mn; }
+    for (int j = tid; j < n; j += kPpcThreads) { const int x = vals[j]; mn = (x > lo && x < mn) ? x : mn; }
 #pragma unroll
     for (int msk = 1; msk < 64; msk <<= 1) { const int o = __shfl_xor(mn, msk, 64); mn = o < mn ? o : mn; }
     if ((tid & 63) == 0) s_cnt[tid >> 6] = mn;
     __syncthreads();
-    nxt = min(min(s_cnt[0], s_cnt[1]), min(s_cnt[2], s_cnt[3]));
+    nxt = s_cnt[0];
+#pragma unroll
+    for (int w = 1; w < kPpcWaves; ++w) nxt = min(nxt, s_cnt[w]);
     __syncthreads();
   }
   *v_r1 = nxt;
 }
 
-__global__ __launch_bounds__(256) void ppcx_ppc_kernel(PpcArgs a) {
+__global__ __launch_bounds__(kPpcThreads) void ppcx_ppc_kernel(PpcArgs a) {
   extern __shared__ int ldsi[];
-  __shared__ double sred[256];
-  __shared__ int s_cnt[4];
+  __shared__ double sred[kPpcThreads];
+  __shared__ int s_cnt[kPpcWaves];
   const Dims& d = a.d;
   const int cell = blockIdx.x;                 // g * S + s
   const int g = cell / d.S, s = cell % d.S;
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(256) void ppcx_ppc_kernel(PpcArgs a) {
   const int n = a.n_gen;
   double sum = 0.0;
   int vmax = 0;
-  for (int j = tid; j < n; j += 256) {
+  for (int j = tid; j < n; j += kPpcThreads) {
     long src = j;
     if (a.resample) {                          // R/utilities.R:760: sample(draws, n, replace = TRUE)
       const double u = coord_uniform((uint32_t)j, (uint32_t)cell, 5u, 0u, a.k0, 0x50504331u);
@@ -509,14 +515,14 @@ __global__ __launch_bounds__(256) void ppcx_ppc_kernel(PpcArgs a) {
   // mean (fixed-order block reduction)
   sred[tid] = sum;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) { if (tid < st) sred[tid] += sred[tid + st]; __syncthreads(); }
+  for (int st = kPpcThreads / 2; st > 0; st >>= 1) { if (tid < st) sred[tid] += sred[tid + st]; __syncthreads(); }
   const double mean = sred[0] / (double)n;
   __syncthreads();
   double ss = 0.0;
-  for (int j = tid; j < n; j += 256) { const double t = (double)vals[j] - mean; ss += t * t; }
+  for (int j = tid; j < n; j += kPpcThreads) { const double t = (double)vals[j] - mean; ss += t * t; }
   sred[tid] = ss;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) { if (tid < st) sred[tid] += sred[tid + st]; __syncthreads(); }
+  for (int st = kPpcThreads / 2; st > 0; st >>= 1) { if (tid < st) sred[tid] += sred[tid + st]; __syncthreads(); }
   const double sd = n > 1 ? sqrt(sred[0] / (double)(n - 1)) : NAN;
   __syncthreads();
   // largest draw of the workgroup (upper end of the bisections)
@@ -524,7 +530,9 @@ __global__ __launch_bounds__(256) void ppcx_ppc_kernel(PpcArgs a) {
   for (int msk = 1; msk < 64; msk <<= 1) { const int o = __shfl_xor(vmax, msk, 64); vmax = o > vmax ? o : vmax; }
   if ((tid & 63) == 0) s_cnt[tid >> 6] = vmax;
   __syncthreads();
-  vmax = max(max(s_cnt[0], s_cnt[1]), max(s_cnt[2], s_cnt[3]));
+  vmax = s_cnt[0];
+#pragma unroll
+  for (int w = 1; w < kPpcWaves; ++w) vmax = max(vmax, s_cnt[w]);
   __syncthreads();
   // type-7 quantiles (R quantile default; rstan::summary) from the two order statistics around (n-1) p
   double q[2];
@@ -612,7 +620,7 @@ hipError_t launch_advi_elbo_kernel(const AdviElboArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_ppc_kernel(const PpcArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(ppcx_ppc_kernel, dim3(a.n_cells), dim3(256), sizeof(int) * (size_t)a.n_gen, st, a);
+  hipLaunchKernelGGL(ppcx_ppc_kernel, dim3(a.n_cells), dim3(kPpcThreads), sizeof(int) * (size_t)a.n_gen, st, a);
   return hipGetLastError();
 }
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st) {
