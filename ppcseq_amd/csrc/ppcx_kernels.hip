@@ -333,6 +333,9 @@ __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
     double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
     for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, nc, v, i, draws, &T0);
   }
+  // kinetic energy of freshly drawn momenta: only commands that draw momenta leave something (the step kernel's reduce
+  // phase reads the slab for exactly those commands)
+  if ((nc.pre_flags & (PRE_NEW_TRANSITION | PRE_EPS_TRY)) == 0) return;
   sT0[tid] = T0;
   __syncthreads();
   for (int stp = 128; stp > 0; stp >>= 1) { if (tid < stp) sT0[tid] += sT0[tid + stp]; __syncthreads(); }
