@@ -221,23 +221,24 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
     for (int k = 0; k < 2; ++k) r_hv[k] = tid + 256 * k < NHV ? hvg[tid + 256 * k] : 0.0;
   }
   if (a.phases & STEP_REDUCE) {
-    const Cmd& exg = a.cmds_in[chain];
-    const int np = (done || exg.type == CMD_DONE || exg.type == CMD_FLUSH) ? 0 : parts_used(exg);
     const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
-    // one pass: thread (c, ch) sums rows ch, ch+8, ... of columns c, c+32, c+64 (only the sums this command produced;
-    // np is uniform), loads of several rows in flight; then column v = sum over the eight row groups in a fixed order
+    // one pass: thread (c, ch) sums rows ch, ch+8, ... of columns c, c+32, c+64, loads of several rows in flight; then
+    // column v = sum over the eight row groups in a fixed order. All columns are loaded (stale ones included) so that
+    // these loads do not wait for the command that says which sums it produced; the selection happens afterwards.
+    const int c = tid & 31, ch = tid >> 5;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     {
-      const int c = tid & 31, ch = tid >> 5;
-      const bool u0 = c < np, u1 = c + 32 < np, u2 = c + 64 < np;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      const bool in2 = c + 64 < PT_COUNT;
 #pragma unroll 4
       for (int b = ch; b < a.nblocks_close; b += 8) {
         const double* row = slab + (long)b * PT_COUNT;
-        const double v0 = u0 ? row[c] : 0.0, v1 = u1 ? row[c + 32] : 0.0, v2 = u2 ? row[c + 64] : 0.0;
+        const double v0 = row[c], v1 = row[c + 32], v2 = in2 ? row[c + 64] : 0.0;
         s0 += v0; s1 += v1; s2 += v2;
       }
-      sm[0][ch][c] = s0; sm[1][ch][c] = s1; sm[2][ch][c] = s2;
     }
+    const Cmd& exg = a.cmds_in[chain];
+    const int np = (done || exg.type == CMD_DONE || exg.type == CMD_FLUSH) ? 0 : parts_used(exg);   // uniform
+    sm[0][ch][c] = c < np ? s0 : 0.0; sm[1][ch][c] = c + 32 < np ? s1 : 0.0; sm[2][ch][c] = c + 64 < np ? s2 : 0.0;
     __syncthreads();
     if (tid < PT_COUNT) {
       double t = 0.0;

@@ -79,8 +79,8 @@ PPCX_HD Hyper make_hyper(const double* u6, double lambda_mu_mu) {
   h.sigma_intercept = u6[4];
   h.sigma_sigma = fast_exp(u6[5]);           // <lower = 0>              (.stan:197)
   h.xi = h.lambda_mu + lambda_mu_mu;         // offset enters twice by construction (.stan:219)
-  h.inv_om = 1.0 / h.lambda_sigma; h.log_om = u6[1];
-  h.inv_ss = 1.0 / h.sigma_sigma; h.inv_ss2 = h.inv_ss * h.inv_ss; h.log_ss = u6[5];
+  h.inv_om = fast_rcp(h.lambda_sigma); h.log_om = u6[1];       // runs on the step kernel's critical path: no division
+  h.inv_ss = fast_rcp(h.sigma_sigma); h.inv_ss2 = h.inv_ss * h.inv_ss; h.log_ss = u6[5];
   return h;
 }
 
