@@ -102,14 +102,30 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
 // kernel A2: one thread per gene closes it -- priors, gradient, second half kick of the gene's coordinates,
 // U-turn dot products and subtree slots -- and the workgroup leaves its partial sums in a slab.
 // -----------------------------------------------------------------------------------------------------
+// v of lane i moved by a DPP control word (data-parallel primitives: a VALU move, no LDS round trip); lanes the
+// control leaves without a source, or outside row_mask, receive 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over the wavefront, left in lane 63: inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the
+// row totals travel to the next row (row_bcast:15 into rows 1 and 3) and to the upper half (row_bcast:31 into rows 2, 3)
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+  v += dpp_take<0x111, 0xf>(v);
+  v += dpp_take<0x112, 0xf>(v);
+  v += dpp_take<0x114, 0xf>(v);
+  v += dpp_take<0x118, 0xf>(v);
+  v += dpp_take<0x142, 0xa>(v);
+  v += dpp_take<0x143, 0xc>(v);
+  return v;
+}
 template <int N>
 __device__ __forceinline__ void block_accumulate(double* vals, double* wacc, int wave, int lane) {
 #pragma unroll
-  for (int msk = 1; msk < 64; msk <<= 1) {      // the N butterflies advance together: shuffle latencies overlap
-#pragma unroll
-    for (int k = 0; k < N; ++k) vals[k] = wave_xor_add(vals[k], msk);
-  }
-  if (lane == 0) {
+  for (int k = 0; k < N; ++k) vals[k] = wave_sum_to_lane63(vals[k]);
+  if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < N; ++k) wacc[wave * PT_COUNT + k] = vals[k];
   }
@@ -187,8 +203,10 @@ struct WaveLanes {                              // cooperating lanes 0..7 of one
   __device__ __forceinline__ int k_begin() const { return lane; }
   __device__ __forceinline__ int k_end() const { return lane < 6 ? lane + 1 : lane; }
   __device__ __forceinline__ bool leader() const { return lane == 0; }
-  __device__ __forceinline__ double sum(double v) const {
-    v += __shfl_xor(v, 1, 8); v += __shfl_xor(v, 2, 8); v += __shfl_xor(v, 4, 8);
+  __device__ __forceinline__ double sum(double v) const {      // all-reduce over the 8 lanes by DPP moves (no LDS round trips)
+    v += dpp_take<0xB1, 0xf>(v);               // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_take<0x4E, 0xf>(v);               // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_take<0x141, 0xf>(v);              // row_half_mirror: lane i <-> lane 7 - i, the other quad's total
     return v;
   }
   __device__ __forceinline__ double pick(const double* own, int k) const { return __shfl(own[0], k, 8); }
