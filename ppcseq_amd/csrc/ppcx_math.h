@@ -220,8 +220,9 @@ PPCX_HD void lgamma_digamma_tab(double x, const double* tab, double* lg, double*
 // ---------------------------------------------------------------------------------------------
 PPCX_HD void log_erfc_and_ratio(double x, double* log_erfc, double* ratio) {
   const double e = erfc(x);
-  *log_erfc = log(e);
-  *ratio = exp(-x * x) / e;
+  *log_erfc = e > 0.0 ? fast_log(e) : -INFINITY;            // log(0) = -inf, as libm's log gives it
+  const double x2 = x * x;
+  *ratio = (x2 < 700.0 ? fast_exp(-x2) : 0.0) / e;          // e = 0 only for x > 26.5: 0/0 = NaN, as exp(-x^2)/erfc(x) there
 }
 
 PPCX_HD double log_sum_exp(double a, double b) {
