@@ -29,7 +29,8 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct ppcx_model {
   int device;
   Dims d;
-  int CM, L, groups_per_wave, nblocks;
+  int CM, L, groups_per_wave, nblocks, nb0, nb1, G0;
+  int split_override = -1;       // 0: never split a launch into two segments (development aid, PPCX_SPLIT)
   int L_override, gpw_override;
   std::vector<int32_t> counts_host;            // original counts (exclusions are re-applied on a copy)
   std::vector<double> X_host, expo_host;
@@ -58,32 +59,57 @@ extern "C" int ppcx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) !=
 extern "C" const char* ppcx_last_error(void) { return g_err.c_str(); }
 
 // choose lanes-per-gene L and workgroups per chain: minimise (duration of one wavefront) x (rounds of resident
-// wavefronts the launch needs). A wavefront executes ~350 instructions of per-gene overhead plus, per cell of a lane,
-// ~85 and ~2 more per doubling of the genes that share the wavefront (they must agree on the lgamma regime) -- the
+// wavefronts the launch needs). A wavefront executes ~400 instructions of per-gene overhead plus, per cell of a lane,
+// ~80 and ~2 more per doubling of the genes that share the wavefront (they must agree on the lgamma regime) -- the
 // measured instruction counts of the kernel (SQ_INSTS_VALU vs S, profiles/). 1024 SIMDs x 4 resident wavefronts make a
 // round; a launch that does not fill one takes a wavefront's duration whatever L is, and because workgroups leave and
 // enter one by one a partly filled last round costs about half of what strict rounds would.
+// A launch may have two segments: whole rounds with L lanes per gene, and the remaining genes with 2L lanes per gene
+// -- twice as many wavefronts of half the duration -- so that the last, partial round is a short one.
+static double launch_wave_time(int S, int L) {
+  const int iters = (S + L - 1) / L;
+  return 400.0 + iters * (80.0 + 2.0 * log2(64.0 / L));
+}
+static double launch_eff_rounds(double rounds) { return rounds <= 1.0 ? 1.0 : 0.5 * rounds + 0.5 * ceil(rounds); }
 static void choose_launch(ppcx_model* m, int nchains) {
   const int G = m->d.G, S = m->d.S;
   const double slots = 4096.0;
-  int bestL = 64; double best = 1e300;
+  int bestL = 64, bestG0 = G; double best = 1e300;
   for (int L = 1; L <= 64; L <<= 1) {
-    const int iters = (S + L - 1) / L;
-    const double wave_time = 350.0 + iters * (85.0 + 2.0 * log2(64.0 / L));
-    const double rounds = ceil((double)G * L / 64.0) * nchains / slots;
-    const double eff_rounds = rounds <= 1.0 ? 1.0 : 0.5 * rounds + 0.5 * ceil(rounds);
-    const double t = wave_time * eff_rounds;
+    const int gpb = 4 * (64 / L);                                      // genes per workgroup
+    const double rounds = ceil((double)G / gpb) * 4.0 * nchains / slots;
+    const double t = launch_wave_time(S, L) * launch_eff_rounds(rounds);
     if (t < best) { best = t; bestL = L; }
   }
-  m->L = m->L_override > 0 ? m->L_override : bestL;
+  // two segments only where the model promises at least 3 % and the 2L segment still has >= 24 cells per lane (below
+  // that its per-gene overhead eats the gain). Measured on cfg3: 8 chains (4 + 8 lanes) -6 %; 4 chains (8 + 16 lanes)
+  // and 16 chains (2 + 4 lanes against a single 4-lane launch of 4.9 rounds) +2 % -- both excluded by these conditions.
+  double best_split = 0.97 * best;
+  for (int L = 1; L < 64 && m->split_override != 0; L <<= 1) {
+    const int gpb = 4 * (64 / L);
+    const double rounds = ceil((double)G / gpb) * 4.0 * nchains / slots;
+    if (rounds <= 1.0 || (S + 2 * L - 1) / (2 * L) < 24) continue;
+    const long nb0 = (long)(floor(rounds) * slots / (4.0 * nchains));
+    const long G0 = nb0 * gpb;
+    if (G0 <= 0 || G0 >= G) continue;
+    const double r1 = ceil((double)(G - G0) / (gpb / 2)) * 4.0 * nchains / slots;
+    const double t2 = launch_wave_time(S, L) * floor(rounds) + launch_wave_time(S, 2 * L) * launch_eff_rounds(r1);
+    if (t2 < best_split) { best_split = t2; bestL = L; bestG0 = (int)G0; }
+  }
+  if (m->L_override > 0) { bestL = m->L_override; bestG0 = G; }
+  m->L = bestL;
   const int gpw = 64 / m->L;
-  const int ngroups = (G + gpw - 1) / gpw;
+  m->G0 = bestG0;
+  const int ngroups0 = (m->G0 + gpw - 1) / gpw;
   int r = m->gpw_override > 0 ? m->gpw_override : 1;
   const int cap = 65528;                       // grid.y limit (the launcher pads to a multiple of 8)
-  int nb = (ngroups + 4 * r - 1) / (4 * r);
-  while (nb > cap) { ++r; nb = (ngroups + 4 * r - 1) / (4 * r); }
+  const int gpw1 = gpw > 1 ? gpw / 2 : 1;
+  const int ngroups1 = (G - m->G0 + gpw1 - 1) / gpw1;
+  int nb0 = (ngroups0 + 4 * r - 1) / (4 * r), nb1 = (ngroups1 + 3) / 4;
+  while (nb0 + nb1 > cap) { ++r; nb0 = (ngroups0 + 4 * r - 1) / (4 * r); nb1 = (ngroups1 + 4 * r - 1) / (4 * r); }
   m->groups_per_wave = r;
-  m->nblocks = nb < 1 ? 1 : nb;
+  m->nb0 = nb0 < 1 ? 1 : nb0; m->nb1 = m->G0 < G ? nb1 : 0;
+  m->nblocks = m->nb0 + m->nb1;
 }
 
 static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
@@ -151,6 +177,7 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   m->d = make_dims(G, S, C, K, lambda_mu_mu);
   m->CM = C <= 2 ? 2 : (C <= 4 ? 4 : 8);
   m->L_override = 0; m->gpw_override = 0;
+  if (const char* e = getenv("PPCX_SPLIT")) m->split_override = atoi(e);
   m->counts_host.assign(counts, counts + (size_t)G * S);
   m->X_host.assign(X, X + (size_t)S * C);
   m->expo_host.assign(exposure, exposure + S);
@@ -303,7 +330,7 @@ static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
 static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
   LoglikArgs la;
   la.d = m->d; la.counts = m->d_counts; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
-  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order;
+  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order; la.nb0 = m->nb0; la.G0 = m->G0; la.nb1 = m->nb1;
   hipError_t e = launch_loglik_kernel(m->L, m->CM, la, m->nblocks, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("loglik kernel: ") + hipGetErrorString(e));
   return PPCX_OK;

@@ -17,7 +17,8 @@ struct LoglikArgs {
   double* sums;                 // [chains][5+CM][G]
   const double* logtab;         // 2 x 256 doubles (device), ppcx_math.h table_log
   const int* order;             // [G] launch position -> gene (host: gene_order)
-  int gene_blocks;              // workgroups per chain (set by the launcher; the grid is padded to a multiple of 8)
+  int nb0, G0, nb1;             // launch segments (choose_launch): nb0 workgroups per chain cover the first G0 gene positions
+                                // with L lanes per gene, nb1 workgroups the rest with 2L (nb1 = 0: one segment, G0 = G)
 };
 
 struct CloseArgs {

@@ -33,21 +33,13 @@ __device__ __forceinline__ double wave_xor_add(double v, int mask) { return v + 
 #ifndef PPCX_LOGLIK_OCC
 #define PPCX_LOGLIK_OCC 4
 #endif
+// One workgroup's share of the launch with L lanes per gene: gene positions pos0 .. pos0 + npos - 1 of the host's
+// gene order, 4 * (64 / L) of them per workgroup; `gblock` counts the workgroups of this segment, `nseg` is their number.
 template <int L, int CM>
-__global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(LoglikArgs a) {
+__device__ __forceinline__ void loglik_body(const LoglikArgs& a, int chain, const Cmd& c, int gblock, int nseg, int pos0,
+                                            int npos, double* lds) {
   constexpr int GPW = 64 / L;                 // genes per wavefront
   constexpr int NS = GeneSums<CM>::N;
-  extern __shared__ double lds[];
-  // grid = (chains, gene blocks): the chain is the fast index, so the dispatch order is the host's gene order
-  // (expensive genes first) for all chains together, and the tail of the launch consists of cheap workgroups
-  // and workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids c*8 + (gblock & 7) inside every run
-  // of 8 gene blocks x chains put the chains of one gene block on ONE XCD, so its L2 fetches the rows once
-  const int nch = gridDim.x, ngblocks = a.gene_blocks;
-  const int lin = blockIdx.y * nch + blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
-  const int chain = r >> 3, gblock = run * 8 + (r & 7);
-  if (gblock >= ngblocks) return;
-  const Cmd& c = a.cmds[chain];
-  if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
   const Dims& d = a.d;
   const int S = d.S, C = d.C;
   double* stab = lds;                          // log table: 256 x 1/c then 256 x log c (4 KB)
@@ -58,11 +50,11 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
   const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
   double* sums = a.sums + (long)chain * NS * d.G;
   const int wave = tid >> 6, lane = tid & 63, sub = lane % L, gl = lane / L;
-  const int ngroups = (d.G + GPW - 1) / GPW;
+  const int ngroups = (npos + GPW - 1) / GPW;
   int grp = gblock * 4 + wave;
   GeneCtx<CM> x;
   // the first group's coordinates are requested before the LDS fill, so that the two round trips overlap
-  if (grp < ngroups) { const int pos = grp * GPW + gl; gene_load<CM>(d, c, v, pos < d.G ? a.order[pos] : d.G, x); }
+  if (grp < ngroups) { const int p = grp * GPW + gl; gene_load<CM>(d, c, v, p < npos ? a.order[pos0 + p] : d.G, x); }
   for (int i = tid; i < 2 * kLogTabSize; i += 256) stab[i] = a.logtab[i];
   const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
   for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
@@ -71,8 +63,8 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
     for (int i = tid; i < S * C; i += 256) sX[i] = a.X[i];
   }
   __syncthreads();
-  for (; grp < ngroups; grp += ngblocks * 4) {
-    if (grp != gblock * 4 + wave) { const int pos = grp * GPW + gl; gene_load<CM>(d, c, v, pos < d.G ? a.order[pos] : d.G, x); }
+  for (; grp < ngroups; grp += nseg * 4) {
+    if (grp != gblock * 4 + wave) { const int p = grp * GPW + gl; gene_load<CM>(d, c, v, p < npos ? a.order[pos0 + p] : d.G, x); }
     gene_consts<CM>(x, stab);
     CellAcc<CM> acc; acc.zero();
     gene_cells<CM>(d, x, a.counts + (long)x.gg * S, sE, sExpo, sX, stab, sub, L, acc);
@@ -96,6 +88,28 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
       }
     }
   }
+}
+
+// The launch has up to two segments (host: choose_launch): the first a.nb0 workgroups per chain take the first a.G0
+// gene positions with L lanes per gene -- whole rounds of resident wavefronts -- and the remaining a.nb1 workgroups
+// take the rest with 2L lanes per gene: twice as many wavefronts of half the duration, which fill the last, partial
+// round (a single-L launch of 2.4 rounds idles through 0.6 of a round; 2 + 0.9 half rounds does not).
+template <int L, int CM>
+__global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(LoglikArgs a) {
+  constexpr int L2 = L < 64 ? 2 * L : 64;
+  extern __shared__ double lds[];
+  // grid = (chains, gene blocks): the chain is the fast index, so the dispatch order is the host's gene order
+  // (expensive genes first) for all chains together, and the tail of the launch consists of cheap workgroups
+  // and workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids c*8 + (gblock & 7) inside every run
+  // of 8 gene blocks x chains put the chains of one gene block on ONE XCD, so its L2 fetches the rows once
+  const int nch = gridDim.x, ngblocks = a.nb0 + a.nb1;
+  const int lin = blockIdx.y * nch + blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
+  const int chain = r >> 3, gblock = run * 8 + (r & 7);
+  if (gblock >= ngblocks) return;
+  const Cmd& c = a.cmds[chain];
+  if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
+  if (gblock < a.nb0) loglik_body<L, CM>(a, chain, c, gblock, a.nb0, 0, a.G0, lds);
+  else loglik_body<L2, CM>(a, chain, c, gblock - a.nb0, a.nb1, a.G0, a.d.G - a.G0, lds);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -608,7 +622,7 @@ static hipError_t launch_loglik_l(int L, const LoglikArgs& a, dim3 grid, size_t 
 }
 hipError_t launch_loglik_kernel(int L, int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st) {
   const size_t lds_bytes = sizeof(double) * (2 * kLogTabSize + (size_t)a.d.S * (2 + a.d.C));
-  LoglikArgs b = a; b.gene_blocks = nblocks;
+  const LoglikArgs& b = a;
   const dim3 grid(nchains, (nblocks + 7) / 8 * 8);
   if (CM <= 2) return launch_loglik_l<2>(L, b, grid, lds_bytes, st);
   if (CM <= 4) return launch_loglik_l<4>(L, b, grid, lds_bytes, st);
