@@ -184,6 +184,10 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   int x0 = 1;
   for (int s = 0; s < S; ++s) if (X[s] != 1.0) x0 = 0;
   m->d.x0_is_one = x0;
+  int x1b = (C == 2);                          // two-group design: the second column is an indicator
+  for (int s = 0; s < S && x1b; ++s) if (X[(size_t)S + s] != 0.0 && X[(size_t)S + s] != 1.0) x1b = 0;
+  if (const char* e = getenv("PPCX_TWO_GROUP")) if (atoi(e) == 0) x1b = 0;     // development aid: force the generic cell path
+  m->d.x1_binary = x1b;
   std::vector<double> E(S);
   for (int s = 0; s < S; ++s) E[s] = exp(exposure[s]);
 #define MCHK(expr) do { int rc_ = (expr); if (rc_ != PPCX_OK) { ppcx_model_destroy(m); return rc_; } } while (0)

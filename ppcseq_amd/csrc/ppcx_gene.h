@@ -7,9 +7,6 @@
 #pragma once
 #include "ppcx_nuts.h"
 
-#ifndef PPCX_PREFETCH
-#define PPCX_PREFETCH 1
-#endif
 
 namespace ppcx {
 
@@ -17,7 +14,7 @@ template <int CM>
 struct GeneCtx {
   static constexpr int NCM = CM + 1;          // coordinates a gene can own: intercept, sigma_raw, CM-1 slopes
   int gg, ncoord;
-  bool active, has_slopes, fast;
+  bool active, has_slopes, fast, two;           // two: fast path with the group-dependent constant A / A1
   int idx[NCM];
   GeneParams<CM> gp;
 };
@@ -41,19 +38,21 @@ PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, Gene
     q[j] = j < x.ncoord ? v.at(V_Q0 + 3 * c.dir, x.idx[j]) : 0.0;
   }
   x.has_slopes = x.active && x.gg < d.K && C >= 2;
-  x.fast = d.x0_is_one && !x.has_slopes;
+  x.two = x.has_slopes && d.x0_is_one && d.x1_binary;
+  x.fast = d.x0_is_one && (!x.has_slopes || x.two);
   x.gp.coef[0] = q[0];
 #pragma unroll
   for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < C) ? q[cc + 1] : 0.0;
   x.gp.sigma_raw = q[1];
   x.gp.phi = fast_exp(-x.gp.sigma_raw);        // sigma = 1 ./ exp(sigma_raw)   (.stan:203)
-  x.gp.lgphi = 0.0; x.gp.dgphi = 0.0; x.gp.A = 0.0;
+  x.gp.lgphi = 0.0; x.gp.dgphi = 0.0; x.gp.A = 0.0; x.gp.A1 = 0.0;
 }
 // the per-gene constants of the cell loop
 template <int CM>
 PPCX_HD void gene_consts(GeneCtx<CM>& x, const double* tab) {
   lgamma_digamma_tab(x.gp.phi, tab, &x.gp.lgphi, &x.gp.dgphi);
   x.gp.A = fast_exp(x.gp.coef[0] + x.gp.sigma_raw);
+  if (PPCX_WAVE_ANY(x.two)) x.gp.A1 = fast_exp(x.gp.coef[0] + x.gp.coef[1] + x.gp.sigma_raw);
 }
 
 // the cells s = sub, sub+L, ... of the gene's row of counts. Excluded cells (count < 0) are skipped.
@@ -64,33 +63,41 @@ PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, con
   const GeneParams<CM>& gp = x.gp;
   if (!x.active) return;
   if (x.fast) {
-#if PPCX_PREFETCH
-    // the count and the sample constant of the next cell are requested before this cell is evaluated
+    // the count and the sample constants of the next cell are requested before this cell is evaluated
     int s = sub;
     int yn = s < S ? row[s] : -1;
     double en = s < S ? sE[s] : 0.0;
-    while (s < S) {
-      const int y = yn;
-      const double e = en;
-      const int s2 = s + L;
-      if (s2 < S) { yn = row[s2]; en = sE[s2]; }
-      if (y >= 0) {
-        double xsig;
-        cell_eval(y, e * gp.A, gp.phi, gp.lgphi, gp.dgphi, tab, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
-        acc.T2u += xsig;
+    if (!PPCX_WAVE_ANY(x.two)) {
+      while (s < S) {
+        const int y = yn;
+        const double e = en;
+        const int s2 = s + L;
+        if (s2 < S) { yn = row[s2]; en = sE[s2]; }
+        if (y >= 0) {
+          double xsig;
+          cell_eval(y, e * gp.A, gp.phi, gp.lgphi, gp.dgphi, tab, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
+          acc.T2u += xsig;
+        }
+        s = s2;
       }
-      s = s2;
-    }
-#else
-    for (int s = sub; s < S; s += L) {
-      const int y = row[s];
-      if (y >= 0) {
-        double xsig;
-        cell_eval(y, sE[s] * gp.A, gp.phi, gp.lgphi, gp.dgphi, tab, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
-        acc.T2u += xsig;
+    } else {
+      // two-group design, wavefront with slope genes: e^t = E_s A or E_s A1 by the sample's group (X[,2] is 0 or 1)
+      const double* sX1 = sX + S;
+      double xn = s < S ? sX1[s] : 0.0;
+      while (s < S) {
+        const int y = yn;
+        const double e = en, xb = xn;
+        const int s2 = s + L;
+        if (s2 < S) { yn = row[s2]; en = sE[s2]; xn = sX1[s2]; }
+        if (y >= 0) {
+          double xsig;
+          cell_eval(y, e * ((x.two && xb != 0.0) ? gp.A1 : gp.A), gp.phi, gp.lgphi, gp.dgphi, tab, &acc.T1, &acc.SP, &acc.T3, &acc.T4, &xsig);
+          acc.T2u += xsig;
+          acc.T2x[1] = fma(xb, xsig, acc.T2x[1]);
+        }
+        s = s2;
       }
     }
-#endif
   } else {
     for (int s = sub; s < S; s += L) {
       const int y = row[s];

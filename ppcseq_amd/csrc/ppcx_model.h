@@ -28,6 +28,8 @@ struct Dims {
   int G, S, C, K, D;
   int off_intercept, off_alpha1, off_alpha2, off_sigma_raw, off_tail;  // Stan declaration order (.stan:183-197)
   int x0_is_one;                // X[,1] == 1 (model.matrix intercept column, R/utilities.R:887-900)
+  int x1_binary;                // C == 2 and X[,2] in {0, 1} (a two-group design, `~ Label`): e^t of a gene with a slope is
+                                // E_s A_g or E_s A1_g by the sample's group -- no per-cell exp for the checked genes either
   int Gt, Kt, g0, k0;           // gene shard: totals of the whole problem and this shard's first gene / checked gene
   double lambda_mu_mu;
 };
@@ -41,7 +43,7 @@ PPCX_HD Dims make_dims(int G, int S, int C, int K, double lambda_mu_mu) {
   d.off_sigma_raw = d.off_alpha2 + (C > 2 ? C - 2 : 0) * K;
   d.off_tail = d.off_sigma_raw + G;
   d.D = d.off_tail + 3;
-  d.x0_is_one = 1; d.lambda_mu_mu = lambda_mu_mu;
+  d.x0_is_one = 1; d.x1_binary = 0; d.lambda_mu_mu = lambda_mu_mu;
   d.Gt = G; d.Kt = K; d.g0 = 0; d.k0 = 0;
   return d;
 }
@@ -159,7 +161,7 @@ PPCX_HD void cell_eval(int y, double u, double phi, double lgphi, double dgphi, 
 template <int CM>
 struct GeneParams {
   double coef[CM];              // intercept, alpha_sub_1, alpha_2...   (zero beyond K, .stan:133-135)
-  double sigma_raw, phi, lgphi, dgphi, A;
+  double sigma_raw, phi, lgphi, dgphi, A, A1;   // A = exp(intercept + sigma_raw), A1 = A exp(slope) (two-group designs)
 };
 
 // Result of closing one gene: its log-density contribution, the gradient of its own coordinates and

@@ -6,6 +6,7 @@ from ppcseq_amd import _lib as L
 from ppcseq_amd.synth import synth
 G, S = int(os.environ.get("G", 20000)), int(os.environ.get("S", 200))
 d = synth(G, S, seed=20253); K = d["K"]
+if os.environ.get("NO_SLOPES"): K = 0                     # every gene takes the intercept-only cell path
 d["counts"] //= int(os.environ.get("COUNT_DIV", 1))      # > 1: low counts everywhere (times the small-count regime)
 m = L.Model(d["counts"], d["X"], d["exposure"], K)
 bgrad = 4.0 * G * S + 16.0 * 3 * G + 8.0 * S * 3
