@@ -69,6 +69,20 @@ def test_design_without_unit_intercept_column(oracle, emul):
     assert abs(lp2 - lp) <= 1e-11 * abs(lp) and np.max(np.abs(g - g2) / (1 + np.abs(g))) < 1e-10
 
 
+def test_continuous_covariate_keeps_the_per_cell_exp(oracle, emul):
+    """C = 2 with a unit intercept column but a continuous second column: not a two-group design, so the checked genes
+    take the generic cell path while the other genes of the same wavefronts take the factorised one."""
+    d = ind.synth(21, 9, K=5, seed=6, C=2)
+    X = d["X"].copy()
+    X[:, 1] = np.linspace(-1.0, 1.5, 9)
+    u = np.random.default_rng(2).uniform(-1, 1, oracle.dim(21, 2, 5))
+    u[3:24] += 4
+    m = oracle.model(d["counts"], X, d["exposure"], 5)
+    lp, g = oracle.log_prob_grad(m, u)
+    lp2, g2 = emul_lp(emul, d["counts"], X, d["exposure"], 5, u)
+    assert abs(lp2 - lp) <= 1e-11 * abs(lp) and np.max(np.abs(g - g2) / (1 + np.abs(g))) < 1e-10
+
+
 @pytest.mark.parametrize("G,S,C,K,seed", [(30, 8, 2, 4, 3), (20, 6, 1, 3, 4), (24, 7, 3, 4, 5)])
 def test_nuts_state_machine_follows_oracle(oracle, emul, G, S, C, K, seed):
     """Same Philox streams, same Stan-default algorithm: the iterative device tree and the oracle's

@@ -54,6 +54,34 @@ def test_log_prob_grad_matches_oracle(L, oracle, G, S, C, K, seed):
         m.close()
 
 
+def test_continuous_covariate_and_two_group_designs(L, oracle, monkeypatch):
+    """C = 2: a 0/1 second column lets the checked genes use the factorised cell path (two constants per gene); a
+    continuous one keeps the per-cell exp. Both against the oracle, and the two-group shortcut against the generic path."""
+    d = ind.synth(70, 19, K=9, seed=6, C=2)
+    u = np.random.default_rng(2).uniform(-1, 1, (2, oracle.dim(70, 2, 9)))
+    u[:, 3:73] += 4
+    Xc = d["X"].copy()
+    Xc[:, 1] = np.linspace(-1.0, 1.5, 19)
+    for X in (d["X"], Xc):
+        mo = oracle.model(d["counts"], X, d["exposure"], 9)
+        ref = [oracle.log_prob_grad(mo, u[i]) for i in range(2)]
+        res = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("PPCX_TWO_GROUP", flag)
+            m = L.Model(d["counts"], X, d["exposure"], 9)
+            try:
+                for lanes in (0, 4, 64):
+                    m.set_launch(lanes, 0)
+                    lp, g = m.log_prob_grad(u)
+                    for i in range(2):
+                        assert abs(lp[i] - ref[i][0]) <= 1e-11 * abs(ref[i][0])
+                        assert np.max(np.abs(g[i] - ref[i][1]) / (1 + np.abs(ref[i][1]))) < 1e-10
+                res[flag] = lp
+            finally:
+                m.close()
+        assert np.max(np.abs(res["0"] - res["1"]) / np.abs(res["0"])) < 1e-13
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_low_counts_across_the_lgamma_regimes(L, oracle, seed):
     """Counts around the regime boundaries of the cell loop (y + phi < 8 / < 32 / >= 32), phi from 0.01 to 100,
