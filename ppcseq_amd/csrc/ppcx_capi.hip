@@ -101,7 +101,13 @@ static void choose_launch(ppcx_model* m, int nchains) {
   const int gpw = 64 / m->L;
   m->G0 = bestG0;
   const int ngroups0 = (m->G0 + gpw - 1) / gpw;
-  int r = m->gpw_override > 0 ? m->gpw_override : 1;
+  // groups per wavefront: with four or more rounds of resident wavefronts (two or more in the whole-round segment of a
+  // split launch) every wavefront takes two groups in turn -- half as many workgroup prologues (LDS fill, barrier, first
+  // loads) for the same balance. Measured on cfg3: 8 chains 14.4 -> 13.4 us per chain gradient (single segment), 13.6 ->
+  // 12.6 (two segments); 16 chains 12.4 -> 11.7; cfg4 72.6 -> 70.5; at 2.4 rounds (4 chains) it costs 2 % and is not used.
+  const double rounds0 = ceil((double)ngroups0 / 4.0) * 4.0 * nchains / slots;
+  int r = (m->G0 < G ? rounds0 >= 1.99 : rounds0 >= 4.0) ? 2 : 1;
+  if (m->gpw_override > 0) r = m->gpw_override;
   const int cap = 65528;                       // grid.y limit (the launcher pads to a multiple of 8)
   const int gpw1 = gpw > 1 ? gpw / 2 : 1;
   const int ngroups1 = (G - m->G0 + gpw1 - 1) / gpw1;
