@@ -66,6 +66,30 @@ extern "C" const char* ppcx_last_error(void) { return g_err.c_str(); }
 // enter one by one a partly filled last round costs about half of what strict rounds would.
 // A launch may have two segments: whole rounds with L lanes per gene, and the remaining genes with 2L lanes per gene
 // -- twice as many wavefronts of half the duration -- so that the last, partial round is a short one.
+// groups per wavefront for `nactive` chains in the launch (L and the segments stay as chosen, so every gene keeps its
+// summation order and the results do not change): with four or more rounds of resident wavefronts (two or more in the
+// whole-round segment of a split launch) every wavefront takes two groups in turn -- half as many workgroup prologues
+// (LDS fill, barrier, first loads) for the same balance. Measured on cfg3: 8 chains 14.4 -> 13.4 us per chain gradient
+// (single segment), 13.6 -> 12.6 (two segments); 16 chains 12.4 -> 11.7; cfg4 72.6 -> 70.5; at 2.4 rounds (4 chains) it
+// costs 2 % and is not used. The pump calls this again as chains finish: fewer chains, fewer rounds.
+static void set_groups_per_wave(ppcx_model* m, int nactive) {
+  const int G = m->d.G;
+  const double slots = 4096.0;
+  const int gpw = 64 / m->L;
+  const int ngroups0 = (m->G0 + gpw - 1) / gpw;
+  const double rounds0 = ceil((double)ngroups0 / 4.0) * 4.0 * (nactive < 1 ? 1 : nactive) / slots;
+  int r = (m->G0 < G ? rounds0 >= 1.99 : rounds0 >= 4.0) ? 2 : 1;
+  if (m->gpw_override > 0) r = m->gpw_override;
+  const int cap = 65528;                       // grid.y limit (the launcher pads to a multiple of 8)
+  const int gpw1 = gpw > 1 ? gpw / 2 : 1;
+  const int ngroups1 = (G - m->G0 + gpw1 - 1) / gpw1;
+  int nb0 = (ngroups0 + 4 * r - 1) / (4 * r), nb1 = (ngroups1 + 3) / 4;
+  while (nb0 + nb1 > cap) { ++r; nb0 = (ngroups0 + 4 * r - 1) / (4 * r); nb1 = (ngroups1 + 4 * r - 1) / (4 * r); }
+  m->groups_per_wave = r;
+  m->nb0 = nb0 < 1 ? 1 : nb0; m->nb1 = m->G0 < G ? nb1 : 0;
+  m->nblocks = m->nb0 + m->nb1;
+}
+
 static double launch_wave_time(int S, int L) {
   const int iters = (S + L - 1) / L;
   return 400.0 + iters * (80.0 + 2.0 * log2(64.0 / L));
@@ -98,24 +122,8 @@ static void choose_launch(ppcx_model* m, int nchains) {
   }
   if (m->L_override > 0) { bestL = m->L_override; bestG0 = G; }
   m->L = bestL;
-  const int gpw = 64 / m->L;
   m->G0 = bestG0;
-  const int ngroups0 = (m->G0 + gpw - 1) / gpw;
-  // groups per wavefront: with four or more rounds of resident wavefronts (two or more in the whole-round segment of a
-  // split launch) every wavefront takes two groups in turn -- half as many workgroup prologues (LDS fill, barrier, first
-  // loads) for the same balance. Measured on cfg3: 8 chains 14.4 -> 13.4 us per chain gradient (single segment), 13.6 ->
-  // 12.6 (two segments); 16 chains 12.4 -> 11.7; cfg4 72.6 -> 70.5; at 2.4 rounds (4 chains) it costs 2 % and is not used.
-  const double rounds0 = ceil((double)ngroups0 / 4.0) * 4.0 * nchains / slots;
-  int r = (m->G0 < G ? rounds0 >= 1.99 : rounds0 >= 4.0) ? 2 : 1;
-  if (m->gpw_override > 0) r = m->gpw_override;
-  const int cap = 65528;                       // grid.y limit (the launcher pads to a multiple of 8)
-  const int gpw1 = gpw > 1 ? gpw / 2 : 1;
-  const int ngroups1 = (G - m->G0 + gpw1 - 1) / gpw1;
-  int nb0 = (ngroups0 + 4 * r - 1) / (4 * r), nb1 = (ngroups1 + 3) / 4;
-  while (nb0 + nb1 > cap) { ++r; nb0 = (ngroups0 + 4 * r - 1) / (4 * r); nb1 = (ngroups1 + 4 * r - 1) / (4 * r); }
-  m->groups_per_wave = r;
-  m->nb0 = nb0 < 1 ? 1 : nb0; m->nb1 = m->G0 < G ? nb1 : 0;
-  m->nblocks = m->nb0 + m->nb1;
+  set_groups_per_wave(m, nchains);
 }
 
 static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
@@ -454,6 +462,7 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       if (w0.done_host[c] == 3) rc = fail(PPCX_ERR_STEPSIZE, "step-size heuristic diverged");
     }
     if (n_done == nchains) break;
+    if (ns == 1) set_groups_per_wave(sh[0].m, nchains - n_done);   // fewer chains in the launch: fewer rounds
     if (pairs > max_pairs) { rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished"); break; }
   }
   if (ev0) (void)hipEventDestroy(ev0);
