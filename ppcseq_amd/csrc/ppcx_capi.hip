@@ -272,6 +272,7 @@ struct Work {
   int* done_host = nullptr;
   long Dpad = 0; int nb_update = 1, nb_close = 1; long launches = 0;
   hipStream_t stream = nullptr; bool own_stream = false;
+  bool retune_launch = true;     // the pump may adapt the model's groups per wavefront (not when several pumps share the model)
   ~Work() {
     (void)hipFree(vecs); (void)hipFree(partials); (void)hipFree(done); (void)hipFree(sums); (void)hipFree(red);
     for (int i = 0; i < 2; ++i) { (void)hipFree(hyper_vecs[i]); (void)hipFree(t0[i]); (void)hipFree(cmds[i]); (void)hipFree(states[i]); }
@@ -462,7 +463,7 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       if (w0.done_host[c] == 3) rc = fail(PPCX_ERR_STEPSIZE, "step-size heuristic diverged");
     }
     if (n_done == nchains) break;
-    if (ns == 1) set_groups_per_wave(sh[0].m, nchains - n_done);   // fewer chains in the launch: fewer rounds
+    if (ns == 1 && w0.retune_launch) set_groups_per_wave(sh[0].m, nchains - n_done);   // fewer chains in the launch: fewer rounds
     if (pairs > max_pairs) { rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished"); break; }
   }
   if (ev0) (void)hipEventDestroy(ev0);
@@ -625,6 +626,7 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
     Group& G = grp[g];
     G.c0 = (int)((long long)nch * g / ngrp); G.n = (int)((long long)nch * (g + 1) / ngrp) - G.c0;
     if (g > 0) { FHIP(hipStreamCreateWithFlags(&G.w.stream, hipStreamNonBlocking)); G.w.own_stream = true; }
+    G.w.retune_launch = ngrp == 1;
     int rc = work_alloc(G.w, m, G.n);
     if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }
     std::vector<ChainState> states(G.n);
