@@ -246,7 +246,14 @@ def outlier_concordance():
     mo = O.model(counts, X, expo, 3, n_threads=4)
     r = O.nuts_model(mo, O.cfg(chains=3, iter=g.iter, warmup=150, seed=seed))
     dr = r.draws.reshape(-1, r.draws.shape[-1])
-    ci = O.summarise(O.generated_quantities(mo, dr, 1.0, seed=seed), p, 1 - p)
+    gq = O.generated_quantities(mo, dr, 1.0, seed=seed)          # [draws, K, S]
+    ci = O.summarise(gq, p, 1 - p)
+    # Monte-Carlo standard error of the upper interval end per cell (bootstrap over the draws of the CPU path); the two
+    # paths are independent runs, so their difference has sqrt(2) times that error
+    rng = np.random.default_rng(0)
+    nd = gq.shape[0]
+    boots = np.stack([np.quantile(gq[rng.integers(0, nd, nd)], 1 - p, axis=0) for _ in range(100)])
+    se_upper = np.sqrt(2.0) * boots.std(axis=0) + 0.5              # + half a count: the ends are interpolated integers
     off = 3 + counts.shape[0]
     o = _post_process(counts[:3], ci, dr[:, off:off + 3].mean(0), X)
     same_ppc = float(np.mean(g.ppc == o.ppc))
@@ -256,7 +263,8 @@ def outlier_concordance():
             "gpu_tot_deleterious": [int(v) for v in g.deleterious_outliers.sum(1)],
             "cpu_tot_deleterious": [int(v) for v in o.deleterious_outliers.sum(1)],
             "max_upper_ci_rel_diff": float(np.max(np.abs(g.upper - o.upper) / (1 + o.upper))),
-            "median_upper_ci_rel_diff": float(np.median(np.abs(g.upper - o.upper) / (1 + o.upper)))}
+            "median_upper_ci_rel_diff": float(np.median(np.abs(g.upper - o.upper) / (1 + o.upper))),
+            "max_upper_ci_diff_in_mc_standard_errors": float(np.max(np.abs(g.upper - o.upper) / se_upper))}
 
 
 def cpu_baseline(arrays, K, gpu_ess, gpu_grad, args):

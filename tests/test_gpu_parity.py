@@ -493,6 +493,7 @@ def test_outlier_call_concordance_with_cpu_path():
     # paths part ways after a few iterations: chaotic dynamics amplify rounding differences) -- typical cells agree
     # within a few per cent, the worst of the 63 cells within the Monte-Carlo error of such a quantile
     assert c["median_upper_ci_rel_diff"] < 0.1 and c["max_upper_ci_rel_diff"] < 1.0
+    assert c["max_upper_ci_diff_in_mc_standard_errors"] < 5.0       # interval ends in units of their MC error
 
 
 def test_dot_C_entry_point_matches_handle_api(L):
