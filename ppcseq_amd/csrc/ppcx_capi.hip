@@ -30,6 +30,7 @@ struct ppcx_model {
   int device;
   Dims d;
   int CM, L, groups_per_wave, nblocks, nb0, nb1, G0;
+  int nblocks_chosen = 0;        // workgroups per chain chosen for the full chain count (what ppcx_model_get_launch reports)
   int split_override = -1;       // 0: never split a launch into two segments (development aid, PPCX_SPLIT)
   int L_override, gpw_override;
   std::vector<int32_t> counts_host;            // original counts (exclusions are re-applied on a copy)
@@ -124,6 +125,7 @@ static void choose_launch(ppcx_model* m, int nchains) {
   m->L = bestL;
   m->G0 = bestG0;
   set_groups_per_wave(m, nchains);
+  m->nblocks_chosen = m->nblocks;
 }
 
 static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
@@ -244,7 +246,7 @@ extern "C" int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int grou
 extern "C" int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int* nblocks) {
   if (!m) return fail(PPCX_ERR_ARG, "model is NULL");
   if (lanes_per_gene) *lanes_per_gene = m->L;
-  if (nblocks) *nblocks = m->nblocks;
+  if (nblocks) *nblocks = m->nblocks_chosen;
   return PPCX_OK;
 }
 extern "C" int ppcx_model_dim(const ppcx_model* m) { return m ? m->d.D : PPCX_ERR_ARG; }
