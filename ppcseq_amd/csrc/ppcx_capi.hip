@@ -36,10 +36,12 @@ struct ppcx_model {
   std::vector<int32_t> counts_host;            // original counts (exclusions are re-applied on a copy)
   std::vector<double> X_host, expo_host;
   int* d_counts = nullptr;
-  double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_ncell = nullptr, *d_Lg1 = nullptr;
+  double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_Lg1 = nullptr;
   double* d_logtab = nullptr;
   int* d_order = nullptr;        // gene_order: position in the log-likelihood kernel's launch -> gene
   hipStream_t stream = nullptr;
+  int live_fits = 0;             // fits that still point at this model: ppcx_model_destroy defers until the last one is freed
+  bool destroy_requested = false;
 };
 
 struct ppcx_fit {
@@ -135,16 +137,16 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
     if (excl[e] < 0 || excl[e] >= G * S) return fail(PPCX_ERR_ARG, "excluded cell id out of range");
     cnt[excl[e]] = -1;
   }
-  std::vector<double> Sy(G, 0.0), SyE(G, 0.0), SyX((size_t)C * G, 0.0), ncell(G, 0.0), Lg1(G, 0.0);
+  std::vector<double> Sy(G, 0.0), SyE(G, 0.0), SyX((size_t)C * G, 0.0), Lg1(G, 0.0);
   for (int g = 0; g < G; ++g) {
-    double sy = 0, sye = 0, nc = 0, lg1 = 0;
+    double sy = 0, sye = 0, lg1 = 0;
     for (int s = 0; s < S; ++s) {
       const int y = cnt[(size_t)g * S + s];
       if (y < 0) continue;
-      sy += y; sye += (double)y * m->expo_host[s]; nc += 1.0; lg1 += lgamma((double)y + 1.0);
+      sy += y; sye += (double)y * m->expo_host[s]; lg1 += lgamma((double)y + 1.0);
       for (int c = 0; c < C; ++c) SyX[(size_t)c * G + g] += (double)y * m->X_host[(size_t)c * S + s];
     }
-    Sy[g] = sy; SyE[g] = sye; ncell[g] = nc; Lg1[g] = lg1;
+    Sy[g] = sy; SyE[g] = sye; Lg1[g] = lg1;
   }
   // gene_order: the log-likelihood kernel picks its lgamma/digamma regime per wavefront from the smallest
   // y + phi among its lanes (ppcx_model.h cell_eval), and runs the generic and the intercept-only cell paths one
@@ -169,7 +171,6 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
   HIPCHK(hipMemcpy(m->d_Sy, Sy.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_SyE, SyE.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_SyX, SyX.data(), sizeof(double) * SyX.size(), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(m->d_ncell, ncell.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_Lg1, Lg1.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   return PPCX_OK;
 }
@@ -182,6 +183,9 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   if (G < 1 || S < 1 || C < 1 || K < 0 || K > G) return fail(PPCX_ERR_ARG, "need G>=1, S>=1, C>=1, 0<=K<=G");
   if (C > kMaxC) return fail(PPCX_ERR_LIMIT, "C exceeds the 8 design columns this build supports");
   if ((long long)G * S > 2000000000LL) return fail(PPCX_ERR_LIMIT, "G*S exceeds int32 cell ids");
+  // the log-likelihood kernel stages the log table and the per-sample constants (exp(exposure), exposure, X) in LDS
+  if (sizeof(double) * (2 * (size_t)kLogTabSize + (size_t)S * (2 + C)) > 160u * 1024u)
+    return fail(PPCX_ERR_LIMIT, "S * (2 + C) doubles of per-sample constants do not fit the 160 KB of LDS of a compute unit");
   if (!counts || !X || !exposure || (n_excl > 0 && !excl)) return fail(PPCX_ERR_ARG, "NULL input buffer");
   for (long long i = 0; i < (long long)G * S; ++i) if (counts[i] < 0) return fail(PPCX_ERR_ARG, "negative count");
   int ndev = 0;
@@ -209,14 +213,14 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
 #define MCHK(expr) do { int rc_ = (expr); if (rc_ != PPCX_OK) { ppcx_model_destroy(m); return rc_; } } while (0)
 #define MHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ppcx_model_destroy(m); return fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
   MHIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-  MHIP(hipMalloc(&m->d_counts, sizeof(int32_t) * (size_t)G * S));
+  MHIP(hipMalloc(&m->d_counts, sizeof(int32_t) * ((size_t)G * S + 64)));   // + 64: the cell loop requests the next cell before testing s < S
+  MHIP(hipMemset(m->d_counts, 0, sizeof(int32_t) * ((size_t)G * S + 64)));
   MHIP(hipMalloc(&m->d_E, sizeof(double) * S));
   MHIP(hipMalloc(&m->d_expo, sizeof(double) * S));
   MHIP(hipMalloc(&m->d_X, sizeof(double) * (size_t)S * C));
   MHIP(hipMalloc(&m->d_Sy, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_SyE, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_SyX, sizeof(double) * (size_t)C * G));
-  MHIP(hipMalloc(&m->d_ncell, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_Lg1, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_logtab, sizeof(double) * 2 * kLogTabSize));
   { double tab[2 * kLogTabSize]; fill_log_table(tab); MHIP(hipMemcpy(m->d_logtab, tab, sizeof(tab), hipMemcpyHostToDevice)); }
@@ -252,9 +256,10 @@ extern "C" int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, i
 extern "C" int ppcx_model_dim(const ppcx_model* m) { return m ? m->d.D : PPCX_ERR_ARG; }
 extern "C" void ppcx_model_destroy(ppcx_model* m) {
   if (!m) return;
+  if (m->live_fits > 0) { m->destroy_requested = true; return; }   // freed by the last ppcx_fit_free
   (void)hipSetDevice(m->device);
   (void)hipFree(m->d_counts); (void)hipFree(m->d_E); (void)hipFree(m->d_expo); (void)hipFree(m->d_X);
-  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_order);
+  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_order);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -291,8 +296,8 @@ static int work_alloc(Work& w, ppcx_model* m, int nchains) {
   HIPCHK(hipMalloc(&w.vecs, sizeof(double) * (size_t)nchains * V_COUNT * w.Dpad));
   w.nb_close = (m->d.G + 255) / 256;
   HIPCHK(hipMalloc(&w.partials, sizeof(double) * (size_t)nchains * w.nb_close * PT_COUNT));
-  HIPCHK(hipMalloc(&w.sums, sizeof(double) * (size_t)nchains * (5 + m->CM) * m->d.G));
-  HIPCHK(hipMemsetAsync(w.sums, 0, sizeof(double) * (size_t)nchains * (5 + m->CM) * m->d.G, w.stream));
+  HIPCHK(hipMalloc(&w.sums, sizeof(double) * (size_t)nchains * (3 + m->CM) * m->d.G));
+  HIPCHK(hipMemsetAsync(w.sums, 0, sizeof(double) * (size_t)nchains * (3 + m->CM) * m->d.G, w.stream));
   HIPCHK(hipMalloc(&w.done, sizeof(int) * nchains));
   HIPCHK(hipMalloc(&w.red, sizeof(double) * (size_t)nchains * PT_COUNT));
   HIPCHK(hipMemsetAsync(w.red, 0, sizeof(double) * (size_t)nchains * PT_COUNT, w.stream));
@@ -315,6 +320,9 @@ static int work_alloc(Work& w, ppcx_model* m, int nchains) {
     HIPCHK(launch_fill_kernel(w.hyper_vecs[0] + ((size_t)c * V_COUNT + V_MINV) * 8, 8, 1.0, w.stream));
   }
   w.launches = 0;
+  // the callers upload the initial chain states / hyper vectors next, some of them with blocking copies on the NULL
+  // stream, which does not order against this non-blocking stream: the zero fills above must have landed first
+  HIPCHK(hipStreamSynchronize(w.stream));
   return PPCX_OK;
 }
 
@@ -351,14 +359,15 @@ static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
 static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
   LoglikArgs la;
   la.d = m->d; la.counts = m->d_counts; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
-  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order; la.nb0 = m->nb0; la.G0 = m->G0; la.nb1 = m->nb1;
-  hipError_t e = launch_loglik_kernel(m->L, m->CM, la, m->nblocks, nchains, w.stream);
+  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order; la.lgL = 0; while ((1 << la.lgL) < m->L) ++la.lgL; la.nb0 = m->nb0; la.G0 = m->G0; la.nb1 = m->nb1;
+  hipError_t e = launch_loglik_kernel(m->CM, la, m->nblocks, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("loglik kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
 }
 static int launch_close(ppcx_model* m, Work& w, int nchains) {
   CloseArgs ca;
-  ca.d = m->d; ca.Sy = m->d_Sy; ca.SyE = m->d_SyE; ca.SyX = m->d_SyX; ca.ncell = m->d_ncell; ca.Lg1 = m->d_Lg1;
+  ca.d = m->d; ca.Sy = m->d_Sy; ca.SyE = m->d_SyE; ca.SyX = m->d_SyX; ca.Lg1 = m->d_Lg1;
+  for (int c = 0; c < kMaxC; ++c) { ca.SXall[c] = 0.0; if (c < m->d.C) for (int s = 0; s < m->d.S; ++s) ca.SXall[c] += m->X_host[(size_t)c * m->d.S + s]; }
   ca.sums = w.sums; ca.vecs = w.vecs; ca.Dpad = w.Dpad; ca.cmds = w.cmds[w.launches & 1]; ca.partials = w.partials;
   hipError_t e = launch_close_kernel(m->CM, ca, w.nb_close, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("close kernel: ") + hipGetErrorString(e));
@@ -417,8 +426,12 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
     if ((rc = launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;
   }
   const int batch = 32, sample_every = 16;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-  if (time_kernels) { HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1)); HIPCHK(hipEventCreate(&ev2)); HIPCHK(hipEventCreate(&ev3)); }
+  struct Events {                // destroyed on every exit path
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+  } evs;
+  if (time_kernels) for (hipEvent_t& x : evs.e) HIPCHK(hipEventCreate(&x));
+  hipEvent_t &ev0 = evs.e[0], &ev1 = evs.e[1], &ev2 = evs.e[2], &ev3 = evs.e[3];
   long long pairs = 0; int n_done = 0;
   Work& w0 = *sh[0].w;
   while (true) {
@@ -468,10 +481,6 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
     if (ns == 1 && w0.retune_launch) set_groups_per_wave(sh[0].m, nchains - n_done);   // fewer chains in the launch: fewer rounds
     if (pairs > max_pairs) { rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished"); break; }
   }
-  if (ev0) (void)hipEventDestroy(ev0);
-  if (ev1) (void)hipEventDestroy(ev1);
-  if (ev2) (void)hipEventDestroy(ev2);
-  if (ev3) (void)hipEventDestroy(ev3);
   stats->pairs = pairs;
   return rc;
 }
@@ -577,12 +586,15 @@ extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs
   return PPCX_OK;
 }
 
+static void fit_attach(ppcx_fit* f, ppcx_model* m) { f->m = m; m->live_fits++; }
 extern "C" void ppcx_fit_free(ppcx_fit* f) {
   if (!f) return;
-  (void)hipSetDevice(f->m->device);
+  ppcx_model* m = f->m;
+  (void)hipSetDevice(m->device);
   (void)hipFree(f->d_draws); (void)hipFree(f->d_lp); (void)hipFree(f->d_stepsize); (void)hipFree(f->d_accept);
   (void)hipFree(f->d_treedepth); (void)hipFree(f->d_nleap); (void)hipFree(f->d_div);
   delete f;
+  if (--m->live_fits == 0 && m->destroy_requested) ppcx_model_destroy(m);
 }
 
 extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fit** out) {
@@ -595,7 +607,7 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   const int nch = cfg->chains, D = m->d.D, iter = cfg->iter, n_keep = cfg->iter - cfg->warmup;
   choose_launch(m, nch);
   ppcx_fit* f = new ppcx_fit();
-  f->m = m; f->chains = nch; f->n_keep = n_keep; f->iter = iter;
+  fit_attach(f, m); f->chains = nch; f->n_keep = n_keep; f->iter = iter;
   NutsConfig nc;
   nc.chains = nch; nc.iter = iter; nc.warmup = cfg->warmup; nc.seed = cfg->seed; nc.adapt_delta = cfg->adapt_delta;
   nc.max_treedepth = cfg->max_treedepth; nc.init_radius = cfg->init_radius; nc.stepsize0 = cfg->stepsize0;
@@ -610,6 +622,8 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   FHIP(hipMalloc(&f->d_treedepth, sizeof(int) * (size_t)nch * iter));
   FHIP(hipMalloc(&f->d_nleap, sizeof(int) * (size_t)nch * iter));
   FHIP(hipMalloc(&f->d_div, sizeof(int) * (size_t)nch * iter));
+  if (n_keep > 0) FHIP(hipMemsetAsync(f->d_draws, 0, sizeof(double) * (size_t)nch * n_keep * D, m->stream));
+  if (n_keep > 0) FHIP(hipMemsetAsync(f->d_lp, 0, sizeof(double) * (size_t)nch * n_keep, m->stream));
   FHIP(hipMemsetAsync(f->d_stepsize, 0, sizeof(double) * (size_t)nch * iter, m->stream));
   FHIP(hipMemsetAsync(f->d_accept, 0, sizeof(double) * (size_t)nch * iter, m->stream));
   FHIP(hipMemsetAsync(f->d_treedepth, 0, sizeof(int) * (size_t)nch * iter, m->stream));
@@ -634,7 +648,8 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
     std::vector<ChainState> states(G.n);
     NutsConfig ncg = nc; ncg.chain_id_offset = nc.chain_id_offset + G.c0;
     for (int c = 0; c < G.n; ++c) state_init(states[c], ncg, c, 0);
-    FHIP(hipMemcpy(G.w.states[0], states.data(), sizeof(ChainState) * G.n, hipMemcpyHostToDevice));
+    FHIP(hipMemcpyAsync(G.w.states[0], states.data(), sizeof(ChainState) * G.n, hipMemcpyHostToDevice, G.w.stream));
+    FHIP(hipStreamSynchronize(G.w.stream));     // `states` is a host temporary
     const size_t c0 = (size_t)G.c0;
     G.io.draws = f->d_draws ? f->d_draws + c0 * n_keep * D : nullptr; G.io.draws_stride = (long)n_keep * D;
     G.io.n_keep = n_keep; G.io.iter = iter;
@@ -794,7 +809,8 @@ extern "C" int ppcx_fit_advi(ppcx_model* m, const ppcx_advi_config* cfg, ppcx_fi
     std::vector<double> hv((size_t)V_COUNT * 8, 0.0);
     for (int k = 0; k < 8; ++k) hv[V_MINV * 8 + k] = 1.0;
     for (int k = 0; k < 6; ++k) hv[V_Q0 * 8 + k] = q0[hyper_index(d, k)];
-    HIPCHK(hipMemcpy(w.hyper_vecs[0], hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(w.hyper_vecs[0], hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
   }
   auto reset = [&]() { return advi_launch(r, ADVI_RESET, 0, 0.0, 0, 0, 0, nullptr, 0); };
   if ((rc = reset()) != PPCX_OK) return rc;
@@ -838,7 +854,7 @@ extern "C" int ppcx_fit_advi(ppcx_model* m, const ppcx_advi_config* cfg, ppcx_fi
   }
   // ---- output_samples draws from the fitted approximation (kept as a one-chain fit)
   ppcx_fit* f = new ppcx_fit();
-  f->m = m; f->chains = 1; f->n_keep = cfg->output_samples; f->iter = iters_done;
+  fit_attach(f, m); f->chains = 1; f->n_keep = cfg->output_samples; f->iter = iters_done;
   memset(&f->cfg, 0, sizeof f->cfg);
 #define AHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ppcx_fit_free(f); return fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
   AHIP(hipMalloc(&f->d_draws, sizeof(double) * (size_t)cfg->output_samples * D));
@@ -904,7 +920,7 @@ static int fit_sharded(ppcx_model** models, int ns, const ppcx_nuts_config* cfg,
     choose_launch(m, nch);
     ppcx_fit* f = new ppcx_fit();
     fits[k] = f;
-    f->m = m; f->chains = nch; f->n_keep = n_keep; f->iter = iter; f->cfg = nc;
+    fit_attach(f, m); f->chains = nch; f->n_keep = n_keep; f->iter = iter; f->cfg = nc;
     if (n_keep > 0) SHIP(hipMalloc(&f->d_draws, sizeof(double) * (size_t)nch * n_keep * D));
     if (n_keep > 0) SHIP(hipMalloc(&f->d_lp, sizeof(double) * (size_t)nch * n_keep));
     SHIP(hipMalloc(&f->d_stepsize, sizeof(double) * (size_t)nch * iter));
@@ -912,6 +928,8 @@ static int fit_sharded(ppcx_model** models, int ns, const ppcx_nuts_config* cfg,
     SHIP(hipMalloc(&f->d_treedepth, sizeof(int) * (size_t)nch * iter));
     SHIP(hipMalloc(&f->d_nleap, sizeof(int) * (size_t)nch * iter));
     SHIP(hipMalloc(&f->d_div, sizeof(int) * (size_t)nch * iter));
+    if (n_keep > 0) SHIP(hipMemset(f->d_draws, 0, sizeof(double) * (size_t)nch * n_keep * D));
+    if (n_keep > 0) SHIP(hipMemset(f->d_lp, 0, sizeof(double) * (size_t)nch * n_keep));
     SHIP(hipMemset(f->d_stepsize, 0, sizeof(double) * (size_t)nch * iter));
     SHIP(hipMemset(f->d_accept, 0, sizeof(double) * (size_t)nch * iter));
     SHIP(hipMemset(f->d_treedepth, 0, sizeof(int) * (size_t)nch * iter));
@@ -921,7 +939,8 @@ static int fit_sharded(ppcx_model** models, int ns, const ppcx_nuts_config* cfg,
     if ((rc = work_alloc(works[k], m, nch)) != PPCX_OK) { cleanup(); return rc; }
     std::vector<ChainState> states(nch);
     for (int c = 0; c < nch; ++c) state_init(states[c], nc, c, 0);   // every shard replicates the same chains
-    SHIP(hipMemcpy(works[k].states[0], states.data(), sizeof(ChainState) * nch, hipMemcpyHostToDevice));
+    SHIP(hipMemcpyAsync(works[k].states[0], states.data(), sizeof(ChainState) * nch, hipMemcpyHostToDevice, works[k].stream));
+    SHIP(hipStreamSynchronize(works[k].stream));   // `states` is a host temporary
     sh[k].m = m; sh[k].w = &works[k];
     RunIO& io = sh[k].io;
     io.draws = f->d_draws; io.draws_stride = (long)n_keep * D; io.n_keep = n_keep; io.iter = iter;

@@ -14,9 +14,10 @@ struct LoglikArgs {
   double* vecs;                 // [chains][V_COUNT][Dpad] (read only here)
   long Dpad;
   const Cmd* cmds;              // [chains]
-  double* sums;                 // [chains][5+CM][G]
+  double* sums;                 // [chains][3+CM][G] (GeneSumsV)
   const double* logtab;         // 2 x 256 doubles (device), ppcx_math.h table_log
   const int* order;             // [G] launch position -> gene (host: gene_order)
+  int lgL;                      // log2 of the lanes per gene of the first segment
   int nb0, G0, nb1;             // launch segments (choose_launch): nb0 workgroups per chain cover the first G0 gene positions
                                 // with L lanes per gene, nb1 workgroups the rest with 2L (nb1 = 0: one segment, G0 = G)
 };
@@ -26,7 +27,7 @@ struct CloseArgs {
   const double* Sy;             // per-gene sufficient statistics over non-excluded cells
   const double* SyE;
   const double* SyX;            // [C][G]
-  const double* ncell;
+  double SXall[kMaxC];          // sum over ALL samples of X_sc
   const double* Lg1;            // per-gene sum of lgamma(y+1)
   const double* sums;
   double* vecs; long Dpad;
@@ -88,7 +89,7 @@ struct PpcArgs {
   int* counts_rng;              // [n_gen][K*S] or null
 };
 
-hipError_t launch_loglik_kernel(int L, int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st);
+hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_step_kernel(const StepArgs& a, int nchains, hipStream_t st);
 hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st);

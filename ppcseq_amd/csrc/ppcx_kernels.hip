@@ -23,22 +23,43 @@
 
 namespace ppcx {
 
-__device__ __forceinline__ double wave_xor_add(double v, int mask) { return v + __shfl_xor(v, mask, 64); }
-
 // -----------------------------------------------------------------------------------------------------
-// kernel A1: the log-likelihood kernel. Streams the count matrix once and leaves, per gene, the sums
-// T1 = sum x log w, SP = sum log w, T2u = sum x u/w, T3 = sum [lgamma(y+phi) - lgamma(phi)],
-// T4 = sum [psi(y+phi) - psi(phi)] (+ T2x[c] = sum X_sc x u/w for genes with slopes).
+// kernel A1: the log-likelihood kernel. Streams the count matrix once and leaves, per gene, the sums of
+// GeneSumsV (ppcx_model.h): the likelihood part of the gene's log density, its d/dphi part, sum rho
+// (+ sum X_sc rho for genes with slopes).
 // -----------------------------------------------------------------------------------------------------
 #ifndef PPCX_LOGLIK_OCC
 #define PPCX_LOGLIK_OCC 4
 #endif
-// One workgroup's share of the launch with L lanes per gene: gene positions pos0 .. pos0 + npos - 1 of the host's
-// gene order, 4 * (64 / L) of them per workgroup; `gblock` counts the workgroups of this segment, `nseg` is their number.
-template <int L, int CM>
-__device__ __forceinline__ void loglik_body(const LoglikArgs& a, int chain, const Cmd& c, int gblock, int nseg, int pos0,
-                                            int npos, double* lds) {
-  constexpr int GPW = 64 / L;                 // genes per wavefront
+__device__ __forceinline__ double wave_xor_add_rt(double v, int lane_xor_mask) {      // run-time mask: ds_bpermute
+  const int src = (int)((threadIdx.x ^ (unsigned)lane_xor_mask) & 63u) << 2;
+  const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+  return v + __hiloint2double(hi, lo);
+}
+// The launch has up to two segments (host: choose_launch): the first a.nb0 workgroups per chain take the first a.G0
+// gene positions of the host's gene order with L = 2^lgL lanes per gene -- whole rounds of resident wavefronts -- and
+// the remaining a.nb1 workgroups take the rest with 2L lanes per gene: twice as many wavefronts of half the duration,
+// which fill the last, partial round (a single-L launch of 2.4 rounds idles through 0.6 of a round; 2 + 0.9 half
+// rounds does not). L is a run-time value of the workgroup, so both segments run the same code.
+template <int CM>
+__global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(LoglikArgs a) {
+  extern __shared__ double lds[];
+  // grid = (chains, gene blocks): the chain is the fast index, so the dispatch order is the host's gene order
+  // (expensive genes first) for all chains together, and the tail of the launch consists of cheap workgroups
+  // and workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids c*8 + (gblock & 7) inside every run
+  // of 8 gene blocks x chains put the chains of one gene block on ONE XCD, so its L2 fetches the rows once
+  const int nch = gridDim.x, ngblocks = a.nb0 + a.nb1;
+  const int lin = blockIdx.y * nch + blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
+  const int chain = r >> 3, gb0 = run * 8 + (r & 7);
+  if (gb0 >= ngblocks) return;
+  const Cmd& c = a.cmds[chain];
+  if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
+  const bool seg1 = gb0 >= a.nb0;
+  const int lgL = seg1 ? (a.lgL < 6 ? a.lgL + 1 : 6) : a.lgL;
+  const int L = 1 << lgL, GPW = 64 >> lgL;       // lanes per gene, genes per wavefront
+  const int gblock = seg1 ? gb0 - a.nb0 : gb0, nseg = seg1 ? a.nb1 : a.nb0;
+  const int pos0 = seg1 ? a.G0 : 0, npos = seg1 ? a.d.G - a.G0 : a.G0;
   constexpr int NS = GeneSums<CM>::N;
   const Dims& d = a.d;
   const int S = d.S, C = d.C;
@@ -49,8 +70,8 @@ __device__ __forceinline__ void loglik_body(const LoglikArgs& a, int chain, cons
   const int tid = threadIdx.x;
   const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
   double* sums = a.sums + (long)chain * NS * d.G;
-  const int wave = tid >> 6, lane = tid & 63, sub = lane % L, gl = lane / L;
-  const int ngroups = (npos + GPW - 1) / GPW;
+  const int wave = tid >> 6, lane = tid & 63, sub = lane & (L - 1), gl = lane >> lgL;
+  const int ngroups = (npos + GPW - 1) >> (6 - lgL);
   int grp = gblock * 4 + wave;
   GeneCtx<CM> x;
   // the first group's coordinates are requested before the LDS fill, so that the two round trips overlap
@@ -68,48 +89,25 @@ __device__ __forceinline__ void loglik_body(const LoglikArgs& a, int chain, cons
     gene_consts<CM>(x, stab);
     CellAcc<CM> acc; acc.zero();
     gene_cells<CM>(d, x, a.counts + (long)x.gg * S, sE, sExpo, sX, stab, sub, L, acc);
+    GeneSumsV<CM> o;
+    cell_acc_close<CM>(x.gp, acc, stab, &o);
     // L-lane butterfly: every lane of the gene ends with the gene totals
-#pragma unroll
     for (int msk = 1; msk < L; msk <<= 1) {
-      acc.T1 = wave_xor_add(acc.T1, msk); acc.SP = wave_xor_add(acc.SP, msk); acc.T2u = wave_xor_add(acc.T2u, msk);
-      acc.T3 = wave_xor_add(acc.T3, msk); acc.T4 = wave_xor_add(acc.T4, msk);
+      o.lik = wave_xor_add_rt(o.lik, msk); o.dph = wave_xor_add_rt(o.dph, msk); o.Sr = wave_xor_add_rt(o.Sr, msk);
       if (any_generic) {
 #pragma unroll
-        for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.T2x[cc] = wave_xor_add(acc.T2x[cc], msk);
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) o.Tx[cc] = wave_xor_add_rt(o.Tx[cc], msk);
       }
     }
     if (x.active && sub == 0) {
       const long G = d.G;
-      sums[0 * G + x.gg] = acc.T1; sums[1 * G + x.gg] = acc.SP; sums[2 * G + x.gg] = acc.T2u;
-      sums[3 * G + x.gg] = acc.T3; sums[4 * G + x.gg] = acc.T4;
+      sums[0 * G + x.gg] = o.lik; sums[1 * G + x.gg] = o.dph; sums[2 * G + x.gg] = o.Sr;
       if (any_generic) {
 #pragma unroll
-        for (int cc = 0; cc < CM; ++cc) if (cc < C) sums[(5 + cc) * G + x.gg] = acc.T2x[cc];
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) sums[(3 + cc) * G + x.gg] = o.Tx[cc];
       }
     }
   }
-}
-
-// The launch has up to two segments (host: choose_launch): the first a.nb0 workgroups per chain take the first a.G0
-// gene positions with L lanes per gene -- whole rounds of resident wavefronts -- and the remaining a.nb1 workgroups
-// take the rest with 2L lanes per gene: twice as many wavefronts of half the duration, which fill the last, partial
-// round (a single-L launch of 2.4 rounds idles through 0.6 of a round; 2 + 0.9 half rounds does not).
-template <int L, int CM>
-__global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(LoglikArgs a) {
-  constexpr int L2 = L < 64 ? 2 * L : 64;
-  extern __shared__ double lds[];
-  // grid = (chains, gene blocks): the chain is the fast index, so the dispatch order is the host's gene order
-  // (expensive genes first) for all chains together, and the tail of the launch consists of cheap workgroups
-  // and workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids c*8 + (gblock & 7) inside every run
-  // of 8 gene blocks x chains put the chains of one gene block on ONE XCD, so its L2 fetches the rows once
-  const int nch = gridDim.x, ngblocks = a.nb0 + a.nb1;
-  const int lin = blockIdx.y * nch + blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
-  const int chain = r >> 3, gblock = run * 8 + (r & 7);
-  if (gblock >= ngblocks) return;
-  const Cmd& c = a.cmds[chain];
-  if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
-  if (gblock < a.nb0) loglik_body<L, CM>(a, chain, c, gblock, a.nb0, 0, a.G0, lds);
-  else loglik_body<L2, CM>(a, chain, c, gblock - a.nb0, a.nb1, a.G0, a.d.G - a.G0, lds);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -161,18 +159,20 @@ __global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
   const bool any_generic = !d.x0_is_one || (d.C >= 2 && d.K > 0);
   GeneCtx<CM> x;
   gene_load<CM>(d, c, v, g, x);
-  CellAcc<CM> acc; acc.zero();
+  GeneSumsV<CM> acc;
+  acc.lik = acc.dph = acc.Sr = 0.0;
+#pragma unroll
+  for (int cc = 0; cc < CM; ++cc) acc.Tx[cc] = 0.0;
   if (x.active) {
     const long G = d.G;
-    acc.T1 = sums[0 * G + g]; acc.SP = sums[1 * G + g]; acc.T2u = sums[2 * G + g];
-    acc.T3 = sums[3 * G + g]; acc.T4 = sums[4 * G + g];
+    acc.lik = sums[0 * G + g]; acc.dph = sums[1 * G + g]; acc.Sr = sums[2 * G + g];
     if (any_generic) {
 #pragma unroll
-      for (int cc = 0; cc < CM; ++cc) if (cc < d.C) acc.T2x[cc] = sums[(5 + cc) * G + g];
+      for (int cc = 0; cc < CM; ++cc) if (cc < d.C) acc.Tx[cc] = sums[(3 + cc) * G + g];
     }
   }
   double pn[NCM], minv[NCM], part[10];
-  gene_finish<CM>(d, c, v, x, acc, a.Sy, a.SyE, a.SyX, a.ncell, a.Lg1, part, pn, minv);
+  gene_finish<CM>(d, c, v, x, acc, a.Sy, a.SyE, a.SyX, a.SXall, a.Lg1, part, pn, minv);
   block_accumulate<10>(part, wacc, wave, lane);
   if (c.type == CMD_LEAF) {
     NodeVals nv[NCM];
@@ -603,30 +603,13 @@ __global__ void ppcx_fill_kernel(double* p, long n, double val) {
 // -----------------------------------------------------------------------------------------------------
 // launch helpers (host)
 // -----------------------------------------------------------------------------------------------------
-template <int L, int CM>
-static hipError_t launch_loglik_t(const LoglikArgs& a, dim3 grid, size_t lds_bytes, hipStream_t st) {
-  hipLaunchKernelGGL((ppcx_loglik_kernel<L, CM>), grid, dim3(256), lds_bytes, st, a);
-  return hipGetLastError();
-}
-template <int CM>
-static hipError_t launch_loglik_l(int L, const LoglikArgs& a, dim3 grid, size_t lds_bytes, hipStream_t st) {
-  switch (L) {
-    case 1: return launch_loglik_t<1, CM>(a, grid, lds_bytes, st);
-    case 2: return launch_loglik_t<2, CM>(a, grid, lds_bytes, st);
-    case 4: return launch_loglik_t<4, CM>(a, grid, lds_bytes, st);
-    case 8: return launch_loglik_t<8, CM>(a, grid, lds_bytes, st);
-    case 16: return launch_loglik_t<16, CM>(a, grid, lds_bytes, st);
-    case 32: return launch_loglik_t<32, CM>(a, grid, lds_bytes, st);
-    default: return launch_loglik_t<64, CM>(a, grid, lds_bytes, st);
-  }
-}
-hipError_t launch_loglik_kernel(int L, int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st) {
+hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st) {
   const size_t lds_bytes = sizeof(double) * (2 * kLogTabSize + (size_t)a.d.S * (2 + a.d.C));
-  const LoglikArgs& b = a;
   const dim3 grid(nchains, (nblocks + 7) / 8 * 8);
-  if (CM <= 2) return launch_loglik_l<2>(L, b, grid, lds_bytes, st);
-  if (CM <= 4) return launch_loglik_l<4>(L, b, grid, lds_bytes, st);
-  return launch_loglik_l<8>(L, b, grid, lds_bytes, st);
+  if (CM <= 2) hipLaunchKernelGGL((ppcx_loglik_kernel<2>), grid, dim3(256), lds_bytes, st, a);
+  else if (CM <= 4) hipLaunchKernelGGL((ppcx_loglik_kernel<4>), grid, dim3(256), lds_bytes, st, a);
+  else hipLaunchKernelGGL((ppcx_loglik_kernel<8>), grid, dim3(256), lds_bytes, st, a);
+  return hipGetLastError();
 }
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st) {
   const dim3 grid(nblocks, nchains);

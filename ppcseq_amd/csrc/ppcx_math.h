@@ -132,83 +132,53 @@ PPCX_HD double fast_exp(double x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// log-gamma and digamma for x > 0 with ONE shared logarithm and ONE reciprocal.
-//   x >= 8 : Stirling series  lgamma(x) = (x-1/2)ln x - x + ln(2pi)/2 + sum B2k/(2k(2k-1)x^(2k-1))
-//            digamma(x) = ln x - 1/(2x) - sum B2k/(2k x^2k)          (Abramowitz & Stegun 6.1.40, 6.3.18)
-//   x <  8 : shift by 8 with the recurrences lgamma(x) = lgamma(x+8) - ln prod_{k<8}(x+k),
-//            digamma(x) = digamma(x+8) - P'(x)/P(x).
-// Truncation error of the 7-term tails at x = 8 is < 2e-15 (next Bernoulli term).
+// Stirling tails for x >= 8, r = 1/x (A&S 6.1.40, 6.3.18 give the asymptotic series):
+//   lgamma(x)  = (x - 1/2) ln x - x + ln(2 pi)/2 + lg_tail(r),      lg_tail(r) = r F(r^2)
+//   digamma(x) = ln x - dg_tail(r),                                  dg_tail(r) = r/2 + r^2 G(r^2)
+// F and G (both 1/12 - ... at 0) are smooth on r^2 in [0, 1/64]; instead of the asymptotic series (7 terms for 2e-15
+// at x = 8) they are evaluated by the degree-4 polynomials that interpolate them at the Chebyshev nodes of that
+// interval (scripts/fit/stirling_tails.py, mpmath at 60 digits): maximum absolute error of the double-precision
+// evaluation 3.7e-16 (lg_tail) and 4.9e-16 (dg_tail) over x in [8, 1e6] -- one regime for every x >= 8.
 // ---------------------------------------------------------------------------------------------
-PPCX_HD void lgamma_digamma_stirling(double x, double lx, double rx, double* lg, double* dg) {
+PPCX_HD void stirling_tails(double rx, double* lgt, double* dgt) {
   const double r2 = rx * rx;
-  // lgamma tail: rx * (1/12 - r2*(1/360 - r2*(1/1260 - r2*(1/1680 - r2*(1/1188 - r2*(691/360360 - r2/156))))))
-  double t = 691.0 / 360360.0 - r2 * (1.0 / 156.0);
-  t = 1.0 / 1188.0 - r2 * t;
-  t = 1.0 / 1680.0 - r2 * t;
-  t = 1.0 / 1260.0 - r2 * t;
-  t = 1.0 / 360.0 - r2 * t;
-  t = 1.0 / 12.0 - r2 * t;
-  *lg = (x - 0.5) * lx - x + 0.91893853320467274178 + rx * t;
-  // digamma tail: r2 * (1/12 - r2*(1/120 - r2*(1/252 - r2*(1/240 - r2*(1/132 - r2*(691/32760 - r2/12))))))
-  double d = 691.0 / 32760.0 - r2 * (1.0 / 12.0);
-  d = 1.0 / 132.0 - r2 * d;
-  d = 1.0 / 240.0 - r2 * d;
-  d = 1.0 / 252.0 - r2 * d;
-  d = 1.0 / 120.0 - r2 * d;
-  d = 1.0 / 12.0 - r2 * d;
-  *dg = lx - 0.5 * rx - r2 * d;
+  double t = fma(r2, 7.72651446721163817e-04, -5.94317590856362882e-04);
+  t = fma(r2, t, 7.93645716111539040e-04);
+  t = fma(r2, t, -2.77777776791245188e-03);
+  t = fma(r2, t, 8.33333333333302478e-02);
+  *lgt = rx * t;
+  double d = fma(r2, 6.82627523986508236e-03, -4.15672846375406482e-03);
+  d = fma(r2, d, 3.96819926156938719e-03);
+  d = fma(r2, d, -8.33333322714054948e-03);
+  d = fma(r2, d, 8.33333333333001886e-02);
+  *dgt = fma(r2, d, 0.5 * rx);
 }
-
-// 4-term tails: valid for x >= 32 (next terms x^-9/1188 and x^-10/132 are < 3e-17 there)
-PPCX_HD void lgamma_digamma_stirling4(double x, double lx, double rx, double* lg, double* dg) {
-  const double r2 = rx * rx;
-  double t = 1.0 / 1260.0 - r2 * (1.0 / 1680.0);
-  t = 1.0 / 360.0 - r2 * t;
-  t = 1.0 / 12.0 - r2 * t;
-  *lg = (x - 0.5) * lx - x + 0.91893853320467274178 + rx * t;
-  double d = 1.0 / 252.0 - r2 * (1.0 / 240.0);
-  d = 1.0 / 120.0 - r2 * d;
-  d = 1.0 / 12.0 - r2 * d;
-  *dg = lx - 0.5 * rx - r2 * d;
-}
-
-PPCX_HD void lgamma_digamma(double x, double* lg, double* dg) {
-  if (x >= 8.0) {
-    lgamma_digamma_stirling(x, fast_log(x), fast_rcp(x), lg, dg);
-  } else {
-    // P = prod_{k=0..7}(x+k), P' by the product rule, both in one pass
-    double P = x, dP = 1.0;
+// The "Stirling excess" of the dispersion phi, the per-gene constants of the cell loop (ppcx_model.h):
+//   dlt = lgamma(phi) - [(phi - 1/2) ln phi - phi + ln(2 pi)/2]          dps = ln phi - digamma(phi)
+// For phi >= 8 they ARE the Stirling tails of 1/phi (no cancellation); below, phi is shifted by 8 and the leading
+// terms are subtracted analytically. lnphi is passed in because the caller knows it exactly (ln phi = -sigma_raw).
+// `any_small` (wave-uniform on the device) says whether some lane needs the shifted form.
+PPCX_HD void stirling_excess(double phi, double lnphi, const double* tab, bool any_small, double* dlt, double* dps) {
+  const bool small = phi < 8.0;
+  const double xs = small ? phi + 8.0 : phi;
+  const double rs = fast_rcp(xs);
+  double lgt, dgt;
+  stirling_tails(rs, &lgt, &dgt);
+  *dlt = lgt; *dps = dgt;
+  if (any_small) {
+    double P = phi, dP = 1.0;
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
-      const double f = x + (double)k;
-      dP = dP * f + P;
+      const double f = phi + (double)k;
+      dP = fma(dP, f, P);
       P = P * f;
     }
-    const double xs = x + 8.0;
-    double l8, d8;
-    lgamma_digamma_stirling(xs, fast_log(xs), fast_rcp(xs), &l8, &d8);
-    *lg = l8 - fast_log(P);
-    *dg = d8 - dP * fast_rcp(P);
-  }
-}
-
-// the same with the table-driven logarithm (normal finite x > 0; the product of the shift stays normal for x > 1e-300)
-PPCX_HD void lgamma_digamma_tab(double x, const double* tab, double* lg, double* dg) {
-  if (x >= 8.0) {
-    lgamma_digamma_stirling(x, table_log(x, tab), fast_rcp(x), lg, dg);
-  } else {
-    double P = x, dP = 1.0;
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
-      const double f = x + (double)k;
-      dP = dP * f + P;
-      P = P * f;
-    }
-    const double xs = x + 8.0;
-    double l8, d8;
-    lgamma_digamma_stirling(xs, table_log(xs, tab), fast_rcp(xs), &l8, &d8);
-    *lg = l8 - table_log(P, tab);
-    *dg = d8 - dP * fast_rcp(P);
+    const double lxs = table_log(xs, tab), lP = table_log(P, tab);
+    // lgamma(phi) = (xs - 1/2) ln xs - xs + c + lgt - ln P ;  minus (phi - 1/2) ln phi - phi + c
+    const double d1 = (xs - 0.5) * lxs - 8.0 - lP - (phi - 0.5) * lnphi + lgt;
+    const double d2 = (lnphi - lxs) + dgt + dP * fast_rcp(P);
+    *dlt = small ? d1 : lgt;
+    *dps = small ? d2 : dgt;
   }
 }
 

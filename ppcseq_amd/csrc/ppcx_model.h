@@ -5,14 +5,21 @@
 //   transforms :183-197,:203      priors :210-223      likelihood lp_reduce :58-120 via map_rect :226-240
 //   coefficient assembly merge_coefficients :122-139 and X*alpha :205 (fused away: eta is formed per cell)
 //
-// How it is computed (the MI355X-first part, see DESIGN.md "lp/grad kernel"):
-//   * log phi = -sigma_raw exactly, so with t = eta + sigma_raw, u = exp(t), w = 1 + u:
-//       NB2log(y|eta,phi) = y*t - (y+phi)*log(w) + [lgamma(y+phi) - lgamma(phi)] - lgamma(y+1)
-//       d/deta = y - (y+phi)*u/w           d/dphi = psi(y+phi) - psi(phi) + 1 - log(w) - (y+phi)/(phi*w)
-//   * sum_s y*t and sum_s y are per-gene SUFFICIENT STATISTICS (Sy, SyE, SyX) precomputed once, so the
-//     large cancelling terms never go through the per-cell loop;
-//   * sum_s lgamma(y+1) is a per-gene constant of the data (Lg1), subtracted at gene level so the
-//     large lgamma terms cancel inside each gene instead of across the whole matrix;
+// How it is computed (the MI355X-first part, see DESIGN.md "log-likelihood kernel"). With log phi = -sigma_raw exactly,
+// t = eta + sigma_raw, u = exp(t), w = 1 + u, x = y + phi, xf = x/phi = 1 + y/phi and rho = xf/w = x/(phi w):
+//   * Stirling at x AND at phi, leading terms cancelled analytically (dlt, dps = the "Stirling excess" of phi,
+//     ppcx_math.h):
+//       NB2log(y|eta,phi) + lgamma(y+1) = y eta - y + (y + phi) ln rho - 1/2 ln xf + lg_tail(1/x) - dlt
+//       d/deta = y - x u/w = phi (rho - 1)
+//       d/dphi = psi(x) - psi(phi) - ln w + 1 - x/(phi w) = ln rho - dg_tail(1/x) + dps + 1 - rho
+//     so a cell needs ONE logarithm (ln rho), one reciprocal (of w xf: it yields 1/w and 1/xf) and the two tails;
+//     sum_s ln xf is the logarithm of a running product (one multiply per cell, renormalised every few cells);
+//     the tails are degree-4 polynomials in 1/x^2 valid for every x >= 8 (ppcx_math.h stirling_tails);
+//   * sum_s y eta, sum_s y are per-gene SUFFICIENT STATISTICS (SyE, SyX, Sy) precomputed once, so the large
+//     cancelling terms never go through the per-cell loop; sum_s lgamma(y+1) is a per-gene constant of the data (Lg1);
+//   * cells with x < 8 (then y <= 7) use the exact recurrences instead of Stirling at x:
+//       lgamma(x) - lgamma(phi) = ln P, P = prod_{k<y}(phi+k);  psi(x) - psi(phi) = P'/P
+//     with the same instruction stream: the logarithm's argument is 1/w instead of rho, the product takes P^-2;
 //   * for genes without slope terms (g >= K, X[,1] == 1) exp(t) factorises into E_s * A_g with
 //     E_s = exp(exposure_s) staged in LDS and A_g = exp(intercept_g + sigma_raw_g): no per-cell exp;
 //   * excluded cells (to_exclude, R/utilities.R:321-359, subtracted at .stan:105-115) are stored as
@@ -86,83 +93,134 @@ PPCX_HD Hyper make_hyper(const double* u6, double lambda_mu_mu) {
   return h;
 }
 
-// per-lane partial sums over the cells of one gene
-template <int CM>
-struct CellAcc {
-  double T1, SP, T2u, T3, T4;   // sum x*log w, sum log w, sum x*u/w, sum dlgamma, sum ddigamma
-  double T2x[CM];               // sum X_sc * x*u/w  (generic path only)
-  PPCX_HD void zero() { T1 = SP = T2u = T3 = T4 = 0.0;
-#pragma unroll
-    for (int c = 0; c < CM; ++c) T2x[c] = 0.0; }
-};
-
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PPCX_WAVE_ANY(p) (__any(p) != 0)
-#define PPCX_WAVE_ALL(p) (__all(p) != 0)
-#else
-#define PPCX_WAVE_ANY(p) (p)
-#define PPCX_WAVE_ALL(p) (p)
-#endif
-
-// One valid cell (y >= 0) once u = exp(t) is known. The per-lane work is free of selects and divisions in
-// the common case: the three regimes of lgamma(y+phi) - lgamma(phi) and its digamma counterpart are chosen per
-// WAVEFRONT (device) / per cell (host emulation): every lane has y+phi >= 32 (4-term Stirling tails), every lane
-// >= 8 (7-term tails), or some lane has y+phi < 8. Such a lane has y <= 7, so the differences are the exact
-// recurrences  log prod_{k<y}(phi+k)  and  P'/P  -- no Stirling series, no cancellation; the other lanes of
-// that wavefront use the 7-term tails. Every regime costs one logarithm and one reciprocal per cell.
-// The host orders the genes by their smallest count (ppcx_capi.hip, gene_order) so that the lanes of a
-// wavefront mostly agree on the regime.
-PPCX_HD void cell_eval(int y, double u, double phi, double lgphi, double dgphi, const double* tab,
-                       double* T1, double* SP, double* T3, double* T4, double* xsig) {
-  const double x = (double)y + phi;
-  const double w = 1.0 + u;
-  const double sp = table_log(w, tab);
-  *T1 = fma(x, sp, *T1);
-  *SP += sp;
-  double dl, dd;                 // lgamma(y+phi) - lgamma(phi), digamma(y+phi) - digamma(phi)
-  // 1/w and 1/arg from ONE hardware reciprocal: q = 1/(w arg), 1/w = q arg, 1/arg = q w (v_rcp_f64 is quarter rate)
-  if (PPCX_WAVE_ALL(x >= 32.0)) {
-    const double q = fast_rcp(w * x), rx = q * w;
-    *xsig = x * (u * (q * x));
-    double lg, dg;
-    lgamma_digamma_stirling4(x, table_log(x, tab), rx, &lg, &dg);
-    dl = lg - lgphi; dd = dg - dgphi;
-  } else if (PPCX_WAVE_ALL(x >= 8.0)) {
-    const double q = fast_rcp(w * x), rx = q * w;
-    *xsig = x * (u * (q * x));
-    double lg, dg;
-    lgamma_digamma_stirling(x, table_log(x, tab), rx, &lg, &dg);
-    dl = lg - lgphi; dd = dg - dgphi;
-  } else {
-    const bool small = x < 8.0;
-    double P = 1.0, dP = 0.0;    // P = prod_{k<y}(phi+k), dP = dP/dphi  (y = 0: P = 1, dP = 0)
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      if (small && k < y) {
-        const double f = phi + (double)k;
-        dP = fma(dP, f, P);
-        P = P * f;
-      }
-    }
-    const double arg = small ? P : x;
-    const double q = fast_rcp(w * arg), ra = q * w;
-    *xsig = x * (u * (q * arg));
-    const double la = table_log(arg, tab);
-    double lg, dg;
-    lgamma_digamma_stirling(x, la, ra, &lg, &dg);        // meaningful for the lanes with x >= 8 only
-    dl = small ? la : lg - lgphi;
-    dd = small ? dP * ra : dg - dgphi;
-  }
-  *T3 += dl;
-  *T4 += dd;
-}
-
 // everything a gene's lanes need that does not depend on the sample
 template <int CM>
 struct GeneParams {
   double coef[CM];              // intercept, alpha_sub_1, alpha_2...   (zero beyond K, .stan:133-135)
-  double sigma_raw, phi, lgphi, dgphi, A, A1;   // A = exp(intercept + sigma_raw), A1 = A exp(slope) (two-group designs)
+  double sigma_raw, phi, invphi;  // phi = exp(-sigma_raw) (.stan:203), invphi = 1/phi
+  double A, A1;                 // A = exp(intercept + sigma_raw), A1 = A exp(slope) (two-group designs)
+  double dlt, dps;              // Stirling excess of phi (ppcx_math.h stirling_excess)
+  int y8;                       // smallest count with y + phi >= 8 (regimes of the cell loop)
 };
+
+// per-lane partial sums over the cells of one gene (see the header comment for the algebra)
+template <int CM>
+struct CellAcc {
+  double SA;                    // sum y ln(arg)  (+ (sigma_raw + 1) y for the cells with x < 8); arg = rho, or 1/w when x < 8
+  double SL;                    // sum ln(arg)
+  double TL;                    // sum lg_tail(1/x) - dlt over the cells with x >= 8
+  double TD;                    // sum dg_tail(1/x) - dps over the cells with x >= 8, minus sum P'/P over the others
+  double Px; int Pxe;           // running product of xf (x >= 8) and P^-2 (x < 8): mantissa and binary exponent
+  double Sr;                    // sum rho
+  double Tx[CM];                // sum X_sc rho  (paths with a per-cell design row only)
+  PPCX_HD void zero() { SA = SL = TL = TD = Sr = 0.0; Px = 1.0; Pxe = 0;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) Tx[c] = 0.0; }
+  PPCX_HD void renorm() {       // keep the running product's exponent in range: called every few cells
+#if defined(__HIP_DEVICE_COMPILE__)
+    Pxe += __builtin_amdgcn_frexp_exp(Px);
+    Px = __builtin_amdgcn_frexp_mant(Px);
+#else
+    int e; Px = frexp(Px, &e); Pxe += e;
+#endif
+  }
+};
+constexpr int kRenormEvery = 8;  // cells between renormalisations: a factor stays below 2^120 for phi > 2^-89
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PPCX_WAVE_ANY(p) (__any(p) != 0)
+#define PPCX_WAVE_ALL(p) (__all(p) != 0)
+// placed in the rarely taken side of a wave-uniform branch: keeps hipcc from turning the branch into selects that
+// execute both sides for every cell (it does so for short bodies: the renormalisation, the longer Stirling tails)
+#define PPCX_KEEP_BRANCH() asm volatile("" ::: "memory")
+// makes a value opaque at this point, so that what is computed from it in a rarely taken branch stays in that branch
+// instead of being hoisted into registers that the hot loop then has to carry
+#define PPCX_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define PPCX_WAVE_ANY(p) (p)
+#define PPCX_WAVE_ALL(p) (p)
+#define PPCX_KEEP_BRANCH() ((void)0)
+#define PPCX_OPAQUE(x) ((void)0)
+#endif
+
+// One cell once u = exp(t) is known; returns rho = x/(phi w). The per-lane work is free of selects and divisions in the
+// common case: the regime is chosen per WAVEFRONT (device) / per cell (host emulation) -- every lane has y + phi >= 8
+// (Stirling tails), or some lane has y + phi < 8 (such a lane has y <= 7 and takes the exact recurrences while the
+// others keep the tails). Both regimes cost one logarithm and one reciprocal per cell. The host orders the genes by their
+// smallest count (ppcx_capi.hip, gene_order) so that the lanes of a wavefront mostly agree on the regime.
+// An excluded cell enters as (y = 0, u = 0): w = xf = rho = 1, so it adds 0 to every sum but 1 to sum rho, which the
+// close kernel compares with the number of ALL samples (gene_cells).
+template <int CM>
+PPCX_HD double cell_eval(int y, double u, const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& a) {
+  const double yd = (double)y;
+  const double w = 1.0 + u;
+  const double xf = fma(yd, gp.invphi, 1.0);
+  if (PPCX_WAVE_ALL(y >= gp.y8)) {
+    // 1/w and 1/xf from ONE hardware reciprocal: q = 1/(w xf), 1/w = q xf, 1/xf = q w (v_rcp_f64 is quarter rate)
+    const double q = fast_rcp(w * xf), rw = q * xf, rx = (q * w) * gp.invphi;
+    const double rho = xf * rw;
+    const double l = table_log(rho, tab);
+    a.SA = fma(yd, l, a.SA);
+    a.SL += l;
+    a.Px *= xf;
+    const double r2 = rx * rx;
+    double t = fma(r2, 7.72651446721163817e-04, -5.94317590856362882e-04);     // stirling_tails (ppcx_math.h), fused with the sums
+    t = fma(r2, t, 7.93645716111539040e-04);
+    t = fma(r2, t, -2.77777776791245188e-03);
+    t = fma(r2, t, 8.33333333333302478e-02);
+    a.TL = fma(rx, t, a.TL);
+    double dd = fma(r2, 6.82627523986508236e-03, -4.15672846375406482e-03);
+    dd = fma(r2, dd, 3.96819926156938719e-03);
+    dd = fma(r2, dd, -8.33333322714054948e-03);
+    dd = fma(r2, dd, 8.33333333333001886e-02);
+    a.TD = fma(0.5, rx, fma(r2, dd, a.TD));
+    return rho;
+  }
+  PPCX_KEEP_BRANCH();
+  const bool small = y < gp.y8;
+  double P = 1.0, dP = 0.0, f = gp.phi;   // P = prod_{k<y}(phi+k), dP = dP/dphi  (y = 0: P = 1, dP = 0)
+  PPCX_OPAQUE(f);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    if (small && k < y) {
+      dP = fma(dP, f, P);
+      P = P * f;
+    }
+    f += 1.0;
+  }
+  const double arg = small ? P : xf;
+  const double q = fast_rcp(w * arg), rw = q * arg, ra = q * w;
+  const double rho = xf * rw;
+  const double l = table_log(small ? rw : rho, tab);
+  a.SA = fma(yd, small ? l + (gp.sigma_raw + 1.0) : l, a.SA);
+  a.SL += l;
+  a.Px *= small ? ra * ra : xf;
+  double lgt, dgt;
+  stirling_tails(ra * gp.invphi, &lgt, &dgt);            // meaningful for the lanes with x >= 8 only
+  a.TL += small ? gp.dlt : lgt;                          // the lane's sums start at -(its cells) * (dlt, dps): see gene_cells
+  a.TD += small ? gp.dps - dP * ra : dgt;
+  return rho;
+}
+
+// What the log-likelihood kernel hands to the close kernel per gene (sums over the gene's non-excluded cells):
+//   lik = sum [ (y + phi) ln rho - 1/2 ln xf + lg_tail - dlt ]   (the exact-recurrence cells accordingly)
+//   dph = sum [ ln rho - dg_tail + dps ]  = sum [ psi(x) - psi(phi) - ln w ]
+//   Sr  = sum rho,  Tx[c] = sum X_sc rho
+template <int CM>
+struct GeneSumsV { double lik, dph, Sr, Tx[CM]; };
+template <int CM> struct GeneSums { static constexpr int N = 3 + CM; };
+
+// a lane's share of the gene: fold the accumulators of its cells into the hand-over sums
+template <int CM>
+PPCX_HD void cell_acc_close(const GeneParams<CM>& gp, CellAcc<CM>& a, const double* tab, GeneSumsV<CM>* o) {
+  a.renorm();
+  const double lPx = fma((double)a.Pxe, 6.93147180559945286227e-01, table_log(a.Px, tab));
+  o->lik = (a.SA + gp.phi * a.SL) - 0.5 * lPx + a.TL;
+  o->dph = a.SL - a.TD;
+  o->Sr = a.Sr;
+#pragma unroll
+  for (int c = 0; c < CM; ++c) o->Tx[c] = a.Tx[c];
+}
 
 // Result of closing one gene: its log-density contribution, the gradient of its own coordinates and
 // its six contributions to the hyper-parameter gradient sums.
@@ -173,23 +231,24 @@ struct GeneOut {
   double h[6];                  // d/d{lambda_mu, lambda_sigma, lambda_skew, sigma_slope, sigma_intercept, sigma_sigma} (constrained scale)
 };
 
-// Sy, SyE, SyX are the per-gene sufficient statistics; ncell = number of non-excluded cells.
+// Sy, SyE, SyX are the per-gene sufficient statistics over the non-excluded cells; SX[c] = sum of X_sc and ncell =
+// number of ALL samples (an excluded cell enters sum rho as 1 and sum X_sc rho as X_sc, cell_eval).
 template <int CM>
 PPCX_HD void gene_close(const Dims& d, const Hyper& hy, int g, bool has_slopes, const GeneParams<CM>& gp,
-                        const CellAcc<CM>& a, double Sy, double SyE, const double* SyX /*CM*/, double ncell,
-                        double Lg1, GeneOut<CM>* o) {
+                        const GeneSumsV<CM>& a, double Sy, double SyE, const double* SyX /*CM*/, const double* SX /*CM*/,
+                        double ncell, double Lg1, GeneOut<CM>* o) {
   const double SQRT1_2 = 0.70710678118654752440, SQRT_2_OVER_PI = 0.79788456080286535588;
   // ----- likelihood -----
-  double lik = SyE + gp.sigma_raw * Sy - a.T1 + (a.T3 - Lg1);
+  double lik = (SyE - Sy) + (a.lik - Lg1);
 #pragma unroll
   for (int c = 0; c < CM; ++c) {
     o->g_coef[c] = 0.0;
     if (c < d.C && (c == 0 || has_slopes)) {
       lik += gp.coef[c] * SyX[c];
-      o->g_coef[c] = SyX[c] - a.T2x[c];
+      o->g_coef[c] = gp.phi * (a.Tx[c] - SX[c]);           // sum X_sc (y - x u/w) = phi sum X_sc (rho - 1)
     }
   }
-  o->g_sigma_raw = -gp.phi * (a.T4 + ncell - a.SP) + (Sy + ncell * gp.phi) - a.T2u;
+  o->g_sigma_raw = gp.phi * ((a.Sr - ncell) - a.dph);      // -phi d/dphi
   // ----- gene-level priors (.stan:219-223) -----
   const double icpt = gp.coef[0];
   const double z = (icpt - hy.xi) * hy.inv_om;

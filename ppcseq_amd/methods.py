@@ -185,7 +185,7 @@ def identify_outliers(data, formula="~ 1", sample="sample", transcript="transcri
                             approximate_posterior_inference=approximate_posterior_inference,
                             approximate_posterior_analysis=False, cores=cores,
                             adj_prob_theshold=adj_prob_theshold_1, how_many_posterior_draws=draws_1,
-                            seed=seed, model=model)
+                            seed=seed, model=model, pass_fit=pass_fit)
         if just_discovery:
             return res1.to_frame()
         # ---- cells to exclude (R/methods.R:292-300)
@@ -198,7 +198,8 @@ def identify_outliers(data, formula="~ 1", sample="sample", transcript="transcri
                             approximate_posterior_analysis=approximate_posterior_analysis, cores=cores,
                             adj_prob_theshold=adj_prob_theshold_2, how_many_posterior_draws=draws_2,
                             to_exclude=to_exclude, truncation_compensation=0.7352941,
-                            save_generated_quantities=save_generated_quantities, seed=seed, model=model)
+                            save_generated_quantities=save_generated_quantities, seed=seed, model=model,
+                            pass_fit=pass_fit)
     finally:
         model.close()
 
@@ -226,4 +227,6 @@ def identify_outliers(data, formula="~ 1", sample="sample", transcript="transcri
     out.attrs.update(total_draws=res2.total_draws, transcript_column=transcript, abundance_column=abundance,
                      sample_column=sample, formula=formula, seed=seed,
                      diagnostics_discovery=res1.diagnostics, diagnostics_test=res2.diagnostics)
-    return out
+    if pass_fit:                                                           # R/methods.R:353-357: attrs "fit 1" / "fit 2"
+        out.attrs["fit 1"], out.attrs["fit 2"] = res1.fit, res2.fit        # device-resident; the library keeps the model
+    return out                                                             # alive until both fits are closed
