@@ -36,7 +36,9 @@ struct ppcx_model {
   std::vector<int32_t> counts_host;            // original counts (exclusions are re-applied on a copy)
   std::vector<double> X_host, expo_host;
   int* d_counts = nullptr;
-  double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_Lg1 = nullptr;
+  double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_SX = nullptr, *d_ncell = nullptr, *d_Lg1 = nullptr;
+  unsigned* d_low = nullptr; size_t low_cap = 0;   // low-count cell list (ppcx_gene.h gene_cells) and its capacity
+  int *d_low_start = nullptr, *d_nhi = nullptr;
   double* d_logtab = nullptr;
   int* d_order = nullptr;        // gene_order: position in the log-likelihood kernel's launch -> gene
   hipStream_t stream = nullptr;
@@ -137,33 +139,42 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
     if (excl[e] < 0 || excl[e] >= G * S) return fail(PPCX_ERR_ARG, "excluded cell id out of range");
     cnt[excl[e]] = -1;
   }
-  std::vector<double> Sy(G, 0.0), SyE(G, 0.0), SyX((size_t)C * G, 0.0), Lg1(G, 0.0);
+  std::vector<double> Sy(G, 0.0), SyE(G, 0.0), SyX((size_t)C * G, 0.0), SX((size_t)C * G, 0.0), ncell(G, 0.0), Lg1(G, 0.0);
+  std::vector<unsigned> low; std::vector<int> low_start(G + 1, 0), nhi(G, 0);
   for (int g = 0; g < G; ++g) {
-    double sy = 0, sye = 0, lg1 = 0;
+    double sy = 0, sye = 0, nc = 0, lg1 = 0;
+    low_start[g] = (int)low.size();
     for (int s = 0; s < S; ++s) {
       const int y = cnt[(size_t)g * S + s];
       if (y < 0) continue;
-      sy += y; sye += (double)y * m->expo_host[s]; lg1 += lgamma((double)y + 1.0);
-      for (int c = 0; c < C; ++c) SyX[(size_t)c * G + g] += (double)y * m->X_host[(size_t)c * S + s];
+      sy += y; sye += (double)y * m->expo_host[s]; nc += 1.0; lg1 += lgamma((double)y + 1.0);
+      if (y < kLowCount) low.push_back(((unsigned)y << 16) | (unsigned)s); else nhi[g]++;
+      for (int c = 0; c < C; ++c) { SyX[(size_t)c * G + g] += (double)y * m->X_host[(size_t)c * S + s]; SX[(size_t)c * G + g] += m->X_host[(size_t)c * S + s]; }
     }
-    Sy[g] = sy; SyE[g] = sye; Lg1[g] = lg1;
+    Sy[g] = sy; SyE[g] = sye; ncell[g] = nc; Lg1[g] = lg1;
   }
-  // gene_order: the log-likelihood kernel picks its lgamma/digamma regime per wavefront from the smallest
-  // y + phi among its lanes (ppcx_model.h cell_eval), and runs the generic and the intercept-only cell paths one
-  // after the other when a wavefront holds genes of both kinds. So neighbours in the launch should be alike:
-  // genes with slopes first, then by smallest count -- the expensive wavefronts start first, the cheap ones fill the tail.
+  low_start[G] = (int)low.size();
+  low.resize(low.size() + 64, 0u);             // the cell loops request the next entry before testing the range
+  if (low.size() > m->low_cap) {
+    (void)hipFree(m->d_low); m->d_low = nullptr; m->low_cap = 0;
+    HIPCHK(hipMalloc(&m->d_low, sizeof(unsigned) * low.size()));
+    m->low_cap = low.size();
+  }
+  HIPCHK(hipMemcpy(m->d_low, low.data(), sizeof(unsigned) * low.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->d_low_start, low_start.data(), sizeof(int) * (size_t)(G + 1), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->d_nhi, nhi.data(), sizeof(int) * (size_t)G, hipMemcpyHostToDevice));
+  // gene_order: a wavefront holds several genes, runs the plain and the slope cell paths one after the other when it
+  // holds genes of both kinds, and stays in the low-count loop (ppcx_gene.h gene_cells) for as long as its gene with the
+  // longest list needs. So neighbours in the launch should be alike: genes with slopes first, then by the length of
+  // their low-count list, longest first -- the expensive wavefronts start first, the cheap ones fill the tail.
   {
-    std::vector<int> ord(G), miny(G);
-    for (int g = 0; g < G; ++g) {
-      int mn = INT32_MAX;
-      for (int s = 0; s < S; ++s) { const int y = cnt[(size_t)g * S + s]; if (y >= 0 && y < mn) mn = y; }
-      miny[g] = mn; ord[g] = g;
-    }
+    std::vector<int> ord(G);
+    for (int g = 0; g < G; ++g) ord[g] = g;
     const int K = m->d.K;
     std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
       const bool sa = a < K && C >= 2, sb = b < K && C >= 2;
       if (sa != sb) return sa;
-      return miny[a] < miny[b];
+      return low_start[a + 1] - low_start[a] > low_start[b + 1] - low_start[b];
     });
     HIPCHK(hipMemcpy(m->d_order, ord.data(), sizeof(int) * (size_t)G, hipMemcpyHostToDevice));
   }
@@ -171,6 +182,8 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
   HIPCHK(hipMemcpy(m->d_Sy, Sy.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_SyE, SyE.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_SyX, SyX.data(), sizeof(double) * SyX.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->d_SX, SX.data(), sizeof(double) * SX.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->d_ncell, ncell.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_Lg1, Lg1.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   return PPCX_OK;
 }
@@ -221,6 +234,10 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   MHIP(hipMalloc(&m->d_Sy, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_SyE, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_SyX, sizeof(double) * (size_t)C * G));
+  MHIP(hipMalloc(&m->d_SX, sizeof(double) * (size_t)C * G));
+  MHIP(hipMalloc(&m->d_ncell, sizeof(double) * G));
+  MHIP(hipMalloc(&m->d_low_start, sizeof(int) * (size_t)(G + 1)));
+  MHIP(hipMalloc(&m->d_nhi, sizeof(int) * (size_t)G));
   MHIP(hipMalloc(&m->d_Lg1, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_logtab, sizeof(double) * 2 * kLogTabSize));
   { double tab[2 * kLogTabSize]; fill_log_table(tab); MHIP(hipMemcpy(m->d_logtab, tab, sizeof(tab), hipMemcpyHostToDevice)); }
@@ -259,7 +276,7 @@ extern "C" void ppcx_model_destroy(ppcx_model* m) {
   if (m->live_fits > 0) { m->destroy_requested = true; return; }   // freed by the last ppcx_fit_free
   (void)hipSetDevice(m->device);
   (void)hipFree(m->d_counts); (void)hipFree(m->d_E); (void)hipFree(m->d_expo); (void)hipFree(m->d_X);
-  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_order);
+  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_SX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_low); (void)hipFree(m->d_low_start); (void)hipFree(m->d_nhi); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_order);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -358,7 +375,7 @@ static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
 }
 static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
   LoglikArgs la;
-  la.d = m->d; la.counts = m->d_counts; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
+  la.d = m->d; la.counts = m->d_counts; la.low = m->d_low; la.low_start = m->d_low_start; la.n_hi = m->d_nhi; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
   la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order; la.lgL = 0; while ((1 << la.lgL) < m->L) ++la.lgL; la.nb0 = m->nb0; la.G0 = m->G0; la.nb1 = m->nb1;
   hipError_t e = launch_loglik_kernel(m->CM, la, m->nblocks, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("loglik kernel: ") + hipGetErrorString(e));
@@ -366,8 +383,7 @@ static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
 }
 static int launch_close(ppcx_model* m, Work& w, int nchains) {
   CloseArgs ca;
-  ca.d = m->d; ca.Sy = m->d_Sy; ca.SyE = m->d_SyE; ca.SyX = m->d_SyX; ca.Lg1 = m->d_Lg1;
-  for (int c = 0; c < kMaxC; ++c) { ca.SXall[c] = 0.0; if (c < m->d.C) for (int s = 0; s < m->d.S; ++s) ca.SXall[c] += m->X_host[(size_t)c * m->d.S + s]; }
+  ca.d = m->d; ca.Sy = m->d_Sy; ca.SyE = m->d_SyE; ca.SyX = m->d_SyX; ca.SX = m->d_SX; ca.ncell = m->d_ncell; ca.Lg1 = m->d_Lg1;
   ca.sums = w.sums; ca.vecs = w.vecs; ca.Dpad = w.Dpad; ca.cmds = w.cmds[w.launches & 1]; ca.partials = w.partials;
   hipError_t e = launch_close_kernel(m->CM, ca, w.nb_close, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("close kernel: ") + hipGetErrorString(e));

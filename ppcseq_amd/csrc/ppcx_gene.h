@@ -42,7 +42,7 @@ PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, Gene
   for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < C) ? q[cc + 1] : 0.0;
   x.gp.sigma_raw = q[1];
   x.gp.phi = fast_exp(-x.gp.sigma_raw);        // sigma = 1 ./ exp(sigma_raw)   (.stan:203)
-  x.gp.invphi = 0.0; x.gp.dlt = 0.0; x.gp.dps = 0.0; x.gp.A = 0.0; x.gp.A1 = 0.0; x.gp.y8 = 0;
+  x.gp.invphi = 0.0; x.gp.dlt = 0.0; x.gp.dps = 0.0; x.gp.A = 0.0; x.gp.A1 = 0.0;
 }
 // the per-gene constants of the cell loop
 template <int CM>
@@ -50,30 +50,23 @@ PPCX_HD void gene_consts(GeneCtx<CM>& x, const double* tab) {
   GeneParams<CM>& gp = x.gp;
   gp.invphi = fast_rcp(gp.phi);
   stirling_excess(gp.phi, -gp.sigma_raw, tab, PPCX_WAVE_ANY(gp.phi < 8.0), &gp.dlt, &gp.dps);
-  // y + phi >= 8  <=>  y >= ceil(8 - phi) for an integer y; phi >= 8: every count qualifies
-  const double c8 = ceil(8.0 - gp.phi);
-  gp.y8 = c8 > 0.0 ? (int)c8 : 0;
   gp.A = fast_exp(gp.coef[0] + gp.sigma_raw);
   if (PPCX_WAVE_ANY(x.two)) gp.A1 = fast_exp(gp.coef[0] + gp.coef[1] + gp.sigma_raw);
 }
 
-// the cells s = sub, sub+L, ... of the gene's row of counts. An excluded cell (count < 0) is evaluated as (y = 0,
-// u = 0), which adds nothing to the sums except 1 to sum rho and X_sc to sum X_sc rho (cell_eval); the close kernel
-// therefore compares those two with their totals over ALL samples.
-// The Stirling-excess terms of phi are charged up front for every cell of the lane and given back by the cells that do
-// not use them (the exact-recurrence cells in cell_eval), so the common path carries no bookkeeping.
-// `row` and `sE` must be readable up to L entries past S: the count and the sample constant of the next cell are
-// requested unconditionally before this cell is evaluated (the host pads the arrays).
+// The gene's cells, split over its L lanes: (1) the row sweep s = sub, sub+L, ... evaluates the cells with y >= 8 --
+// one regime, straight-line code; cells with smaller or excluded (-1) counts are passed over; (2) the gene's low-count
+// list (0 <= y <= 7; entries (y << 16) | s, built by the host in sample order) goes through cell_eval_low.
+// `row`, `sE`, `sX` and `low` must be readable up to L entries past their end: the next cell is requested
+// unconditionally before the current one is evaluated (the host pads the arrays).
+constexpr int kLowCount = 8;     // counts below this are list cells
 template <int CM>
-PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, const double* sE, const double* sExpo,
-                        const double* sX, const double* tab, int sub, int L, CellAcc<CM>& acc) {
+PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, const unsigned* low, int low_n,
+                        const double* sE, const double* sExpo, const double* sX, const double* tab, int sub, int L,
+                        CellAcc<CM>& acc) {
   const int S = d.S, C = d.C;
   const GeneParams<CM>& gp = x.gp;
   if (!x.active) return;
-  {
-    const double ncells = sub < S ? (double)((S - sub + L - 1) / L) : 0.0;
-    acc.TL = -ncells * gp.dlt; acc.TD = -ncells * gp.dps;
-  }
   int it = 0;
   if (x.fast) {
     int s = sub;
@@ -81,12 +74,17 @@ PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, con
     double en = sE[s];
     if (!PPCX_WAVE_ANY(x.two)) {
       while (s < S) {
-        const bool ex = yn < 0;
-        const int y = ex ? 0 : yn;
-        const double e = ex ? 0.0 : en;
+        const int y = yn;
+        const double e = en;
         s += L;
         yn = row[s]; en = sE[s];
-        acc.Sr += cell_eval<CM>(y, e * gp.A, gp, tab, acc);
+        if (y >= kLowCount) (void)cell_eval<CM>(y, e, gp.A, gp, tab, acc);
+        if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
+      }
+      for (int i = sub; i < low_n; i += L) {
+        const unsigned en2 = low[i];
+        const int sl = (int)(en2 & 0xffffu);
+        (void)cell_eval_low<CM>((int)(en2 >> 16), sE[sl], gp.A, gp, tab, acc);
         if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
       }
     } else {
@@ -94,28 +92,37 @@ PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, con
       const double* sX1 = sX + S;
       double xn = sX1[s];
       while (s < S) {
-        const bool ex = yn < 0;
-        const int y = ex ? 0 : yn;
-        const double e = ex ? 0.0 : en, xb = xn;
+        const int y = yn;
+        const double e = en, xb = xn;
         s += L;
         yn = row[s]; en = sE[s]; xn = sX1[s];
-        const double rho = cell_eval<CM>(y, e * ((x.two && xb != 0.0) ? gp.A1 : gp.A), gp, tab, acc);
-        acc.Sr += rho;
+        if (y >= kLowCount) {
+          const double rho = cell_eval<CM>(y, e, (x.two && xb != 0.0) ? gp.A1 : gp.A, gp, tab, acc);
+          acc.Tx[1] = fma(xb, rho, acc.Tx[1]);
+        }
+        if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
+      }
+      for (int i = sub; i < low_n; i += L) {
+        const unsigned en2 = low[i];
+        const int sl = (int)(en2 & 0xffffu);
+        const double xb = sX1[sl];
+        const double rho = cell_eval_low<CM>((int)(en2 >> 16), sE[sl], (x.two && xb != 0.0) ? gp.A1 : gp.A, gp, tab, acc);
         acc.Tx[1] = fma(xb, rho, acc.Tx[1]);
         if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
       }
     }
   } else {
     for (int s = sub; s < S; s += L) {
-      const int yr = row[s];
-      const bool ex = yr < 0;
-      double t = sExpo[s] + gp.sigma_raw;
+      const int y = row[s];
+      if (y >= 0) {
+        double t = sExpo[s] + gp.sigma_raw;
 #pragma unroll
-      for (int cc = 0; cc < CM; ++cc) if (cc < C) t += sX[cc * S + s] * gp.coef[cc];
-      const double rho = cell_eval<CM>(ex ? 0 : yr, ex ? 0.0 : fast_exp(t), gp, tab, acc);
-      acc.Sr += rho;
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) t += sX[cc * S + s] * gp.coef[cc];
+        const double u = fast_exp(t);
+        const double rho = y >= kLowCount ? cell_eval<CM>(y, u, 1.0, gp, tab, acc) : cell_eval_low<CM>(y, u, 1.0, gp, tab, acc);
 #pragma unroll
-      for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.Tx[cc] = fma(sX[cc * S + s], rho, acc.Tx[cc]);
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.Tx[cc] = fma(sX[cc * S + s], rho, acc.Tx[cc]);
+      }
       if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
     }
   }
@@ -124,7 +131,7 @@ PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, con
 // close the gene with its reduced sums: gradient, second half kick, stores, partial sums part[0..9]
 template <int CM>
 PPCX_HD void gene_finish(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, GeneSumsV<CM>& acc,
-                         const double* Sy, const double* SyE, const double* SyXg, const double* SXall,
+                         const double* Sy, const double* SyE, const double* SyXg, const double* SXg, const double* ncell,
                          const double* Lg1, double* part, double* pn, double* minv) {
   constexpr int NCM = CM + 1;
   if (x.fast) acc.Tx[0] = acc.Sr;               // X[,1] == 1
@@ -132,10 +139,10 @@ PPCX_HD void gene_finish(const Dims& d, const Cmd& c, const VecRef& v, const Gen
 #pragma unroll
   for (int cc = 0; cc < CM; ++cc) {
     SyX[cc] = (cc < d.C) ? SyXg[(long)cc * d.G + x.gg] : 0.0;
-    SX[cc] = (cc < d.C) ? SXall[cc] : 0.0;        // sum over ALL samples of X_sc: excluded cells add X_sc to sum X_sc rho
+    SX[cc] = (cc < d.C) ? SXg[(long)cc * d.G + x.gg] : 0.0;
   }
   GeneOut<CM> go;
-  gene_close<CM>(d, c.hy, x.gg, x.has_slopes, x.gp, acc, Sy[x.gg], SyE[x.gg], SyX, SX, (double)d.S, Lg1[x.gg], &go);
+  gene_close<CM>(d, c.hy, x.gg, x.has_slopes, x.gp, acc, Sy[x.gg], SyE[x.gg], SyX, SX, ncell[x.gg], Lg1[x.gg], &go);
 #pragma unroll
   for (int k = 0; k < 10; ++k) part[k] = 0.0;
   bool bad = false;

@@ -8,6 +8,9 @@ namespace ppcx {
 struct LoglikArgs {
   Dims d;
   const int* counts;            // G x S gene-major, excluded cells = -1
+  const unsigned* low;          // the cells with 0 <= count <= 7, gene after gene: (count << 16) | sample
+  const int* low_start;         // [G + 1] a gene's range in `low`
+  const int* n_hi;              // [G] number of cells with count >= 8
   const double* sampleE;        // exp(exposure_s)
   const double* exposure;       // S
   const double* X;              // S x C column-major
@@ -27,7 +30,8 @@ struct CloseArgs {
   const double* Sy;             // per-gene sufficient statistics over non-excluded cells
   const double* SyE;
   const double* SyX;            // [C][G]
-  double SXall[kMaxC];          // sum over ALL samples of X_sc
+  const double* SX;             // [C][G] sum of X_sc over the gene's non-excluded cells
+  const double* ncell;          // [G] number of non-excluded cells
   const double* Lg1;            // per-gene sum of lgamma(y+1)
   const double* sums;
   double* vecs; long Dpad;

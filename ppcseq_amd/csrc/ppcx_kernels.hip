@@ -88,9 +88,10 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
     if (grp != gblock * 4 + wave) { const int p = grp * GPW + gl; gene_load<CM>(d, c, v, p < npos ? a.order[pos0 + p] : d.G, x); }
     gene_consts<CM>(x, stab);
     CellAcc<CM> acc; acc.zero();
-    gene_cells<CM>(d, x, a.counts + (long)x.gg * S, sE, sExpo, sX, stab, sub, L, acc);
+    const int lo = a.low_start[x.gg];
+    gene_cells<CM>(d, x, a.counts + (long)x.gg * S, a.low + lo, a.low_start[x.gg + 1] - lo, sE, sExpo, sX, stab, sub, L, acc);
     GeneSumsV<CM> o;
-    cell_acc_close<CM>(x.gp, acc, stab, &o);
+    cell_acc_close<CM>(x.gp, acc, stab, sub == 0 ? (double)a.n_hi[x.gg] : 0.0, &o);
     // L-lane butterfly: every lane of the gene ends with the gene totals
     for (int msk = 1; msk < L; msk <<= 1) {
       o.lik = wave_xor_add_rt(o.lik, msk); o.dph = wave_xor_add_rt(o.dph, msk); o.Sr = wave_xor_add_rt(o.Sr, msk);
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
     }
   }
   double pn[NCM], minv[NCM], part[10];
-  gene_finish<CM>(d, c, v, x, acc, a.Sy, a.SyE, a.SyX, a.SXall, a.Lg1, part, pn, minv);
+  gene_finish<CM>(d, c, v, x, acc, a.Sy, a.SyE, a.SyX, a.SX, a.ncell, a.Lg1, part, pn, minv);
   block_accumulate<10>(part, wacc, wave, lane);
   if (c.type == CMD_LEAF) {
     NodeVals nv[NCM];

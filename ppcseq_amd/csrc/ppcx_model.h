@@ -22,8 +22,11 @@
 //     with the same instruction stream: the logarithm's argument is 1/w instead of rho, the product takes P^-2;
 //   * for genes without slope terms (g >= K, X[,1] == 1) exp(t) factorises into E_s * A_g with
 //     E_s = exp(exposure_s) staged in LDS and A_g = exp(intercept_g + sigma_raw_g): no per-cell exp;
-//   * excluded cells (to_exclude, R/utilities.R:321-359, subtracted at .stan:105-115) are stored as
-//     count = -1 and skipped, and are left out of the sufficient statistics.
+//   * the row sweep evaluates only the cells with y >= 8 (then x >= 8 whatever phi is: one regime, no test); the cells
+//     with 0 <= y <= 7 are kept in a per-gene list built at upload and evaluated by a second, short loop that chooses
+//     per lane between the recurrences and the tails;
+//   * excluded cells (to_exclude, R/utilities.R:321-359, subtracted at .stan:105-115) are stored as count = -1, are in
+//     neither loop, and are left out of the sufficient statistics.
 #pragma once
 #include "ppcx_math.h"
 
@@ -100,7 +103,6 @@ struct GeneParams {
   double sigma_raw, phi, invphi;  // phi = exp(-sigma_raw) (.stan:203), invphi = 1/phi
   double A, A1;                 // A = exp(intercept + sigma_raw), A1 = A exp(slope) (two-group designs)
   double dlt, dps;              // Stirling excess of phi (ppcx_math.h stirling_excess)
-  int y8;                       // smallest count with y + phi >= 8 (regimes of the cell loop)
 };
 
 // per-lane partial sums over the cells of one gene (see the header comment for the algebra)
@@ -108,8 +110,9 @@ template <int CM>
 struct CellAcc {
   double SA;                    // sum y ln(arg)  (+ (sigma_raw + 1) y for the cells with x < 8); arg = rho, or 1/w when x < 8
   double SL;                    // sum ln(arg)
-  double TL;                    // sum lg_tail(1/x) - dlt over the cells with x >= 8
-  double TD;                    // sum dg_tail(1/x) - dps over the cells with x >= 8, minus sum P'/P over the others
+  double TL;                    // sum lg_tail(1/x) over the cells with x >= 8 (the row sweep leaves their - dlt to the gene's
+                                // epilogue, which knows their number; the low-count loop subtracts it per cell)
+  double TD;                    // sum dg_tail(1/x) over the cells with x >= 8 (- dps likewise), minus sum P'/P over the others
   double Px; int Pxe;           // running product of xf (x >= 8) and P^-2 (x < 8): mantissa and binary exponent
   double Sr;                    // sum rho
   double Tx[CM];                // sum X_sc rho  (paths with a per-cell design row only)
@@ -143,43 +146,127 @@ constexpr int kRenormEvery = 8;  // cells between renormalisations: a factor sta
 #define PPCX_OPAQUE(x) ((void)0)
 #endif
 
-// One cell once u = exp(t) is known; returns rho = x/(phi w). The per-lane work is free of selects and divisions in the
-// common case: the regime is chosen per WAVEFRONT (device) / per cell (host emulation) -- every lane has y + phi >= 8
-// (Stirling tails), or some lane has y + phi < 8 (such a lane has y <= 7 and takes the exact recurrences while the
-// others keep the tails). Both regimes cost one logarithm and one reciprocal per cell. The host orders the genes by their
-// smallest count (ppcx_capi.hip, gene_order) so that the lanes of a wavefront mostly agree on the regime.
-// An excluded cell enters as (y = 0, u = 0): w = xf = rho = 1, so it adds 0 to every sum but 1 to sum rho, which the
-// close kernel compares with the number of ALL samples (gene_cells).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PPCX_NO_ASM_CELL)
+// The common regime of cell_eval on the device, written as three register-only blocks of gfx950 instructions (no
+// memory operation and no wait inside: the table reads between them are the compiler's). hipcc's own code for the same
+// C++ (cell_eval below, which the host emulation runs) spends 62 vector issue slots on it -- every Horner step of the
+// polynomials becomes a register copy plus v_fmac, and the joins of the regime branches add more copies; this is 41:
+// one v_fma per Horner step with the coefficient in an SGPR pair (a VOP3 instruction may read one SGPR operand, so the
+// first step's second coefficient sits in a VGPR). v_rcp_f64 is a transcendental-unit instruction: the instruction after it
+// must not read its result (one wait state on gfx940-class chips), hence the independent product update there.
 template <int CM>
-PPCX_HD double cell_eval(int y, double u, const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& a) {
-  const double yd = (double)y;
-  const double w = 1.0 + u;
-  const double xf = fma(yd, gp.invphi, 1.0);
-  if (PPCX_WAVE_ALL(y >= gp.y8)) {
-    // 1/w and 1/xf from ONE hardware reciprocal: q = 1/(w xf), 1/w = q xf, 1/xf = q w (v_rcp_f64 is quarter rate)
-    const double q = fast_rcp(w * xf), rw = q * xf, rx = (q * w) * gp.invphi;
-    const double rho = xf * rw;
-    const double l = table_log(rho, tab);
-    a.SA = fma(yd, l, a.SA);
-    a.SL += l;
-    a.Px *= xf;
-    const double r2 = rx * rx;
-    double t = fma(r2, 7.72651446721163817e-04, -5.94317590856362882e-04);     // stirling_tails (ppcx_math.h), fused with the sums
-    t = fma(r2, t, 7.93645716111539040e-04);
-    t = fma(r2, t, -2.77777776791245188e-03);
-    t = fma(r2, t, 8.33333333333302478e-02);
-    a.TL = fma(rx, t, a.TL);
-    double dd = fma(r2, 6.82627523986508236e-03, -4.15672846375406482e-03);
-    dd = fma(r2, dd, 3.96819926156938719e-03);
-    dd = fma(r2, dd, -8.33333322714054948e-03);
-    dd = fma(r2, dd, 8.33333333333001886e-02);
-    a.TD = fma(0.5, rx, fma(r2, dd, a.TD));
-    return rho;
+__device__ __forceinline__ double cell_big_dev(int y, double e, double A, const GeneParams<CM>& gp, const double* tab,
+                                               CellAcc<CM>& a) {
+  double yd, w, xf, r2, rx, rho;
+  asm("v_cvt_f64_u32_e32 %[yd], %[y]\n\t"
+      "v_fma_f64 %[w], %[e], %[A], 1.0\n\t"
+      "v_fma_f64 %[xf], %[yd], %[ip], 1.0\n\t"
+      "v_mul_f64 %[r2], %[w], %[xf]\n\t"             // m = w xf
+      "v_rcp_f64_e32 %[rx], %[r2]\n\t"               // q ~ 1/m
+      "s_nop 0\n\t"                                  // transcendental result: one wait state before its first reader
+      "v_fma_f64 %[r2], -%[r2], %[rx], 1.0\n\t"      // 1 - m q
+      "v_fma_f64 %[rx], %[rx], %[r2], %[rx]\n\t"     // q (one Newton step)
+      "v_mul_f64 %[r2], %[rx], %[xf]\n\t"            // 1/w = q xf
+      "v_mul_f64 %[rx], %[rx], %[w]\n\t"             // 1/xf = q w
+      "v_mul_f64 %[rho], %[xf], %[r2]\n\t"           // rho = xf/w
+      "v_mul_f64 %[rx], %[rx], %[ip]\n\t"            // 1/x = (1/xf)(1/phi)
+      "v_mul_f64 %[r2], %[rx], %[rx]"
+      : [yd] "=&v"(yd), [w] "=&v"(w), [xf] "=&v"(xf), [r2] "=&v"(r2), [rx] "=&v"(rx), [rho] "=&v"(rho)
+      : [y] "v"(y), [e] "v"(e), [A] "v"(A), [ip] "v"(gp.invphi));
+  const int j = (int)(dbl_bits(rho) >> (52 - kLogTabBits)) & (kLogTabSize - 1);
+  const double cinv = tab[j], logc = tab[kLogTabSize + j];
+  __builtin_amdgcn_sched_barrier(0);     // the table reads are issued here, before the tails: their latency hides behind those
+  a.Sr += rho;
+  a.Px *= xf;
+  double t, d;
+  {
+    const double F3 = -5.94317590856362882e-04, G3 = -4.15672846375406482e-03;
+    asm("v_fma_f64 %[t], %[r2], %[F4], %[F3]\n\t"
+        "v_fma_f64 %[d], %[r2], %[G4], %[G3]\n\t"
+        "v_fma_f64 %[t], %[r2], %[t], %[F2]\n\t"
+        "v_fma_f64 %[d], %[r2], %[d], %[G2]\n\t"
+        "v_fma_f64 %[t], %[r2], %[t], %[F1]\n\t"
+        "v_fma_f64 %[d], %[r2], %[d], %[G1]\n\t"
+        "v_fma_f64 %[t], %[r2], %[t], %[F0]\n\t"
+        "v_fma_f64 %[d], %[r2], %[d], %[G0]"
+        : [t] "=&v"(t), [d] "=&v"(d)
+        : [r2] "v"(r2), [F3] "v"(F3), [G3] "v"(G3),
+          [F4] "s"(7.72651446721163817e-04), [F2] "s"(7.93645716111539040e-04), [F1] "s"(-2.77777776791245188e-03),
+          [F0] "s"(8.33333333333302478e-02), [G4] "s"(6.82627523986508236e-03), [G2] "s"(3.96819926156938719e-03),
+          [G1] "s"(-8.33333322714054948e-03), [G0] "s"(8.33333333333001886e-02));
   }
-  PPCX_KEEP_BRANCH();
-  const bool small = y < gp.y8;
+  a.TL = fma(rx, t, a.TL);
+  a.TD = fma(r2, d, a.TD);
+  a.TD = fma(0.5, rx, a.TD);
+  double l;
+  {
+    double m, ed; int ex;
+    const double L4 = -0.25;
+    asm("v_frexp_mant_f64_e32 %[m], %[rho]\n\t"
+        "v_frexp_exp_i32_f64_e32 %[ex], %[rho]\n\t"
+        "v_fma_f64 %[m], %[m], %[cinv], -1.0\n\t"      // r = m/c - 1
+        "v_cvt_f64_i32_e32 %[ed], %[ex]\n\t"
+        "v_fma_f64 %[p], %[m], %[L5], %[L4]\n\t"       // log1p(r) = r (1 - r/2 + r^2/3 - r^3/4 + r^4/5)
+        "v_fma_f64 %[p], %[m], %[p], %[L3]\n\t"
+        "v_fma_f64 %[p], %[m], %[p], -0.5\n\t"
+        "v_fma_f64 %[p], %[m], %[p], 1.0\n\t"
+        "v_fma_f64 %[p], %[m], %[p], %[logc]\n\t"
+        "v_fma_f64 %[p], %[ed], %[LN2], %[p]"            // l = ln rho
+        : [m] "=&v"(m), [ex] "=&v"(ex), [ed] "=&v"(ed), [p] "=&v"(l)
+        : [rho] "v"(rho), [cinv] "v"(cinv), [logc] "v"(logc), [L4] "v"(L4),
+          [L5] "s"(0.2), [L3] "s"(1.0 / 3.0), [LN2] "s"(6.93147180559945286227e-01));
+  }
+  a.SA = fma(yd, l, a.SA);
+  a.SL += l;
+  return rho;
+}
+#endif
+
+// One cell of the row sweep (count y >= 8, hence x = y + phi >= 8 for every phi) with e^t = e A: adds the cell to the
+// sums and returns rho = x/(phi w). Straight-line code: one logarithm, one reciprocal, the two tails.
+template <int CM>
+PPCX_HD double cell_eval(int y, double e, double A, const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PPCX_NO_ASM_CELL)
+  return cell_big_dev<CM>(y, e, A, gp, tab, a);
+#else
+  const double yd = (double)y;
+  const double w = fma(e, A, 1.0);
+  const double xf = fma(yd, gp.invphi, 1.0);
+  // 1/w and 1/xf from ONE hardware reciprocal: q = 1/(w xf), 1/w = q xf, 1/xf = q w (v_rcp_f64 is quarter rate)
+  const double q = fast_rcp(w * xf), rw = q * xf, rx = (q * w) * gp.invphi;
+  const double rho = xf * rw;
+  const double l = table_log(rho, tab);
+  a.SA = fma(yd, l, a.SA);
+  a.SL += l;
+  a.Sr += rho;
+  a.Px *= xf;
+  const double r2 = rx * rx;
+  double t = fma(r2, 7.72651446721163817e-04, -5.94317590856362882e-04);     // stirling_tails (ppcx_math.h), fused with the sums
+  t = fma(r2, t, 7.93645716111539040e-04);
+  t = fma(r2, t, -2.77777776791245188e-03);
+  t = fma(r2, t, 8.33333333333302478e-02);
+  a.TL = fma(rx, t, a.TL);
+  double dd = fma(r2, 6.82627523986508236e-03, -4.15672846375406482e-03);
+  dd = fma(r2, dd, 3.96819926156938719e-03);
+  dd = fma(r2, dd, -8.33333322714054948e-03);
+  dd = fma(r2, dd, 8.33333333333001886e-02);
+  a.TD = fma(0.5, rx, fma(r2, dd, a.TD));
+  return rho;
+#endif
+}
+
+// One cell of the low-count list (0 <= y <= 7). Per lane: x = y + phi < 8 takes the exact recurrences
+//   lgamma(x) - lgamma(phi) = ln P, P = prod_{k<y}(phi+k);  psi(x) - psi(phi) = P'/P
+// with the same instruction stream as the Stirling form -- the logarithm's argument is 1/w instead of rho, the product
+// takes P^-2, and y (sigma_raw + 1) makes up for the terms the analytic cancellation assumed -- otherwise (phi > 8 - y)
+// the tails as in cell_eval, with the Stirling excess of phi subtracted here, per cell.
+template <int CM>
+PPCX_HD double cell_eval_low(int y, double e, double A, const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& a) {
+  const double yd = (double)y;
+  const double w = fma(e, A, 1.0);
+  const double xf = fma(yd, gp.invphi, 1.0);
+  const bool small = yd + gp.phi < 8.0;
   double P = 1.0, dP = 0.0, f = gp.phi;   // P = prod_{k<y}(phi+k), dP = dP/dphi  (y = 0: P = 1, dP = 0)
-  PPCX_OPAQUE(f);
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
     if (small && k < y) {
@@ -194,11 +281,12 @@ PPCX_HD double cell_eval(int y, double u, const GeneParams<CM>& gp, const double
   const double l = table_log(small ? rw : rho, tab);
   a.SA = fma(yd, small ? l + (gp.sigma_raw + 1.0) : l, a.SA);
   a.SL += l;
+  a.Sr += rho;
   a.Px *= small ? ra * ra : xf;
   double lgt, dgt;
   stirling_tails(ra * gp.invphi, &lgt, &dgt);            // meaningful for the lanes with x >= 8 only
-  a.TL += small ? gp.dlt : lgt;                          // the lane's sums start at -(its cells) * (dlt, dps): see gene_cells
-  a.TD += small ? gp.dps - dP * ra : dgt;
+  a.TL += small ? 0.0 : lgt - gp.dlt;
+  a.TD += small ? -dP * ra : dgt - gp.dps;
   return rho;
 }
 
@@ -210,10 +298,14 @@ template <int CM>
 struct GeneSumsV { double lik, dph, Sr, Tx[CM]; };
 template <int CM> struct GeneSums { static constexpr int N = 3 + CM; };
 
-// a lane's share of the gene: fold the accumulators of its cells into the hand-over sums
+// a lane's share of the gene: fold the accumulators of its cells into the hand-over sums. The Stirling excess of phi
+// that every cell of the row sweep owes (n_hi = their number in the whole gene) is added by ONE lane of the gene.
 template <int CM>
-PPCX_HD void cell_acc_close(const GeneParams<CM>& gp, CellAcc<CM>& a, const double* tab, GeneSumsV<CM>* o) {
+PPCX_HD void cell_acc_close(const GeneParams<CM>& gp, CellAcc<CM>& a, const double* tab, double n_hi_if_first_lane,
+                            GeneSumsV<CM>* o) {
   a.renorm();
+  a.TL = fma(-n_hi_if_first_lane, gp.dlt, a.TL);
+  a.TD = fma(-n_hi_if_first_lane, gp.dps, a.TD);
   const double lPx = fma((double)a.Pxe, 6.93147180559945286227e-01, table_log(a.Px, tab));
   o->lik = (a.SA + gp.phi * a.SL) - 0.5 * lPx + a.TL;
   o->dph = a.SL - a.TD;
@@ -231,8 +323,7 @@ struct GeneOut {
   double h[6];                  // d/d{lambda_mu, lambda_sigma, lambda_skew, sigma_slope, sigma_intercept, sigma_sigma} (constrained scale)
 };
 
-// Sy, SyE, SyX are the per-gene sufficient statistics over the non-excluded cells; SX[c] = sum of X_sc and ncell =
-// number of ALL samples (an excluded cell enters sum rho as 1 and sum X_sc rho as X_sc, cell_eval).
+// Sy, SyE, SyX are the per-gene sufficient statistics; SX[c] = sum of X_sc and ncell = number of non-excluded cells.
 template <int CM>
 PPCX_HD void gene_close(const Dims& d, const Hyper& hy, int g, bool has_slopes, const GeneParams<CM>& gp,
                         const GeneSumsV<CM>& a, double Sy, double SyE, const double* SyX /*CM*/, const double* SX /*CM*/,

@@ -14,7 +14,8 @@ static const double* log_table() { static double t[2 * kLogTabSize]; static bool
 
 struct EmulModel {
   Dims d; int CM;
-  std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, SXall, Lg1;
+  std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, SX, ncell, Lg1;
+  std::vector<unsigned> low; std::vector<int> low_start, nhi;
 };
 
 static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, const double* X, const double* expo,
@@ -30,13 +31,16 @@ static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, c
   int x1b = (C == 2);
   for (int s = 0; s < S && x1b; ++s) if (X[(size_t)S + s] != 0.0 && X[(size_t)S + s] != 1.0) x1b = 0;
   m.d.x1_binary = x1b;
-  m.Sy.assign(G, 0); m.SyE.assign(G, 0); m.SyX.assign((size_t)C * G, 0); m.SXall.assign(kMaxC, 0); m.Lg1.assign(G, 0);
-  for (int c = 0; c < C; ++c) for (int s = 0; s < S; ++s) m.SXall[c] += X[(size_t)c * S + s];
-  for (int g = 0; g < G; ++g) for (int s = 0; s < S; ++s) {
+  m.Sy.assign(G, 0); m.SyE.assign(G, 0); m.SyX.assign((size_t)C * G, 0); m.SX.assign((size_t)C * G, 0); m.ncell.assign(G, 0); m.Lg1.assign(G, 0);
+  m.low_start.assign(G + 1, 0); m.nhi.assign(G, 0);
+  for (int g = 0; g < G; ++g) { m.low_start[g] = (int)m.low.size(); for (int s = 0; s < S; ++s) {
     int y = m.counts[(size_t)g * S + s]; if (y < 0) continue;
-    m.Sy[g] += y; m.SyE[g] += (double)y * expo[s]; m.Lg1[g] += lgamma((double)y + 1.0);
-    for (int c = 0; c < C; ++c) m.SyX[(size_t)c * G + g] += (double)y * X[(size_t)c * S + s];
-  }
+    if (y < kLowCount) m.low.push_back(((unsigned)y << 16) | (unsigned)s); else m.nhi[g]++;
+    m.Sy[g] += y; m.SyE[g] += (double)y * expo[s]; m.ncell[g] += 1; m.Lg1[g] += lgamma((double)y + 1.0);
+    for (int c = 0; c < C; ++c) { m.SyX[(size_t)c * G + g] += (double)y * X[(size_t)c * S + s]; m.SX[(size_t)c * G + g] += X[(size_t)c * S + s]; }
+  } }
+  m.low_start[G] = (int)m.low.size();
+  m.low.resize(m.low.size() + 64, 0u);
   return m;
 }
 
@@ -52,14 +56,15 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
     gene_load<CM>(d, c, v, g, x);
     gene_consts<CM>(x, log_table());
     CellAcc<CM> acc; acc.zero();
-    gene_cells<CM>(d, x, m.counts.data() + (size_t)g * d.S, m.E.data(), m.expo.data(), m.X.data(), log_table(), 0, 1, acc);
+    gene_cells<CM>(d, x, m.counts.data() + (size_t)g * d.S, m.low.data() + m.low_start[g], m.low_start[g + 1] - m.low_start[g],
+                   m.E.data(), m.expo.data(), m.X.data(), log_table(), 0, 1, acc);
     GeneSumsV<CM> o;
-    cell_acc_close<CM>(x.gp, acc, log_table(), &o);
+    cell_acc_close<CM>(x.gp, acc, log_table(), (double)m.nhi[g], &o);
     // close kernel
     GeneCtx<CM> x2;
     gene_load<CM>(d, c, v, g, x2);
     double pn[NCM], minv[NCM], part[10];
-    gene_finish<CM>(d, c, v, x2, o, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.SXall.data(), m.Lg1.data(), part, pn, minv);
+    gene_finish<CM>(d, c, v, x2, o, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.SX.data(), m.ncell.data(), m.Lg1.data(), part, pn, minv);
     for (int k = 0; k < 10; ++k) red[k] += part[k];
     if (c.type == CMD_LEAF) {
       NodeVals nv[NCM];
