@@ -71,7 +71,7 @@ def load() -> C.CDLL:
     lib.ppcx_fit_get_columns.argtypes = [C.c_void_p, C.c_int, ip, dp]
     lib.ppcx_fit_get_diagnostics.argtypes = [C.c_void_p, dp, dp, ip, ip, ip, dp]
     lib.ppcx_fit_get_timing.argtypes = [C.c_void_p, dp, C.POINTER(C.c_longlong), dp, C.POINTER(C.c_longlong), dp]
-    lib.ppcx_fit_get_kernel_times.argtypes = [C.c_void_p, dp, dp, C.POINTER(C.c_longlong)]
+    lib.ppcx_fit_get_kernel_times.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_longlong)]
     lib.ppcx_fit_ppc.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_ulonglong, C.c_int, C.c_int, dp, ip]
     lib.ppcx_fit_free.argtypes = [C.c_void_p]
     lib.ppcx_bench_gene_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.POINTER(C.c_int)]
@@ -290,10 +290,10 @@ class Fit:
         return dict(iterations=it.value, converged=bool(cv.value), elbo=el.value, eta=et.value)
 
     def kernel_times(self):
-        a, b = C.c_double(), C.c_double()
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
         n = C.c_longlong()
-        _check(load().ppcx_fit_get_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n)))
-        return dict(gene_ms=a.value, step_ms=b.value, launch_pairs=n.value)
+        _check(load().ppcx_fit_get_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return dict(loglik_ms=a.value, close_ms=b.value, update_ms=c.value, launch_triples=n.value)
 
     def ppc(self, truncation_compensation=1.0, p_lo=0.025, p_hi=0.975, seed=1, n_gen=0, resample=False,
             return_counts_rng=False):

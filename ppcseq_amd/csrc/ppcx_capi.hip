@@ -29,7 +29,9 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct ppcx_model {
   int device;
   Dims d;
-  int CM, L, groups_per_wave, ntiles;   // launch geometry of the gene kernel (choose_launch)
+  int CM, L, groups_per_wave, nblocks, nb0, nb1, G0;
+  int nblocks_chosen = 0;        // workgroups per chain chosen for the full chain count (what ppcx_model_get_launch reports)
+  int split_override = -1;       // 0: never split a launch into two segments (development aid, PPCX_SPLIT)
   int L_override, gpw_override;
   std::vector<int32_t> counts_host;            // original counts (exclusions are re-applied on a copy)
   std::vector<double> X_host, expo_host;
@@ -53,7 +55,7 @@ struct ppcx_fit {
   int *d_treedepth = nullptr, *d_nleap = nullptr, *d_div = nullptr;
   double seconds = 0; long long grad_evals = 0;
   double kA_ms_mean = 0; long long kA_samples = 0; double kA_chain_launches_mean = 0;
-  double kS_ms_mean = 0; long long launch_pairs = 0;
+  double kC_ms_mean = 0, kU_ms_mean = 0; long long launch_triples = 0;
   double advi_elbo = 0, advi_eta = 0; int advi_converged = 0;
 };
 
@@ -61,37 +63,73 @@ extern "C" int ppcx_version(void) { return 100; }
 extern "C" int ppcx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" const char* ppcx_last_error(void) { return g_err.c_str(); }
 
-// Launch geometry of the gene kernel: lanes per gene L (a power of two, 4..64), gene groups per wavefront R (1 or 2);
-// a workgroup (4 wavefronts) then owns a tile of 4 (64 / L) R genes. Chosen to minimise (duration of one wavefront) x
-// (rounds of resident wavefronts the launch needs): a wavefront executes ~250 instructions per gene group (LDS record,
-// setup, butterfly), ~50 per cell of a lane and its share of the one-lane-per-gene phases, whose ~1200 instructions
-// serve a whole tile; 1024 SIMDs x 4 resident wavefronts make a round, and because workgroups leave and enter one by
-// one a partly filled last round costs about half of what strict rounds would. Fewer lanes per gene mean fewer, longer
-// wavefronts (less overhead, coarser rounds); two groups per wavefront halve the prologues (LDS fill, phases P and E)
-// per gene once there are rounds to spare.
+// choose lanes-per-gene L and workgroups per chain: minimise (duration of one wavefront) x (rounds of resident
+// wavefronts the launch needs). A wavefront executes ~400 instructions of per-gene overhead plus, per cell of a lane,
+// ~80 and ~2 more per doubling of the genes that share the wavefront (they must agree on the lgamma regime) -- the
+// measured instruction counts of the kernel (SQ_INSTS_VALU vs S, profiles/). 1024 SIMDs x 4 resident wavefronts make a
+// round; a launch that does not fill one takes a wavefront's duration whatever L is, and because workgroups leave and
+// enter one by one a partly filled last round costs about half of what strict rounds would.
+// A launch may have two segments: whole rounds with L lanes per gene, and the remaining genes with 2L lanes per gene
+// -- twice as many wavefronts of half the duration -- so that the last, partial round is a short one.
+// groups per wavefront for `nactive` chains in the launch (L and the segments stay as chosen, so every gene keeps its
+// summation order and the results do not change): with four or more rounds of resident wavefronts (two or more in the
+// whole-round segment of a split launch) every wavefront takes two groups in turn -- half as many workgroup prologues
+// (LDS fill, barrier, first loads) for the same balance. Measured on cfg3: 8 chains 14.4 -> 13.4 us per chain gradient
+// (single segment), 13.6 -> 12.6 (two segments); 16 chains 12.4 -> 11.7; cfg4 72.6 -> 70.5; at 2.4 rounds (4 chains) it
+// costs 2 % and is not used. The pump calls this again as chains finish: fewer chains, fewer rounds.
+static void set_groups_per_wave(ppcx_model* m, int nactive) {
+  const int G = m->d.G;
+  const double slots = 4096.0;
+  const int gpw = 64 / m->L;
+  const int ngroups0 = (m->G0 + gpw - 1) / gpw;
+  const double rounds0 = ceil((double)ngroups0 / 4.0) * 4.0 * (nactive < 1 ? 1 : nactive) / slots;
+  int r = (m->G0 < G ? rounds0 >= 1.99 : rounds0 >= 4.0) ? 2 : 1;
+  if (m->gpw_override > 0) r = m->gpw_override;
+  const int cap = 65528;                       // grid.y limit (the launcher pads to a multiple of 8)
+  const int gpw1 = gpw > 1 ? gpw / 2 : 1;
+  const int ngroups1 = (G - m->G0 + gpw1 - 1) / gpw1;
+  int nb0 = (ngroups0 + 4 * r - 1) / (4 * r), nb1 = (ngroups1 + 3) / 4;
+  while (nb0 + nb1 > cap) { ++r; nb0 = (ngroups0 + 4 * r - 1) / (4 * r); nb1 = (ngroups1 + 4 * r - 1) / (4 * r); }
+  m->groups_per_wave = r;
+  m->nb0 = nb0 < 1 ? 1 : nb0; m->nb1 = m->G0 < G ? nb1 : 0;
+  m->nblocks = m->nb0 + m->nb1;
+}
+
+static double launch_wave_time(int S, int L) {
+  const int iters = (S + L - 1) / L;
+  return 400.0 + iters * (80.0 + 2.0 * log2(64.0 / L));
+}
 static double launch_eff_rounds(double rounds) { return rounds <= 1.0 ? 1.0 : 0.5 * rounds + 0.5 * ceil(rounds); }
 static void choose_launch(ppcx_model* m, int nchains) {
   const int G = m->d.G, S = m->d.S;
   const double slots = 4096.0;
-  int bestL = 64, bestR = 1; double best = 1e300;
-  for (int L = 4; L <= 64; L <<= 1) {
-    for (int R = 1; R <= 2; ++R) {
-      const int TG = 4 * (64 / L) * R;
-      if (TG > 64) continue;                                             // one lane per gene in phases P and E
-      const double ntiles = ceil((double)G / TG);
-      const double rounds = ntiles * 4.0 * (nchains < 1 ? 1 : nchains) / slots;
-      const double cells = (double)((S + L - 1) / L);
-      const double wave = R * (250.0 + 50.0 * cells) + 600.0;
-      const double t = wave * launch_eff_rounds(rounds);
-      if (t < best) { best = t; bestL = L; bestR = R; }
-    }
+  int bestL = 64, bestG0 = G; double best = 1e300;
+  for (int L = 1; L <= 64; L <<= 1) {
+    const int gpb = 4 * (64 / L);                                      // genes per workgroup
+    const double rounds = ceil((double)G / gpb) * 4.0 * nchains / slots;
+    const double t = launch_wave_time(S, L) * launch_eff_rounds(rounds);
+    if (t < best) { best = t; bestL = L; }
   }
-  if (m->L_override > 0) { bestL = m->L_override < 4 ? 4 : m->L_override; if (m->gpw_override <= 0) bestR = 1; }
-  if (m->gpw_override > 0) bestR = m->gpw_override > 2 ? 2 : m->gpw_override;
-  while (4 * (64 / bestL) * bestR > 64) { if (bestR > 1) bestR = 1; else bestL <<= 1; }
-  m->L = bestL; m->groups_per_wave = bestR;
-  const int TG = 4 * (64 / bestL) * bestR;
-  m->ntiles = (G + TG - 1) / TG;
+  // two segments only where the model promises at least 3 % and the 2L segment still has >= 24 cells per lane (below
+  // that its per-gene overhead eats the gain). Measured on cfg3: 8 chains (4 + 8 lanes) -6 %; 4 chains (8 + 16 lanes)
+  // and 16 chains (2 + 4 lanes against a single 4-lane launch of 4.9 rounds) +2 % -- both excluded by these conditions.
+  double best_split = 0.97 * best;
+  for (int L = 1; L < 64 && m->split_override != 0; L <<= 1) {
+    const int gpb = 4 * (64 / L);
+    const double rounds = ceil((double)G / gpb) * 4.0 * nchains / slots;
+    if (rounds <= 1.0 || (S + 2 * L - 1) / (2 * L) < 24) continue;
+    const long nb0 = (long)(floor(rounds) * slots / (4.0 * nchains));
+    const long G0 = nb0 * gpb;
+    if (G0 <= 0 || G0 >= G) continue;
+    const double r1 = ceil((double)(G - G0) / (gpb / 2)) * 4.0 * nchains / slots;
+    const double t2 = launch_wave_time(S, L) * floor(rounds) + launch_wave_time(S, 2 * L) * launch_eff_rounds(r1);
+    if (t2 < best_split) { best_split = t2; bestL = L; bestG0 = (int)G0; }
+  }
+  if (m->L_override > 0) { bestL = m->L_override; bestG0 = G; }
+  m->L = bestL;
+  m->G0 = bestG0;
+  set_groups_per_wave(m, nchains);
+  m->nblocks_chosen = m->nblocks;
 }
 
 static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
@@ -158,9 +196,8 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   if (G < 1 || S < 1 || C < 1 || K < 0 || K > G) return fail(PPCX_ERR_ARG, "need G>=1, S>=1, C>=1, 0<=K<=G");
   if (C > kMaxC) return fail(PPCX_ERR_LIMIT, "C exceeds the 8 design columns this build supports");
   if ((long long)G * S > 2000000000LL) return fail(PPCX_ERR_LIMIT, "G*S exceeds int32 cell ids");
-  // the gene kernel stages the log table, the per-sample constants (exp(exposure), exposure, X) and a tile's gene
-  // records in LDS; a sample index must fit the 16 bits it has in the low-count list
-  if (gene_kernel_lds_bytes(C <= 2 ? 2 : (C <= 4 ? 4 : 8), S, C, 64, 1) > 160u * 1024u || S > 65535)
+  // the log-likelihood kernel stages the log table and the per-sample constants (exp(exposure), exposure, X) in LDS
+  if (sizeof(double) * (2 * (size_t)kLogTabSize + (size_t)S * (2 + C)) > 160u * 1024u)
     return fail(PPCX_ERR_LIMIT, "S * (2 + C) doubles of per-sample constants do not fit the 160 KB of LDS of a compute unit");
   if (!counts || !X || !exposure || (n_excl > 0 && !excl)) return fail(PPCX_ERR_ARG, "NULL input buffer");
   for (long long i = 0; i < (long long)G * S; ++i) if (counts[i] < 0) return fail(PPCX_ERR_ARG, "negative count");
@@ -173,6 +210,7 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   m->d = make_dims(G, S, C, K, lambda_mu_mu);
   m->CM = C <= 2 ? 2 : (C <= 4 ? 4 : 8);
   m->L_override = 0; m->gpw_override = 0;
+  if (const char* e = getenv("PPCX_SPLIT")) m->split_override = atoi(e);
   m->counts_host.assign(counts, counts + (size_t)G * S);
   m->X_host.assign(X, X + (size_t)S * C);
   m->expo_host.assign(exposure, exposure + S);
@@ -220,9 +258,8 @@ extern "C" int ppcx_model_set_exclusions(ppcx_model* m, int n_excl, const int32_
 }
 extern "C" int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int groups_per_wave) {
   if (!m) return fail(PPCX_ERR_ARG, "model is NULL");
-  if (lanes_per_gene != 0 && (lanes_per_gene < 4 || lanes_per_gene > 64 || (lanes_per_gene & (lanes_per_gene - 1))))
-    return fail(PPCX_ERR_ARG, "lanes_per_gene must be 0 or a power of two in 4..64");
-  if (groups_per_wave < 0 || groups_per_wave > 2) return fail(PPCX_ERR_ARG, "groups_per_wave must be 0, 1 or 2");
+  if (lanes_per_gene != 0 && (lanes_per_gene < 1 || lanes_per_gene > 64 || (lanes_per_gene & (lanes_per_gene - 1))))
+    return fail(PPCX_ERR_ARG, "lanes_per_gene must be 0 or a power of two <= 64");
   m->L_override = lanes_per_gene; m->gpw_override = groups_per_wave > 0 ? groups_per_wave : 0;
   choose_launch(m, 1);
   return PPCX_OK;
@@ -230,7 +267,7 @@ extern "C" int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int grou
 extern "C" int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int* nblocks) {
   if (!m) return fail(PPCX_ERR_ARG, "model is NULL");
   if (lanes_per_gene) *lanes_per_gene = m->L;
-  if (nblocks) *nblocks = m->ntiles;
+  if (nblocks) *nblocks = m->nblocks_chosen;
   return PPCX_OK;
 }
 extern "C" int ppcx_model_dim(const ppcx_model* m) { return m ? m->d.D : PPCX_ERR_ARG; }
@@ -254,14 +291,15 @@ extern "C" void ppcx_nuts_config_default(ppcx_nuts_config* c) {
 // device scratch of one run of the launch pump. States, commands, hyper-coordinate vectors and the T0 slab
 // are double-buffered: update launch k reads buffer k&1 and writes buffer (k+1)&1.
 struct Work {
-  double *vecs = nullptr, *hyper_vecs[2] = {nullptr, nullptr}, *partials = nullptr, *red = nullptr;
+  double *vecs = nullptr, *hyper_vecs[2] = {nullptr, nullptr}, *partials = nullptr, *t0[2] = {nullptr, nullptr}, *sums = nullptr, *red = nullptr;
   Cmd* cmds[2] = {nullptr, nullptr}; ChainState* states[2] = {nullptr, nullptr}; int* done = nullptr;
   int* done_host = nullptr;
-  long Dpad = 0; int ntiles_max = 1; long launches = 0;
+  long Dpad = 0; int nb_update = 1, nb_close = 1; long launches = 0;
   hipStream_t stream = nullptr; bool own_stream = false;
+  bool retune_launch = true;     // the pump may adapt the model's groups per wavefront (not when several pumps share the model)
   ~Work() {
-    (void)hipFree(vecs); (void)hipFree(partials); (void)hipFree(done); (void)hipFree(red);
-    for (int i = 0; i < 2; ++i) { (void)hipFree(hyper_vecs[i]); (void)hipFree(cmds[i]); (void)hipFree(states[i]); }
+    (void)hipFree(vecs); (void)hipFree(partials); (void)hipFree(done); (void)hipFree(sums); (void)hipFree(red);
+    for (int i = 0; i < 2; ++i) { (void)hipFree(hyper_vecs[i]); (void)hipFree(t0[i]); (void)hipFree(cmds[i]); (void)hipFree(states[i]); }
     if (done_host) (void)hipHostFree(done_host);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -271,23 +309,28 @@ static int work_alloc(Work& w, ppcx_model* m, int nchains) {
   const int D = m->d.D;
   if (!w.stream) w.stream = m->stream;
   w.Dpad = ((long)D + 31) / 32 * 32;
+  w.nb_update = (D + 255) / 256; if (w.nb_update > 1024) w.nb_update = 1024; if (w.nb_update < 1) w.nb_update = 1;
   HIPCHK(hipMalloc(&w.vecs, sizeof(double) * (size_t)nchains * V_COUNT * w.Dpad));
-  w.ntiles_max = (m->d.G + 3) / 4;              // the finest tiling the gene kernel can be given (L = 64, one group)
-  HIPCHK(hipMalloc(&w.partials, sizeof(double) * (size_t)nchains * w.ntiles_max * PT_COUNT));
+  w.nb_close = (m->d.G + 255) / 256;
+  HIPCHK(hipMalloc(&w.partials, sizeof(double) * (size_t)nchains * w.nb_close * PT_COUNT));
+  HIPCHK(hipMalloc(&w.sums, sizeof(double) * (size_t)nchains * (3 + m->CM) * m->d.G));
+  HIPCHK(hipMemsetAsync(w.sums, 0, sizeof(double) * (size_t)nchains * (3 + m->CM) * m->d.G, w.stream));
   HIPCHK(hipMalloc(&w.done, sizeof(int) * nchains));
   HIPCHK(hipMalloc(&w.red, sizeof(double) * (size_t)nchains * PT_COUNT));
   HIPCHK(hipMemsetAsync(w.red, 0, sizeof(double) * (size_t)nchains * PT_COUNT, w.stream));
   HIPCHK(hipHostMalloc(&w.done_host, sizeof(int) * nchains));
   for (int i = 0; i < 2; ++i) {
     HIPCHK(hipMalloc(&w.hyper_vecs[i], sizeof(double) * (size_t)nchains * V_COUNT * 8));
+    HIPCHK(hipMalloc(&w.t0[i], sizeof(double) * (size_t)nchains * w.nb_update));
     HIPCHK(hipMalloc(&w.cmds[i], sizeof(Cmd) * nchains));
     HIPCHK(hipMalloc(&w.states[i], sizeof(ChainState) * nchains));
     HIPCHK(hipMemsetAsync(w.hyper_vecs[i], 0, sizeof(double) * (size_t)nchains * V_COUNT * 8, w.stream));
+    HIPCHK(hipMemsetAsync(w.t0[i], 0, sizeof(double) * (size_t)nchains * w.nb_update, w.stream));
     HIPCHK(hipMemsetAsync(w.cmds[i], 0, sizeof(Cmd) * nchains, w.stream));
     HIPCHK(hipMemsetAsync(w.states[i], 0, sizeof(ChainState) * nchains, w.stream));
   }
   HIPCHK(hipMemsetAsync(w.vecs, 0, sizeof(double) * (size_t)nchains * V_COUNT * w.Dpad, w.stream));
-  HIPCHK(hipMemsetAsync(w.partials, 0, sizeof(double) * (size_t)nchains * w.ntiles_max * PT_COUNT, w.stream));
+  HIPCHK(hipMemsetAsync(w.partials, 0, sizeof(double) * (size_t)nchains * w.nb_close * PT_COUNT, w.stream));
   HIPCHK(hipMemsetAsync(w.done, 0, sizeof(int) * nchains, w.stream));
   for (int c = 0; c < nchains; ++c) {          // inverse metric starts at identity
     HIPCHK(launch_fill_kernel(w.vecs + ((size_t)c * V_COUNT + V_MINV) * w.Dpad, w.Dpad, 1.0, w.stream));
@@ -313,7 +356,7 @@ static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int
   sa.states_in = w.states[in]; sa.states_out = w.states[out];
   sa.cmds_in = w.cmds[in]; sa.cmds_out = w.cmds[out];
   sa.hyper_in = w.hyper_vecs[in]; sa.hyper_out = w.hyper_vecs[out];
-  sa.partials = w.partials; sa.ntiles = m->ntiles; sa.red = w.red;
+  sa.partials = w.partials; sa.nblocks_close = w.nb_close; sa.t0 = w.t0[0]; sa.nblocks_update = w.nb_update; sa.red = w.red;
   sa.draws = io.draws; sa.draws_chain_stride = io.draws_stride; sa.n_keep = io.n_keep; sa.iter = io.iter;
   sa.out_lp = io.lp; sa.out_stepsize = io.stepsize; sa.out_treedepth = io.treedepth; sa.out_n_leapfrog = io.nleap;
   sa.out_divergent = io.div; sa.out_accept = io.accept; sa.done = w.done;
@@ -322,25 +365,38 @@ static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int
   if (phases & STEP_ADVANCE) w.launches++;
   return PPCX_OK;
 }
-// the gene kernel: the command's coordinate work, one gradient evaluation and the tiles' partial sums
-static int launch_gene(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
-  GeneArgs ga;
-  ga.d = m->d; ga.counts = m->d_counts; ga.low = m->d_low; ga.low_start = m->d_low_start; ga.n_hi = m->d_nhi;
-  ga.sampleE = m->d_E; ga.exposure = m->d_expo; ga.X = m->d_X;
-  ga.Sy = m->d_Sy; ga.SyE = m->d_SyE; ga.SyX = m->d_SyX; ga.SX = m->d_SX; ga.ncell = m->d_ncell; ga.Lg1 = m->d_Lg1;
-  ga.vecs = w.vecs; ga.Dpad = w.Dpad; ga.cmds = w.cmds[w.launches & 1];
-  ga.draws = io.draws; ga.draws_chain_stride = io.draws_stride;
-  ga.partials = w.partials; ga.logtab = m->d_logtab; ga.order = m->d_order;
-  ga.lgL = 0; while ((1 << ga.lgL) < m->L) ++ga.lgL;
-  ga.groups_per_wave = m->groups_per_wave; ga.ntiles = m->ntiles;
-  hipError_t e = launch_gene_kernel(m->CM, ga, nchains, w.stream);
-  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("gene kernel: ") + hipGetErrorString(e));
+static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
+  UpdateArgs ua;
+  ua.d = m->d; ua.cmds = w.cmds[w.launches & 1]; ua.vecs = w.vecs; ua.Dpad = w.Dpad;
+  ua.draws = io.draws; ua.draws_chain_stride = io.draws_stride; ua.t0_out = w.t0[0];
+  hipError_t e = launch_update_kernel(ua, w.nb_update, nchains, w.stream);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("update kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
+}
+static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
+  LoglikArgs la;
+  la.d = m->d; la.counts = m->d_counts; la.low = m->d_low; la.low_start = m->d_low_start; la.n_hi = m->d_nhi; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
+  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order; la.lgL = 0; while ((1 << la.lgL) < m->L) ++la.lgL; la.nb0 = m->nb0; la.G0 = m->G0; la.nb1 = m->nb1;
+  hipError_t e = launch_loglik_kernel(m->CM, la, m->nblocks, nchains, w.stream);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("loglik kernel: ") + hipGetErrorString(e));
+  return PPCX_OK;
+}
+static int launch_close(ppcx_model* m, Work& w, int nchains) {
+  CloseArgs ca;
+  ca.d = m->d; ca.Sy = m->d_Sy; ca.SyE = m->d_SyE; ca.SyX = m->d_SyX; ca.SX = m->d_SX; ca.ncell = m->d_ncell; ca.Lg1 = m->d_Lg1;
+  ca.sums = w.sums; ca.vecs = w.vecs; ca.Dpad = w.Dpad; ca.cmds = w.cmds[w.launches & 1]; ca.partials = w.partials;
+  hipError_t e = launch_close_kernel(m->CM, ca, w.nb_close, nchains, w.stream);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("close kernel: ") + hipGetErrorString(e));
+  return PPCX_OK;
+}
+static int launch_gene(ppcx_model* m, Work& w, int nchains) {   // one gradient evaluation = loglik + close
+  int rc = launch_loglik(m, w, nchains);
+  return rc != PPCX_OK ? rc : launch_close(m, w, nchains);
 }
 static ChainState* current_states(Work& w) { return w.states[w.launches & 1]; }
 static double* current_hyper(Work& w) { return w.hyper_vecs[w.launches & 1]; }
 
-struct PumpStats { double kA_ms_sum = 0, kS_ms_sum = 0; long long kA_samples = 0; double chain_launches = 0; long long pairs = 0; };
+struct PumpStats { double kA_ms_sum = 0, kC_ms_sum = 0, kU_ms_sum = 0; long long kA_samples = 0; double chain_launches = 0; long long pairs = 0; };
 
 // ---- RCCL, bound at run time (dlopen) so the library has no link-time dependency and shares the RCCL that
 // the process may already have loaded (torch ships one)
@@ -373,35 +429,40 @@ struct ppcx_comm { ncclComm_t comm = nullptr; int nranks = 1, rank = 0, device =
 // One shard of a run: its model (all genes, or a contiguous gene range) and its device scratch.
 struct Shard { ppcx_model* m; Work* w; RunIO io; };
 
-// Launch (gene kernel, step kernel) rounds until every chain reports done; with gene shards the step kernel runs as
-// reduce, exchange, advance. With several shards in one process they share shard 0's stream and their partial sums are
-// added by ppcx_sum_shards_kernel; with a communicator the sums are all-reduced over the ranks (RCCL, xGMI).
+// Launch (loglik, close, reduce [, exchange], update) rounds until every chain reports done. With several
+// shards in one process they share shard 0's stream and their partial sums are added by ppcx_sum_shards_kernel;
+// with a communicator the sums are all-reduced over the ranks (RCCL, xGMI) between reduce and update.
 static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long max_pairs, bool time_kernels,
                 PumpStats* stats) {
   const int ns = (int)sh.size();
   hipStream_t st = sh[0].w->stream;
   int rc = PPCX_OK;
-  for (int k = 0; k < ns; ++k)                                     // PH_START: the first command
+  for (int k = 0; k < ns; ++k) {                                   // PH_START: first command, then its coordinate work
     if ((rc = launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_REDUCE | STEP_ADVANCE)) != PPCX_OK) return rc;
+    if ((rc = launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;
+  }
   const int batch = 32, sample_every = 16;
   struct Events {                // destroyed on every exit path
-    hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
   } evs;
   if (time_kernels) for (hipEvent_t& x : evs.e) HIPCHK(hipEventCreate(&x));
-  hipEvent_t &ev0 = evs.e[0], &ev1 = evs.e[1], &ev2 = evs.e[2];
+  hipEvent_t &ev0 = evs.e[0], &ev1 = evs.e[1], &ev2 = evs.e[2], &ev3 = evs.e[3];
   long long pairs = 0; int n_done = 0;
   Work& w0 = *sh[0].w;
-  const bool exchange = ns > 1 || (comm && comm->comm);
   while (true) {
     bool sampled = false;
     for (int i = 0; i < batch; ++i, ++pairs) {
       const bool smp = time_kernels && !sampled && (pairs / batch) % sample_every == 0 && i == batch / 2;
       if (smp) HIPCHK(hipEventRecord(ev0, st));
-      for (int k = 0; k < ns; ++k) if ((rc = launch_gene(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;
+      for (int k = 0; k < ns; ++k) if ((rc = launch_loglik(sh[k].m, *sh[k].w, nchains)) != PPCX_OK) return rc;
       if (smp) { HIPCHK(hipEventRecord(ev1, st)); sampled = true; }
-      for (int k = 0; k < ns; ++k)
+      const bool exchange = ns > 1 || (comm && comm->comm);
+      for (int k = 0; k < ns; ++k) {
+        if ((rc = launch_close(sh[k].m, *sh[k].w, nchains)) != PPCX_OK) return rc;
+        if (smp && k == ns - 1) HIPCHK(hipEventRecord(ev2, st));
         if ((rc = launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, exchange ? STEP_REDUCE : (STEP_REDUCE | STEP_ADVANCE))) != PPCX_OK) return rc;
+      }
       if (ns > 1) {
         ShardSumArgs sa; sa.n_shards = ns; sa.n = nchains * PT_COUNT;
         for (int k = 0; k < ns; ++k) sa.bufs[k] = sh[k].w->red;
@@ -412,17 +473,19 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
         const int e = g_rccl.AllReduce(w0.red, w0.red, (size_t)nchains * PT_COUNT, /*ncclDouble*/ 8, /*ncclSum*/ 0, comm->comm, st);
         if (e != 0) return fail(PPCX_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"));
       }
-      if (exchange)
-        for (int k = 0; k < ns; ++k)
-          if ((rc = launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_ADVANCE)) != PPCX_OK) return rc;
-      if (smp) HIPCHK(hipEventRecord(ev2, st));
+      for (int k = 0; k < ns; ++k) {
+        if (exchange && (rc = launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_ADVANCE)) != PPCX_OK) return rc;
+        if ((rc = launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;
+      }
+      if (smp) HIPCHK(hipEventRecord(ev3, st));
     }
     HIPCHK(hipMemcpyAsync(w0.done_host, w0.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (sampled && n_done == 0) {               // only launches in which every chain was still active
       float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
       stats->kA_ms_sum += ms; stats->kA_samples++; stats->chain_launches += nchains;
-      HIPCHK(hipEventElapsedTime(&ms, ev1, ev2)); stats->kS_ms_sum += ms;
+      HIPCHK(hipEventElapsedTime(&ms, ev1, ev2)); stats->kC_ms_sum += ms;
+      HIPCHK(hipEventElapsedTime(&ms, ev2, ev3)); stats->kU_ms_sum += ms;
     }
     n_done = 0;
     for (int c = 0; c < nchains; ++c) {
@@ -431,6 +494,7 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       if (w0.done_host[c] == 3) rc = fail(PPCX_ERR_STEPSIZE, "step-size heuristic diverged");
     }
     if (n_done == nchains) break;
+    if (ns == 1 && w0.retune_launch) set_groups_per_wave(sh[0].m, nchains - n_done);   // fewer chains in the launch: fewer rounds
     if (pairs > max_pairs) { rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished"); break; }
   }
   stats->pairs = pairs;
@@ -492,7 +556,7 @@ extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, 
 // same work.
 extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs, int reps, int n_merge,
                                       double* ms_per_launch, int* cmd_type) {
-  const int which = n_merge >= 100 ? (n_merge / 100) : 0;      // 0 gene kernel, 3 step, 5 step:reduce, 6 step:advance (development aid)
+  const int which = n_merge >= 100 ? (n_merge / 100) : 0;      // 0 loglik, 1 close, 2 both, 3 step, 4 update, 5 step:reduce, 6 step:advance (development aid)
   if (n_merge >= 100) n_merge %= 100;
   if (!m || nchains < 1 || reps < 1 || !ms_per_launch) return fail(PPCX_ERR_ARG, "bad arguments");
   HIPCHK(hipSetDevice(m->device));
@@ -509,33 +573,27 @@ extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs
   RunIO io; io.iter = nc.iter;
   hipStream_t st = m->stream;
   if ((rc = launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE)) != PPCX_OK) return rc;
+  if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
   for (int i = 0; i < warm_pairs; ++i) {
-    if ((rc = launch_gene(m, w, nchains, io)) != PPCX_OK) return rc;
+    if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
     if ((rc = launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE)) != PPCX_OK) return rc;
+    if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
   }
   HIPCHK(hipStreamSynchronize(st));
   Cmd* dcmds = w.cmds[w.launches & 1];
   std::vector<Cmd> cmds(nchains);
   HIPCHK(hipMemcpy(cmds.data(), dcmds, sizeof(Cmd) * nchains, hipMemcpyDeviceToHost));
   if (cmd_type) *cmd_type = cmds[0].type;
-  // the timed launches repeat ONE command: without its pre-operations and with a tiny step, so that the repeated
-  // kicks and drifts stay on a bounded trajectory
-  for (int c = 0; c < nchains; ++c) {
-    cmds[c].pre_flags = 0; cmds[c].eps *= 1e-6;
-    if (n_merge >= 0 && cmds[c].type == CMD_LEAF) { cmds[c].n_merge = n_merge; cmds[c].subtree_complete = 0; }
+  if (n_merge >= 0) for (int c = 0; c < nchains; ++c) if (cmds[c].type == CMD_LEAF) {
+    cmds[c].n_merge = n_merge; cmds[c].subtree_complete = 0;
+    cmds[c].eps *= 1e-3;                         // keep the repeated second half kicks on a bounded trajectory
   }
   HIPCHK(hipMemcpy(dcmds, cmds.data(), sizeof(Cmd) * nchains, hipMemcpyHostToDevice));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) if ((rc = launch_gene(m, w, nchains, io)) != PPCX_OK) return rc;
+  for (int i = 0; i < 3; ++i) if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) {
-    if (which == 3) rc = launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE);
-    else if (which == 5) rc = launch_step(m, w, nchains, io, STEP_REDUCE);
-    else if (which == 6) rc = launch_step(m, w, nchains, io, STEP_ADVANCE);
-    else rc = launch_gene(m, w, nchains, io);
-    if (rc != PPCX_OK) return rc;
-  }
+  for (int i = 0; i < reps; ++i) if ((rc = (which == 1 ? launch_close(m, w, nchains) : (which == 2 ? launch_gene(m, w, nchains) : (which == 3 ? launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE) : (which == 4 ? launch_update(m, w, nchains, io) : (which == 5 ? launch_step(m, w, nchains, io, STEP_REDUCE) : (which == 6 ? launch_step(m, w, nchains, io, STEP_ADVANCE) : launch_loglik(m, w, nchains)))))))) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
@@ -600,6 +658,7 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
     Group& G = grp[g];
     G.c0 = (int)((long long)nch * g / ngrp); G.n = (int)((long long)nch * (g + 1) / ngrp) - G.c0;
     if (g > 0) { FHIP(hipStreamCreateWithFlags(&G.w.stream, hipStreamNonBlocking)); G.w.own_stream = true; }
+    G.w.retune_launch = ngrp == 1;
     int rc = work_alloc(G.w, m, G.n);
     if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }
     std::vector<ChainState> states(G.n);
@@ -639,14 +698,15 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   PumpStats ps;
   for (int g = 0; g < ngrp; ++g) {
     f->grad_evals += grp[g].leap;
-    ps.kA_ms_sum += grp[g].ps.kA_ms_sum; ps.kS_ms_sum += grp[g].ps.kS_ms_sum;
+    ps.kA_ms_sum += grp[g].ps.kA_ms_sum; ps.kC_ms_sum += grp[g].ps.kC_ms_sum; ps.kU_ms_sum += grp[g].ps.kU_ms_sum;
     ps.kA_samples += grp[g].ps.kA_samples; ps.chain_launches += grp[g].ps.chain_launches; ps.pairs += grp[g].ps.pairs;
   }
   f->kA_samples = ps.kA_samples;
   f->kA_ms_mean = ps.kA_samples ? ps.kA_ms_sum / (double)ps.kA_samples : 0.0;
   f->kA_chain_launches_mean = ps.kA_samples ? ps.chain_launches / (double)ps.kA_samples : 0.0;
-  f->kS_ms_mean = ps.kA_samples ? ps.kS_ms_sum / (double)ps.kA_samples : 0.0;
-  f->launch_pairs = ps.pairs;
+  f->kC_ms_mean = ps.kA_samples ? ps.kC_ms_sum / (double)ps.kA_samples : 0.0;
+  f->kU_ms_mean = ps.kA_samples ? ps.kU_ms_sum / (double)ps.kA_samples : 0.0;
+  f->launch_triples = ps.pairs;
   *out = f;
   return PPCX_OK;
 }
@@ -670,9 +730,9 @@ static int advi_launch(AdviRun& r, int op, int n_slots, double eta_scaled, int f
   return PPCX_OK;
 }
 static int advi_eval(AdviRun& r, int n_slots) {      // gradient evaluation of the first n_slots slots
-  RunIO io;
-  int rc = launch_gene(r.m, *r.w, n_slots, io);
-  if (rc == PPCX_OK) rc = launch_step(r.m, *r.w, n_slots, io, STEP_REDUCE);
+  int rc = launch_loglik(r.m, *r.w, n_slots);
+  if (rc == PPCX_OK) rc = launch_close(r.m, *r.w, n_slots);
+  if (rc == PPCX_OK) { RunIO io; rc = launch_step(r.m, *r.w, n_slots, io, STEP_REDUCE); }
   return rc;
 }
 static int advi_elbo(AdviRun& r, double* elbo) {     // Stan advi::calc_ELBO
@@ -921,8 +981,9 @@ static int fit_sharded(ppcx_model** models, int ns, const ppcx_nuts_config* cfg,
     f->kA_samples = ps.kA_samples;
     f->kA_ms_mean = ps.kA_samples ? ps.kA_ms_sum / (double)ps.kA_samples : 0.0;
     f->kA_chain_launches_mean = ps.kA_samples ? ps.chain_launches / (double)ps.kA_samples : 0.0;
-    f->kS_ms_mean = ps.kA_samples ? ps.kS_ms_sum / (double)ps.kA_samples : 0.0;
-    f->launch_pairs = ps.pairs;
+    f->kC_ms_mean = ps.kA_samples ? ps.kC_ms_sum / (double)ps.kA_samples : 0.0;
+    f->kU_ms_mean = ps.kA_samples ? ps.kU_ms_sum / (double)ps.kA_samples : 0.0;
+    f->launch_triples = ps.pairs;
   }
   return PPCX_OK;
 }
@@ -1014,11 +1075,13 @@ extern "C" int ppcx_fit_get_diagnostics(ppcx_fit* f, double* lp, double* stepsiz
   if (accept && f->d_accept) HIPCHK(hipMemcpy(accept, f->d_accept, sizeof(double) * ni, hipMemcpyDeviceToHost));
   return PPCX_OK;
 }
-extern "C" int ppcx_fit_get_kernel_times(ppcx_fit* f, double* gene_ms, double* step_ms, long long* launch_pairs) {
+extern "C" int ppcx_fit_get_kernel_times(ppcx_fit* f, double* loglik_ms, double* close_ms, double* update_ms,
+                                         long long* launch_triples) {
   if (!f) return fail(PPCX_ERR_ARG, "fit is NULL");
-  if (gene_ms) *gene_ms = f->kA_ms_mean;
-  if (step_ms) *step_ms = f->kS_ms_mean;
-  if (launch_pairs) *launch_pairs = f->launch_pairs;
+  if (loglik_ms) *loglik_ms = f->kA_ms_mean;
+  if (close_ms) *close_ms = f->kC_ms_mean;
+  if (update_ms) *update_ms = f->kU_ms_mean;
+  if (launch_triples) *launch_triples = f->launch_triples;
   return PPCX_OK;
 }
 extern "C" int ppcx_fit_get_timing(ppcx_fit* f, double* seconds, long long* grad_evals, double* gene_kernel_ms_mean,

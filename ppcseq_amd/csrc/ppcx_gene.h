@@ -1,10 +1,9 @@
 // ppcx_gene.h -- the per-gene bodies of the kernels:
-//   gene kernel, phase P (one lane per gene)  : gene_index -> coord_update of the gene's coordinates -> gene_consts
-//                phase C (L lanes per gene)   : gene_cells -> cell_acc_close -> [L-lane butterfly] -> per-gene sums
-//                phase E (one lane per gene)  : gene_finish -> tree bookkeeping (coord_merge_dots / coord_store_slot /
-//                                               coord_top_dots)
-//   step kernel                               : chain_step (scalar state machine)
-// Shared by the gfx950 kernels (ppcx_kernels.hip) and the CPU emulation harness in tests/emul.
+//   log-likelihood kernel : gene_load -> gene_consts -> gene_cells (per lane) -> [L-lane butterfly] -> per-gene sums
+//   close kernel          : gene_load -> gene_finish -> tree bookkeeping (coord_merge_dots / coord_store_slot /
+//                           coord_top_dots)
+//   update kernel         : chain_step (scalar state machine) and coord_update (per coordinate)
+// Shared by the gfx950 kernel (ppcx_kernels.hip) and the CPU emulation harness in tests/emul.
 #pragma once
 #include "ppcx_nuts.h"
 
@@ -20,41 +19,30 @@ struct GeneCtx {
   GeneParams<CM> gp;
 };
 
-// the gene's coordinates in the unconstrained vector and the cell path it takes (no memory access)
+// load the gene's (already drifted) coordinates: coefficients, sigma_raw, phi
 template <int CM>
-PPCX_HD void gene_index(const Dims& d, int g, GeneCtx<CM>& x) {
+PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, GeneCtx<CM>& x) {
   constexpr int NCM = CM + 1;
   x.active = g < d.G;
   x.gg = x.active ? g : 0;
   const int C = d.C;
   const int nslope = x.gg < d.K ? (C - 1 > 1 ? C - 1 : 1) : 0;   // alpha_sub_1 exists even for C == 1 (.stan:189)
   x.ncoord = x.active ? 2 + nslope : 0;
+  double q[NCM];
 #pragma unroll
-  for (int j = 0; j < NCM; ++j)
+  for (int j = 0; j < NCM; ++j) {
     x.idx[j] = j == 0 ? d.off_intercept + x.gg : (j == 1 ? d.off_sigma_raw + x.gg : coef_index(d, j - 1, x.gg));
+    q[j] = j < x.ncoord ? v.at(V_Q0 + 3 * c.dir, x.idx[j]) : 0.0;
+  }
   x.has_slopes = x.active && x.gg < d.K && C >= 2;
   x.two = x.has_slopes && d.x0_is_one && d.x1_binary;
   x.fast = d.x0_is_one && (!x.has_slopes || x.two);
-}
-// the gene's parameters from the values q[0..NCM) of its coordinates (intercept, sigma_raw, slopes)
-template <int CM>
-PPCX_HD void gene_params(const Dims& d, const double* q, GeneCtx<CM>& x) {
   x.gp.coef[0] = q[0];
 #pragma unroll
-  for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < d.C) ? q[cc + 1] : 0.0;
+  for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < C) ? q[cc + 1] : 0.0;
   x.gp.sigma_raw = q[1];
   x.gp.phi = fast_exp(-x.gp.sigma_raw);        // sigma = 1 ./ exp(sigma_raw)   (.stan:203)
   x.gp.invphi = 0.0; x.gp.dlt = 0.0; x.gp.dps = 0.0; x.gp.A = 0.0; x.gp.A1 = 0.0;
-}
-// load the gene's (already drifted) coordinates: coefficients, sigma_raw, phi
-template <int CM>
-PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, GeneCtx<CM>& x) {
-  constexpr int NCM = CM + 1;
-  gene_index<CM>(d, g, x);
-  double q[NCM];
-#pragma unroll
-  for (int j = 0; j < NCM; ++j) q[j] = j < x.ncoord ? v.at(V_Q0 + 3 * c.dir, x.idx[j]) : 0.0;
-  gene_params<CM>(d, q, x);
 }
 // the per-gene constants of the cell loop
 template <int CM>
@@ -140,69 +128,55 @@ PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, con
   }
 }
 
-// Phase E, per gene: the log density of the gene and the gradient of its coordinates from the reduced sums of its
-// cells. gnew[j] = gradient of coordinate j (intercept, sigma_raw, slopes); part[PT_LP], part[PT_H0 .. PT_H0+5] are set.
-template <int CM>
-PPCX_HD void gene_grad(const Dims& d, const Cmd& c, const GeneCtx<CM>& x, GeneSumsV<CM>& acc, double Sy, double SyE,
-                       const double* SyX /*CM*/, const double* SX /*CM*/, double ncell, double Lg1, double* gnew /*CM+1*/,
-                       double* part /*10, zeroed here*/) {
-  constexpr int NCM = CM + 1;
-  if (x.fast) acc.Tx[0] = acc.Sr;               // X[,1] == 1
-  GeneOut<CM> go;
-  gene_close<CM>(d, c.hy, x.gg, x.has_slopes, x.gp, acc, Sy, SyE, SyX, SX, ncell, Lg1, &go);
-#pragma unroll
-  for (int k = 0; k < 10; ++k) part[k] = 0.0;
-#pragma unroll
-  for (int j = 0; j < NCM; ++j) gnew[j] = j == 0 ? go.g_coef[0] : (j == 1 ? go.g_sigma_raw : go.g_coef[j >= 2 ? j - 1 : 0]);
-  if (x.active) {
-    part[PT_LP] = go.lp;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) part[PT_H0 + k] = go.h[k];
-  }
-}
-// Phase E, per coordinate: the second half kick with the new gradient. Returns the momentum; *T1 and *bad receive the
-// coordinate's kinetic-energy term and whether its gradient is non-finite.
-PPCX_HD double coord_kick(const Cmd& c, const VecRef& v, int i, double gnew, double* minv, double* T1, double* bad) {
-  *minv = v.at(V_MINV, i);
-  const double pn = v.at(V_P0 + 3 * c.dir, i) + 0.5 * c.eps * gnew;
-  v.at(V_P0 + 3 * c.dir, i) = pn;
-  v.at(V_G0 + 3 * c.dir, i) = gnew;
-  *T1 += pn * pn * *minv;
-  if (!isfinite(gnew)) *bad = 1.0;
-  return pn;
-}
-// close the gene with its reduced sums (one lane does the gene and all its coordinates: host emulation)
+// close the gene with its reduced sums: gradient, second half kick, stores, partial sums part[0..9]
 template <int CM>
 PPCX_HD void gene_finish(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, GeneSumsV<CM>& acc,
                          const double* Sy, const double* SyE, const double* SyXg, const double* SXg, const double* ncell,
                          const double* Lg1, double* part, double* pn, double* minv) {
   constexpr int NCM = CM + 1;
-  double SyX[CM], SX[CM], gnew[NCM];
+  if (x.fast) acc.Tx[0] = acc.Sr;               // X[,1] == 1
+  double SyX[CM], SX[CM];
 #pragma unroll
   for (int cc = 0; cc < CM; ++cc) {
     SyX[cc] = (cc < d.C) ? SyXg[(long)cc * d.G + x.gg] : 0.0;
     SX[cc] = (cc < d.C) ? SXg[(long)cc * d.G + x.gg] : 0.0;
   }
-  gene_grad<CM>(d, c, x, acc, Sy[x.gg], SyE[x.gg], SyX, SX, ncell[x.gg], Lg1[x.gg], gnew, part);
+  GeneOut<CM> go;
+  gene_close<CM>(d, c.hy, x.gg, x.has_slopes, x.gp, acc, Sy[x.gg], SyE[x.gg], SyX, SX, ncell[x.gg], Lg1[x.gg], &go);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) part[k] = 0.0;
+  bool bad = false;
 #pragma unroll
   for (int j = 0; j < NCM; ++j) {
+    const double gnew = j == 0 ? go.g_coef[0] : (j == 1 ? go.g_sigma_raw : go.g_coef[j >= 2 ? j - 1 : 0]);
     pn[j] = 0.0; minv[j] = 1.0;
-    if (j < x.ncoord) pn[j] = coord_kick(c, v, x.idx[j], gnew[j], &minv[j], &part[PT_T1], &part[PT_NONFINITE]);
+    if (j < x.ncoord) {
+      minv[j] = v.at(V_MINV, x.idx[j]);
+      pn[j] = v.at(V_P0 + 3 * c.dir, x.idx[j]) + 0.5 * c.eps * gnew;      // second half kick
+      v.at(V_P0 + 3 * c.dir, x.idx[j]) = pn[j];
+      v.at(V_G0 + 3 * c.dir, x.idx[j]) = gnew;
+      part[PT_T1] += pn[j] * pn[j] * minv[j];
+      bad = bad || !isfinite(gnew);
+    }
+  }
+  if (x.active) {
+    part[PT_LP] = go.lp;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) part[PT_H0 + k] = go.h[k];
+    part[PT_NONFINITE] = bad ? 1.0 : 0.0;
   }
 }
 
-// one gene-owned coordinate at the start of a round: the pre-operations of the new command, then the first half kick
-// and the drift of the leapfrog (written in place into the end being advanced); returns the position to evaluate.
-// A command without a step (eps = 0: evaluations of a given point) leaves position and momentum as they are.
-PPCX_HD double coord_update(const Dims& d, const Cmd& nc, const VecRef& v, int i, double* draws, double* T0,
-                            const CoordCache* cc = nullptr) {
+// per-coordinate part of kernel B for one gene-owned coordinate: pre-operations of the new command, then the
+// first half kick and the drift of the next leapfrog (written in place into the end being advanced)
+PPCX_HD void coord_update(const Dims& d, const Cmd& nc, const VecRef& v, int i, double* draws, double* T0,
+                          const CoordCache* cc = nullptr) {
   const CoordVals cv = coord_pre(nc, v, i, i, global_flat(d, i), true, draws, d.D, nc.k0, nc.k1, T0, cc);
-  if (nc.type == CMD_FLUSH || nc.eps == 0.0) return cv.q;
-  const double ph = cv.p + 0.5 * nc.eps * cv.g;
-  const double qn = cv.q + nc.eps * cv.minv * ph;
-  v.at(V_P0 + 3 * nc.dir, i) = ph;
-  v.at(V_Q0 + 3 * nc.dir, i) = qn;
-  return qn;
+  if (nc.type != CMD_FLUSH) {
+    const double ph = cv.p + 0.5 * nc.eps * cv.g;
+    v.at(V_P0 + 3 * nc.dir, i) = ph;
+    v.at(V_Q0 + 3 * nc.dir, i) = cv.q + nc.eps * cv.minv * ph;
+  }
 }
 
 // Kernel B, serial part (one thread per chain): finish the hyper coordinates of the executed command,

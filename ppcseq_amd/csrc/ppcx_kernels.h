@@ -5,31 +5,38 @@
 
 namespace ppcx {
 
-struct GeneArgs {
+struct LoglikArgs {
   Dims d;
-  const int* counts;            // G x S gene-major (+ 64 entries of padding), excluded cells = -1
+  const int* counts;            // G x S gene-major, excluded cells = -1
   const unsigned* low;          // the cells with 0 <= count <= 7, gene after gene: (count << 16) | sample
   const int* low_start;         // [G + 1] a gene's range in `low`
   const int* n_hi;              // [G] number of cells with count >= 8
   const double* sampleE;        // exp(exposure_s)
   const double* exposure;       // S
   const double* X;              // S x C column-major
+  double* vecs;                 // [chains][V_COUNT][Dpad] (read only here)
+  long Dpad;
+  const Cmd* cmds;              // [chains]
+  double* sums;                 // [chains][3+CM][G] (GeneSumsV)
+  const double* logtab;         // 2 x 256 doubles (device), ppcx_math.h table_log
+  const int* order;             // [G] launch position -> gene (host: gene_order)
+  int lgL;                      // log2 of the lanes per gene of the first segment
+  int nb0, G0, nb1;             // launch segments (choose_launch): nb0 workgroups per chain cover the first G0 gene positions
+                                // with L lanes per gene, nb1 workgroups the rest with 2L (nb1 = 0: one segment, G0 = G)
+};
+
+struct CloseArgs {
+  Dims d;
   const double* Sy;             // per-gene sufficient statistics over non-excluded cells
   const double* SyE;
   const double* SyX;            // [C][G]
   const double* SX;             // [C][G] sum of X_sc over the gene's non-excluded cells
   const double* ncell;          // [G] number of non-excluded cells
   const double* Lg1;            // per-gene sum of lgamma(y+1)
-  double* vecs;                 // [chains][V_COUNT][Dpad]
-  long Dpad;
-  const Cmd* cmds;              // [chains] the commands the step kernel just wrote
-  double* draws; long draws_chain_stride;   // kept draws (PRE_STORE_DRAW), or null
-  double* partials;             // [chains][ntiles][PT_COUNT]
-  const double* logtab;         // 2 x 256 doubles (device), ppcx_math.h table_log
-  const int* order;             // [G] launch position -> gene (host: gene_order)
-  int lgL;                      // log2 of the lanes per gene
-  int groups_per_wave;          // gene groups a wavefront takes in turn (R): a tile holds 4 (64 / L) R genes
-  int ntiles;                   // tiles per chain
+  const double* sums;
+  double* vecs; long Dpad;
+  const Cmd* cmds;
+  double* partials;             // [chains][nblocks_close][PT_COUNT]
 };
 
 enum StepPhase : int { STEP_REDUCE = 1, STEP_ADVANCE = 2 };
@@ -39,7 +46,8 @@ struct StepArgs {
   const ChainState* states_in; ChainState* states_out;   // double-buffered between rounds
   const Cmd* cmds_in; Cmd* cmds_out;
   const double* hyper_in; double* hyper_out;             // [chains][V_COUNT][8]
-  const double* partials; int ntiles;                    // [chains][ntiles][PT_COUNT]: the gene kernel's slab
+  const double* partials; int nblocks_close;             // [chains][nblocks_close][PT_COUNT]
+  const double* t0; int nblocks_update;                  // [chains][nblocks_update]
   double* red;                                           // [chains][PT_COUNT]
   double* draws; long draws_chain_stride;
   int n_keep, iter;
@@ -49,6 +57,14 @@ struct StepArgs {
 
 constexpr int kMaxShards = 16;
 struct ShardSumArgs { double* bufs[kMaxShards]; int n_shards; int n; };
+
+struct UpdateArgs {
+  Dims d;
+  const Cmd* cmds;              // the commands the step kernel just wrote
+  double* vecs; long Dpad;
+  double* draws; long draws_chain_stride;
+  double* t0_out;               // [chains][nblocks_update]
+};
 
 enum AdviOp : int { ADVI_DRAW = 0, ADVI_RESET = 1, ADVI_STEP = 2 };
 struct AdviArgs {
@@ -77,10 +93,11 @@ struct PpcArgs {
   int* counts_rng;              // [n_gen][K*S] or null
 };
 
-size_t gene_kernel_lds_bytes(int CM, int S, int C, int lanes_per_gene, int groups_per_wave);
-hipError_t launch_gene_kernel(int CM, const GeneArgs& a, int nchains, hipStream_t st);
+hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st);
+hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_step_kernel(const StepArgs& a, int nchains, hipStream_t st);
 hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st);
+hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_advi_kernel(const AdviArgs& a, int nblocks, hipStream_t st);
 hipError_t launch_advi_elbo_kernel(const AdviElboArgs& a, hipStream_t st);
 hipError_t launch_ppc_kernel(const PpcArgs& a, hipStream_t st);

@@ -1,24 +1,22 @@
 // ppcx_kernels.hip -- gfx950 kernels of the NB hierarchical NUTS / posterior-predictive engine.
 //
-//   ppcx_gene_kernel<CM>   one launch per leapfrog, one workgroup per tile of genes and chain, three phases:
-//                           P  one lane per gene: the pre-operations of the chain's command on the gene's coordinates,
-//                              first half kick + drift, the gene's constants (phi, Stirling excess, A);
-//                           C  L lanes per gene: streams the gene's row of the int32 count matrix and reduces it to a
-//                              handful of sums. Replaces lp_reduce + map_rect + X*alpha of
-//                              inst/stan/negBinomial_MPI.stan:58-120,:205,:226-240;
-//                           E  one lane per gene: priors (.stan:219-223), gradient, second half kick, NUTS tree
-//                              bookkeeping of the gene's coordinates, the tile's partial sums.
-//   ppcx_step_kernel        reduction of the tiles' partial sums, hyper-parameters, NUTS/adaptation state machine
-//                           (ppcx_nuts.h), next command.
+//   ppcx_loglik_kernel<L,CM> "kernel A1": streams the int32 count matrix once per gradient evaluation and reduces
+//                           it to a handful of sums per gene. Replaces lp_reduce + map_rect + X*alpha of
+//                           inst/stan/negBinomial_MPI.stan:58-120,:205,:226-240.
+//   ppcx_close_kernel<CM>   "kernel A2": per gene: priors (.stan:219-223), gradient, second half kick of the
+//                           leapfrog, NUTS tree bookkeeping of the gene's coordinates, block partial sums.
+//   ppcx_update_kernel      "kernel B": reduction of A's block partials, hyper-parameters, NUTS/adaptation
+//                           state machine (ppcx_nuts.h) and the per-coordinate updates of the next command.
 //   ppcx_ppc_kernel         generated quantities (.stan:259-266) + credible-interval summary
 //                           (R/utilities.R:685-703 / :733-784): NB draws straight into LDS, order
 //                           statistics by bisection on the value, type-7 quantiles, mean, sd.
 //   ppcx_gather_kernel      column gather of the retained draws.
 //
-// Work decomposition of phase C: a gene is owned by L lanes of one wavefront (L in {4,...,64}, chosen per
-// problem); lanes stride over that gene's samples, read the per-sample constants from LDS, and combine with an L-lane
-// xor butterfly. Per-tile partial sums go to a slab that the step kernel reduces in a fixed order, so results are
-// bitwise reproducible for a fixed geometry.
+// Work decomposition of kernel A1 (DESIGN.md "lp/grad kernel"): a gene is owned by L lanes of one
+// wavefront (L in {1,2,4,...,64}, chosen per problem so that ceil(S/L)*L wastes few lanes and the
+// launch fills 1024 SIMDs evenly); lanes stride over that gene's samples, read the per-sample
+// constants from LDS, and combine with an L-lane xor-shuffle butterfly. Per-block partial sums go to a
+// slab that kernel B reduces in a fixed order, so results are bitwise reproducible for a fixed grid.
 #include <hip/hip_runtime.h>
 #include "ppcx_gene.h"
 #include "ppcx_kernels.h"
@@ -26,9 +24,99 @@
 namespace ppcx {
 
 // -----------------------------------------------------------------------------------------------------
-// DPP helpers: v of lane i moved by a DPP control word (data-parallel primitives: a VALU move, no LDS round trip);
-// lanes the control leaves without a source, or outside row_mask, receive 0
+// kernel A1: the log-likelihood kernel. Streams the count matrix once and leaves, per gene, the sums of
+// GeneSumsV (ppcx_model.h): the likelihood part of the gene's log density, its d/dphi part, sum rho
+// (+ sum X_sc rho for genes with slopes).
 // -----------------------------------------------------------------------------------------------------
+#ifndef PPCX_LOGLIK_OCC
+#define PPCX_LOGLIK_OCC 4
+#endif
+__device__ __forceinline__ double wave_xor_add_rt(double v, int lane_xor_mask) {      // run-time mask: ds_bpermute
+  const int src = (int)((threadIdx.x ^ (unsigned)lane_xor_mask) & 63u) << 2;
+  const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+  return v + __hiloint2double(hi, lo);
+}
+// The launch has up to two segments (host: choose_launch): the first a.nb0 workgroups per chain take the first a.G0
+// gene positions of the host's gene order with L = 2^lgL lanes per gene -- whole rounds of resident wavefronts -- and
+// the remaining a.nb1 workgroups take the rest with 2L lanes per gene: twice as many wavefronts of half the duration,
+// which fill the last, partial round (a single-L launch of 2.4 rounds idles through 0.6 of a round; 2 + 0.9 half
+// rounds does not). L is a run-time value of the workgroup, so both segments run the same code.
+template <int CM>
+__global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(LoglikArgs a) {
+  extern __shared__ double lds[];
+  // grid = (chains, gene blocks): the chain is the fast index, so the dispatch order is the host's gene order
+  // (expensive genes first) for all chains together, and the tail of the launch consists of cheap workgroups
+  // and workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids c*8 + (gblock & 7) inside every run
+  // of 8 gene blocks x chains put the chains of one gene block on ONE XCD, so its L2 fetches the rows once
+  const int nch = gridDim.x, ngblocks = a.nb0 + a.nb1;
+  const int lin = blockIdx.y * nch + blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
+  const int chain = r >> 3, gb0 = run * 8 + (r & 7);
+  if (gb0 >= ngblocks) return;
+  const Cmd& c = a.cmds[chain];
+  if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
+  const bool seg1 = gb0 >= a.nb0;
+  const int lgL = seg1 ? (a.lgL < 6 ? a.lgL + 1 : 6) : a.lgL;
+  const int L = 1 << lgL, GPW = 64 >> lgL;       // lanes per gene, genes per wavefront
+  const int gblock = seg1 ? gb0 - a.nb0 : gb0, nseg = seg1 ? a.nb1 : a.nb0;
+  const int pos0 = seg1 ? a.G0 : 0, npos = seg1 ? a.d.G - a.G0 : a.G0;
+  constexpr int NS = GeneSums<CM>::N;
+  const Dims& d = a.d;
+  const int S = d.S, C = d.C;
+  double* stab = lds;                          // log table: 256 x 1/c then 256 x log c (4 KB)
+  double* sE = lds + 2 * kLogTabSize;          // exp(exposure_s)
+  double* sExpo = sE + S;
+  double* sX = sExpo + S;                      // S x C column-major
+  const int tid = threadIdx.x;
+  const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
+  double* sums = a.sums + (long)chain * NS * d.G;
+  const int wave = tid >> 6, lane = tid & 63, sub = lane & (L - 1), gl = lane >> lgL;
+  const int ngroups = (npos + GPW - 1) >> (6 - lgL);
+  int grp = gblock * 4 + wave;
+  GeneCtx<CM> x;
+  // the first group's coordinates are requested before the LDS fill, so that the two round trips overlap
+  if (grp < ngroups) { const int p = grp * GPW + gl; gene_load<CM>(d, c, v, p < npos ? a.order[pos0 + p] : d.G, x); }
+  for (int i = tid; i < 2 * kLogTabSize; i += 256) stab[i] = a.logtab[i];
+  const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
+  for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
+  if (any_generic) {
+    for (int i = tid; i < S; i += 256) sExpo[i] = a.exposure[i];
+    for (int i = tid; i < S * C; i += 256) sX[i] = a.X[i];
+  }
+  __syncthreads();
+  for (; grp < ngroups; grp += nseg * 4) {
+    if (grp != gblock * 4 + wave) { const int p = grp * GPW + gl; gene_load<CM>(d, c, v, p < npos ? a.order[pos0 + p] : d.G, x); }
+    gene_consts<CM>(x, stab);
+    CellAcc<CM> acc; acc.zero();
+    const int lo = a.low_start[x.gg];
+    gene_cells<CM>(d, x, a.counts + (long)x.gg * S, a.low + lo, a.low_start[x.gg + 1] - lo, sE, sExpo, sX, stab, sub, L, acc);
+    GeneSumsV<CM> o;
+    cell_acc_close<CM>(x.gp, acc, stab, sub == 0 ? (double)a.n_hi[x.gg] : 0.0, &o);
+    // L-lane butterfly: every lane of the gene ends with the gene totals
+    for (int msk = 1; msk < L; msk <<= 1) {
+      o.lik = wave_xor_add_rt(o.lik, msk); o.dph = wave_xor_add_rt(o.dph, msk); o.Sr = wave_xor_add_rt(o.Sr, msk);
+      if (any_generic) {
+#pragma unroll
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) o.Tx[cc] = wave_xor_add_rt(o.Tx[cc], msk);
+      }
+    }
+    if (x.active && sub == 0) {
+      const long G = d.G;
+      sums[0 * G + x.gg] = o.lik; sums[1 * G + x.gg] = o.dph; sums[2 * G + x.gg] = o.Sr;
+      if (any_generic) {
+#pragma unroll
+        for (int cc = 0; cc < CM; ++cc) if (cc < C) sums[(3 + cc) * G + x.gg] = o.Tx[cc];
+      }
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// kernel A2: one thread per gene closes it -- priors, gradient, second half kick of the gene's coordinates,
+// U-turn dot products and subtree slots -- and the workgroup leaves its partial sums in a slab.
+// -----------------------------------------------------------------------------------------------------
+// v of lane i moved by a DPP control word (data-parallel primitives: a VALU move, no LDS round trip); lanes the
+// control leaves without a source, or outside row_mask, receive 0
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_take(double v) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
@@ -46,260 +134,70 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
   v += dpp_take<0x143, 0xc>(v);
   return v;
 }
-__device__ __forceinline__ double wave_xor_add_rt(double v, int lane_xor_mask) {      // run-time mask: ds_bpermute
-  const int src = (int)((threadIdx.x ^ (unsigned)lane_xor_mask) & 63u) << 2;
-  const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
-  const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
-  return v + __hiloint2double(hi, lo);
-}
-
-// -----------------------------------------------------------------------------------------------------
-// gene kernel: one workgroup = one tile of TG = 4 (64 / L) R <= 64 gene positions of the host's gene order, for one
-// chain. Phases P and E are latency bound (dependent global loads), so their work is spread over the four wavefronts
-// by COORDINATE: wavefront j owns coordinate j (intercept, sigma_raw, slopes) of the tile's genes, lane t the gene.
-// -----------------------------------------------------------------------------------------------------
-#ifndef PPCX_GENE_OCC
-#define PPCX_GENE_OCC 4
-#endif
-// what phase P leaves in LDS for the lanes of phase C and for phase E
-template <int CM>
-struct GeneRec {
-  double coef[CM];
-  double sigma_raw, phi, invphi, A, A1, dlt, dps;
-  int gg, flags, low_lo, low_n;
-};
-enum GeneRecFlag : int { GR_ACTIVE = 1, GR_SLOPES = 2, GR_TWO = 4, GR_FAST = 8 };
-template <int CM> struct GeneLds {
-  static constexpr int kRecDoubles = (int)(sizeof(GeneRec<CM>) / sizeof(double));
-  static constexpr int kStats = 4 + 2 * CM;   // Sy, SyE, ncell, Lg1, SyX[CM], SX[CM]
-  // per tile: records and hand-over sums of up to 64 genes, coordinate values / gradients and fresh kinetic energies
-  // per (coordinate, gene), the genes' sufficient statistics, the wavefronts' partial sums
-  static constexpr int kTileDoubles = 64 * (kRecDoubles + GeneSums<CM>::N + 2 * (CM + 1) + kStats) + 4 * PT_COUNT;
-};
-
 template <int N>
-__device__ __forceinline__ void wave_accumulate(double* vals, double* wrow, int lane) {   // wrow[k] += wavefront sum of vals[k]
+__device__ __forceinline__ void block_accumulate(double* vals, double* wacc, int wave, int lane) {
 #pragma unroll
   for (int k = 0; k < N; ++k) vals[k] = wave_sum_to_lane63(vals[k]);
   if (lane == 63) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) wrow[k] += vals[k];
+    for (int k = 0; k < N; ++k) wacc[wave * PT_COUNT + k] = vals[k];
   }
 }
 
 template <int CM>
-__global__ __launch_bounds__(256, PPCX_GENE_OCC) void ppcx_gene_kernel(GeneArgs a) {
-  extern __shared__ double lds[];
+__global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
   constexpr int NCM = CM + 1;
   constexpr int NS = GeneSums<CM>::N;
-  constexpr int NR = GeneLds<CM>::kRecDoubles;
-  constexpr int NST = GeneLds<CM>::kStats;
-  constexpr int NJ = (NCM + 3) / 4;            // coordinates a wavefront owns
-  // grid = (chains, tiles): the chain is the fast index, so the dispatch order is the host's gene order (expensive
-  // genes first) for all chains together and the tail of the launch consists of cheap workgroups; workgroups are dealt
-  // to the 8 XCDs round-robin in dispatch order: ids c*8 + (tile & 7) inside every run of 8 tiles x chains put the
-  // chains of one tile on ONE XCD, so its L2 fetches the rows once
-  const int nch = gridDim.x;
-  const int lin = blockIdx.y * nch + blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
-  const int chain = r >> 3, tile = run * 8 + (r & 7);
-  if (tile >= a.ntiles) return;
+  __shared__ double wacc[4 * PT_COUNT];
+  const int chain = blockIdx.y;
   const Cmd& c = a.cmds[chain];
-  if (c.type == CMD_DONE) return;
+  if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
   const Dims& d = a.d;
-  const int S = d.S, C = d.C;
-  const int lgL = a.lgL, L = 1 << lgL, GPW = 64 >> lgL, R = a.groups_per_wave;
-  const int TG = 4 * GPW * R;                  // genes of a tile (<= 64)
-  double* stab = lds;                          // log table: 256 x 1/c then 256 x log c (4 KB)
-  double* sE = lds + 2 * kLogTabSize;          // exp(exposure_s)   (+ 64 entries of padding: the sweep reads ahead)
-  double* sExpo = sE + S + 64;
-  double* sX = sExpo + S;                      // S x C column-major (+ 64)
-  double* srec = sX + (long)S * C + 64;        // [64] GeneRec
-  double* ssum = srec + 64 * NR;               // [64][NS] per-gene sums of phase C
-  double* sq = ssum + 64 * NS;                 // [NCM][64] coordinate values (phase P), then their gradients (phase E)
-  double* st0 = sq + 64 * NCM;                 // [NCM][64] kinetic energy of momenta drawn in phase P
-  double* sst = st0 + 64 * NCM;                // [NST][64] sufficient statistics of the tile's genes
-  double* wacc = sst + 64 * NST;               // [4][PT_COUNT] wavefront partial sums
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
-  double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
-  const int pos0 = tile * TG;
-  // ---- phase P, first part: wavefront j, lane t = coordinate j of gene t: the command's pre-operations, first half
-  // kick and drift. The loads go out before the LDS fill, so that the two round trips overlap.
-  const int gT = (lane < TG && pos0 + lane < d.G) ? a.order[pos0 + lane] : d.G;
-  GeneCtx<CM> xt;
-  gene_index<CM>(d, gT, xt);
-  int idw[NJ]; bool on[NJ];                    // this thread's coordinates (selected without run-time indexing of idx[])
+  const double* sums = a.sums + (long)chain * NS * d.G;
+  const int g = blockIdx.x * 256 + tid;
+  const bool any_generic = !d.x0_is_one || (d.C >= 2 && d.K > 0);
+  GeneCtx<CM> x;
+  gene_load<CM>(d, c, v, g, x);
+  GeneSumsV<CM> acc;
+  acc.lik = acc.dph = acc.Sr = 0.0;
 #pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    const int j = wave + 4 * jj;
-    idw[jj] = 0;
+  for (int cc = 0; cc < CM; ++cc) acc.Tx[cc] = 0.0;
+  if (x.active) {
+    const long G = d.G;
+    acc.lik = sums[0 * G + g]; acc.dph = sums[1 * G + g]; acc.Sr = sums[2 * G + g];
+    if (any_generic) {
 #pragma unroll
-    for (int q2 = 0; q2 < NCM; ++q2) if (q2 == j) idw[jj] = xt.idx[q2];
-    on[jj] = j < NCM && j < xt.ncoord;
-  }
-#pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    const int j = wave + 4 * jj;
-    if (j < NCM) {
-      double T0 = 0.0;
-#ifdef PPCX_TIMING_SKIP_UPDATE
-      const double q = on[jj] ? v.at(V_Q0 + 3 * c.dir, idw[jj]) : 0.0;
-#else
-      const double q = on[jj] ? coord_update(d, c, v, idw[jj], draws, &T0) : 0.0;
-#endif
-      sq[j * 64 + lane] = q; st0[j * 64 + lane] = T0;
+      for (int cc = 0; cc < CM; ++cc) if (cc < d.C) acc.Tx[cc] = sums[(3 + cc) * G + g];
     }
   }
-  if (c.type == CMD_FLUSH) return;             // the last command of a chain only stores: nothing to evaluate
-  // the genes' sufficient statistics for phase E: field k of gene t by wavefront k mod 4
-  for (int k = wave; k < NST; k += 4) {
-    const long g = xt.gg;
-    double val;
-    if (k == 0) val = a.Sy[g]; else if (k == 1) val = a.SyE[g]; else if (k == 2) val = a.ncell[g]; else if (k == 3) val = a.Lg1[g];
-    else if (k < 4 + CM) val = (k - 4) < C ? a.SyX[(long)(k - 4) * d.G + g] : 0.0;
-    else val = (k - 4 - CM) < C ? a.SX[(long)(k - 4 - CM) * d.G + g] : 0.0;
-    sst[k * 64 + lane] = val;
-  }
-  for (int i = tid; i < 2 * kLogTabSize; i += 256) stab[i] = a.logtab[i];
-  for (int i = tid; i < 4 * PT_COUNT; i += 256) wacc[i] = 0.0;
-  const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
-  for (int i = tid; i < S + 64; i += 256) sE[i] = i < S ? a.sampleE[i] : 0.0;
-  if (any_generic) {
-    for (int i = tid; i < S; i += 256) sExpo[i] = a.exposure[i];
-    for (int i = tid; i < S * C + 64; i += 256) sX[i] = i < S * C ? a.X[i] : 0.0;
-  }
-  __syncthreads();
-  // ---- phase P, second part: the gene's constants, one lane per gene
-#ifdef PPCX_TIMING_SKIP_CONSTS
-  if (wave == 0 && lane < TG && sq[0] == 1.2345e-300) {
-#else
-  if (wave == 0 && lane < TG) {
-#endif
-    double qp[NCM];
+  double pn[NCM], minv[NCM], part[10];
+  gene_finish<CM>(d, c, v, x, acc, a.Sy, a.SyE, a.SyX, a.SX, a.ncell, a.Lg1, part, pn, minv);
+  block_accumulate<10>(part, wacc, wave, lane);
+  if (c.type == CMD_LEAF) {
+    NodeVals nv[NCM];
 #pragma unroll
-    for (int j = 0; j < NCM; ++j) qp[j] = sq[j * 64 + lane];
-    gene_params<CM>(d, qp, xt);
-    gene_consts<CM>(xt, stab);
-    GeneRec<CM>& rec = *reinterpret_cast<GeneRec<CM>*>(srec + (long)lane * NR);
+    for (int j = 0; j < NCM; ++j) nv[j] = NodeVals{pn[j], pn[j]};
+    for (int lev = 0; lev < c.n_merge; ++lev) {
+      double dots[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int cc = 0; cc < CM; ++cc) rec.coef[cc] = xt.gp.coef[cc];
-    rec.sigma_raw = xt.gp.sigma_raw; rec.phi = xt.gp.phi; rec.invphi = xt.gp.invphi; rec.A = xt.gp.A; rec.A1 = xt.gp.A1;
-    rec.dlt = xt.gp.dlt; rec.dps = xt.gp.dps;
-    rec.gg = xt.gg;
-    rec.flags = (xt.active ? GR_ACTIVE : 0) | (xt.has_slopes ? GR_SLOPES : 0) | (xt.two ? GR_TWO : 0) | (xt.fast ? GR_FAST : 0);
-    const int lo = a.low_start[xt.gg];
-    rec.low_lo = lo; rec.low_n = xt.active ? a.low_start[xt.gg + 1] - lo : 0;
-  }
-  __syncthreads();
-  // ---- phase C: L lanes per gene
-  {
-    const int sub = lane & (L - 1), gl = lane >> lgL;
-    for (int rr = 0; rr < R; ++rr) {
-      const int slot = (wave * R + rr) * GPW + gl;
-      const GeneRec<CM>& rec = *reinterpret_cast<const GeneRec<CM>*>(srec + (long)slot * NR);
-      GeneCtx<CM> x;
-      x.gg = rec.gg; x.ncoord = 0;
-      const int fl = rec.flags;
-      x.active = (fl & GR_ACTIVE) != 0; x.has_slopes = (fl & GR_SLOPES) != 0; x.two = (fl & GR_TWO) != 0; x.fast = (fl & GR_FAST) != 0;
-#pragma unroll
-      for (int cc = 0; cc < CM; ++cc) x.gp.coef[cc] = rec.coef[cc];
-      x.gp.sigma_raw = rec.sigma_raw; x.gp.phi = rec.phi; x.gp.invphi = rec.invphi; x.gp.A = rec.A; x.gp.A1 = rec.A1;
-      x.gp.dlt = rec.dlt; x.gp.dps = rec.dps;
-      CellAcc<CM> acc; acc.zero();
-#ifndef PPCX_TIMING_SKIP_C
-      gene_cells<CM>(d, x, a.counts + (long)x.gg * S, a.low + rec.low_lo, rec.low_n, sE, sExpo, sX, stab, sub, L, acc);
-#endif
-      GeneSumsV<CM> o;
-      cell_acc_close<CM>(x.gp, acc, stab, sub == 0 ? (double)a.n_hi[x.gg] : 0.0, &o);
-      // L-lane butterfly: every lane of the gene ends with the gene totals
-      for (int msk = 1; msk < L; msk <<= 1) {
-        o.lik = wave_xor_add_rt(o.lik, msk); o.dph = wave_xor_add_rt(o.dph, msk); o.Sr = wave_xor_add_rt(o.Sr, msk);
-        if (any_generic) {
-#pragma unroll
-          for (int cc = 0; cc < CM; ++cc) if (cc < C) o.Tx[cc] = wave_xor_add_rt(o.Tx[cc], msk);
-        }
-      }
-      if (sub == 0) {
-        double* so = ssum + (long)slot * NS;
-        so[0] = o.lik; so[1] = o.dph; so[2] = o.Sr;
-#pragma unroll
-        for (int cc = 0; cc < CM; ++cc) so[3 + cc] = o.Tx[cc];
-      }
+      for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots(v, x.idx[j], lev, pn[j], minv[j], &nv[j], dots);
+      block_accumulate<6>(dots, wacc + PT_DOTS + 6 * lev, wave, lane);
     }
-  }
-  __syncthreads();
-  // ---- phase E, first part (one lane per gene): priors (.stan:219-223), log density and gradient of the gene
-#ifdef PPCX_TIMING_SKIP_E1
-  if (wave == 0 && sq[0] == 1.2345e-300) {
-#else
-  if (wave == 0) {
-#endif
-    GeneSumsV<CM> acc;
-    acc.lik = acc.dph = acc.Sr = 0.0;
+    if (!c.subtree_complete) {
 #pragma unroll
-    for (int cc = 0; cc < CM; ++cc) acc.Tx[cc] = 0.0;
-    double SyX[CM], SX[CM], gnew[NCM], part[10];
-    if (lane < TG) {
-      const GeneRec<CM>& rec = *reinterpret_cast<const GeneRec<CM>*>(srec + (long)lane * NR);
+      for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_store_slot(v, x.idx[j], c.n_merge, pn[j], nv[j]);
+    } else {
+      double top[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int cc = 0; cc < CM; ++cc) xt.gp.coef[cc] = rec.coef[cc];
-      xt.gp.sigma_raw = rec.sigma_raw; xt.gp.phi = rec.phi;
-      const double* so = ssum + (long)lane * NS;
-      acc.lik = so[0]; acc.dph = so[1]; acc.Sr = so[2];
-#pragma unroll
-      for (int cc = 0; cc < CM; ++cc) acc.Tx[cc] = so[3 + cc];
-    }
-#pragma unroll
-    for (int cc = 0; cc < CM; ++cc) { SyX[cc] = sst[(4 + cc) * 64 + lane]; SX[cc] = sst[(4 + CM + cc) * 64 + lane]; }
-    gene_grad<CM>(d, c, xt, acc, sst[lane], sst[64 + lane], SyX, SX, sst[2 * 64 + lane], sst[3 * 64 + lane], gnew, part);
-#pragma unroll
-    for (int j = 0; j < NCM; ++j) sq[j * 64 + lane] = gnew[j];
-    wave_accumulate<7>(part, wacc, lane);      // PT_LP and the six hyper-gradient sums
-  }
-  __syncthreads();
-  // ---- phase E, second part (wavefront j, lane t = coordinate j of gene t): second half kick, kinetic energies, U-turn
-  // dot products and subtree slots
-#ifdef PPCX_TIMING_SKIP_E2
-  if (sq[0] == 1.2345e-300) {
-#else
-  {
-#endif
-    double pnw[NJ], minvw[NJ];
-    double k3[3] = {0.0, 0.0, 0.0};            // PT_T0, PT_T1, PT_NONFINITE
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-      const int j = wave + 4 * jj;
-      pnw[jj] = 0.0; minvw[jj] = 1.0;
-      if (on[jj]) {
-        k3[0] += st0[j * 64 + lane];
-        pnw[jj] = coord_kick(c, v, idw[jj], sq[j * 64 + lane], &minvw[jj], &k3[1], &k3[2]);
-      }
-    }
-    wave_accumulate<3>(k3, wacc + wave * PT_COUNT + PT_T0, lane);
-    if (c.type == CMD_LEAF) {
-      NodeVals nv[NJ];
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) nv[jj] = NodeVals{pnw[jj], pnw[jj]};
-      for (int lev = 0; lev < c.n_merge; ++lev) {
-        double dots[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) if (on[jj]) coord_merge_dots(v, idw[jj], lev, pnw[jj], minvw[jj], &nv[jj], dots);
-        wave_accumulate<6>(dots, wacc + wave * PT_COUNT + PT_DOTS + 6 * lev, lane);
-      }
-      if (!c.subtree_complete) {
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) if (on[jj]) coord_store_slot(v, idw[jj], c.n_merge, pnw[jj], nv[jj]);
-      } else {
-        double top[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) if (on[jj]) coord_top_dots(v, idw[jj], c.dir, pnw[jj], minvw[jj], nv[jj], top);
-        wave_accumulate<6>(top, wacc + wave * PT_COUNT + PT_TOP, lane);
-      }
+      for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_top_dots(v, x.idx[j], c.dir, pn[j], minv[j], nv[j], top);
+      block_accumulate<6>(top, wacc + PT_TOP, wave, lane);
     }
   }
   __syncthreads();
   const int np = parts_used(c);
-  double* slab = a.partials + ((long)chain * a.ntiles + tile) * PT_COUNT;
+  double* slab = a.partials + ((long)chain * gridDim.x + blockIdx.x) * PT_COUNT;
   for (int k = tid; k < np; k += 256) {
     const bool used = k < 10 || (k >= PT_DOTS && k < PT_DOTS + 6 * c.n_merge) || (k >= PT_TOP && c.subtree_complete);
     slab[k] = used ? ((wacc[k] + wacc[PT_COUNT + k]) + wacc[2 * PT_COUNT + k]) + wacc[3 * PT_COUNT + k] : 0.0;
@@ -308,7 +206,8 @@ __global__ __launch_bounds__(256, PPCX_GENE_OCC) void ppcx_gene_kernel(GeneArgs 
 
 // -----------------------------------------------------------------------------------------------------
 // step kernel: one workgroup per chain.
-//  phase REDUCE: fold the gene kernel's slab of per-tile partial sums into PT_COUNT sums in a fixed order. For gene shards these per-shard sums are then added across shards (RCCL all-reduce
+//  phase REDUCE: fold the close kernel's slab (and the T0 slab of the previous update launch) into PT_COUNT sums in
+//                a fixed order. For gene shards these per-shard sums are then added across shards (RCCL all-reduce
 //                between processes, ppcx_sum_shards_kernel inside one process) before phase STEP runs.
 //  phase STEP  : eight lanes of wavefront 0 run the NUTS / adaptation state machine (chain_step): lane k < 6 owns
 //                hyper-parameter k, the scalar logic runs redundantly in registers, run-time-indexed arrays in LDS.
@@ -330,6 +229,7 @@ struct WaveLanes {                              // cooperating lanes 0..7 of one
 
 __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   __shared__ double sm[3][8][32];
+  __shared__ double sT0[256];
   __shared__ double red[PT_COUNT];
   __shared__ double hv[V_COUNT * 8];           // the six hyper coordinates of every per-coordinate vector
   __shared__ Cmd s_ex;
@@ -354,7 +254,7 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
     for (int k = 0; k < 2; ++k) r_hv[k] = tid + 256 * k < NHV ? hvg[tid + 256 * k] : 0.0;
   }
   if (a.phases & STEP_REDUCE) {
-    const double* slab = a.partials + (long)chain * a.ntiles * PT_COUNT;
+    const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
     // one pass: thread (c, ch) sums rows ch, ch+8, ... of columns c, c+32, c+64, loads of several rows in flight; then
     // column v = sum over the eight row groups in a fixed order. All columns are loaded (stale ones included) so that
     // these loads do not wait for the command that says which sums it produced; the selection happens afterwards.
@@ -363,7 +263,7 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
     {
       const bool in2 = c + 64 < PT_COUNT;
 #pragma unroll 4
-      for (int b = ch; b < a.ntiles; b += 8) {
+      for (int b = ch; b < a.nblocks_close; b += 8) {
         const double* row = slab + (long)b * PT_COUNT;
         const double v0 = row[c], v1 = row[c + 32], v2 = in2 ? row[c + 64] : 0.0;
         s0 += v0; s1 += v1; s2 += v2;
@@ -375,11 +275,22 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
     __syncthreads();
     if (tid < PT_COUNT) {
       double t = 0.0;
-      if (tid < np) {
+      if (tid < np && tid != PT_T0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += sm[tid >> 5][k][tid & 31];
       }
       red[tid] = t;
+    }
+    // kinetic energy of freshly drawn momenta: only commands that drew momenta left something in the T0 slab
+    const bool fresh = !done && (exg.pre_flags & (PRE_NEW_TRANSITION | PRE_EPS_TRY)) != 0;
+    if (fresh) {
+      const double* t0s = a.t0 + (long)chain * a.nblocks_update;
+      double s = 0.0;
+      for (int b = tid; b < a.nblocks_update; b += 256) s += t0s[b];
+      sT0[tid] = s;
+      __syncthreads();
+      for (int stp = 128; stp > 0; stp >>= 1) { if (tid < stp) sT0[tid] += sT0[tid + stp]; __syncthreads(); }
+      if (tid == 0) red[PT_T0] = sT0[0];
     }
     __syncthreads();
     if (!(a.phases & STEP_ADVANCE)) { for (int i = tid; i < PT_COUNT; i += 256) rg[i] = red[i]; return; }
@@ -438,6 +349,31 @@ __global__ void ppcx_sum_shards_kernel(ShardSumArgs a) {
   double s = 0.0;
   for (int k = 0; k < a.n_shards; ++k) s += a.bufs[k][i];
   for (int k = 0; k < a.n_shards; ++k) a.bufs[k][i] = s;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// update kernel: apply the command the step kernel just issued to every gene-owned coordinate -- proposal / sample
+// copies, draw storage, Welford / metric updates, momentum refresh (Philox per coordinate), first half kick and
+// drift of the next leapfrog -- and leave the kinetic energy of fresh momenta as per-workgroup partial sums.
+// -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
+  __shared__ double sT0[256];
+  const int chain = blockIdx.y, tid = threadIdx.x;
+  const Cmd& nc = a.cmds[chain];
+  const Dims& d = a.d;
+  double T0 = 0.0;
+  if (nc.type != CMD_DONE) {
+    const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
+    double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
+    for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, nc, v, i, draws, &T0);
+  }
+  // kinetic energy of freshly drawn momenta: only commands that draw momenta leave something (the step kernel's reduce
+  // phase reads the slab for exactly those commands)
+  if ((nc.pre_flags & (PRE_NEW_TRANSITION | PRE_EPS_TRY)) == 0) return;
+  sT0[tid] = T0;
+  __syncthreads();
+  for (int stp = 128; stp > 0; stp >>= 1) { if (tid < stp) sT0[tid] += sT0[tid + stp]; __syncthreads(); }
+  if (tid == 0) a.t0_out[(long)chain * gridDim.x + blockIdx.x] = sT0[0];
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -668,17 +604,19 @@ __global__ void ppcx_fill_kernel(double* p, long n, double val) {
 // -----------------------------------------------------------------------------------------------------
 // launch helpers (host)
 // -----------------------------------------------------------------------------------------------------
-size_t gene_kernel_lds_bytes(int CM, int S, int C, int lanes_per_gene, int groups_per_wave) {
-  (void)lanes_per_gene; (void)groups_per_wave;      // a tile's LDS is sized for 64 genes whatever the geometry
-  const size_t tile = CM <= 2 ? GeneLds<2>::kTileDoubles : (CM <= 4 ? GeneLds<4>::kTileDoubles : GeneLds<8>::kTileDoubles);
-  return sizeof(double) * (2 * kLogTabSize + (size_t)S * (2 + C) + 128 + tile);
+hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st) {
+  const size_t lds_bytes = sizeof(double) * (2 * kLogTabSize + (size_t)a.d.S * (2 + a.d.C));
+  const dim3 grid(nchains, (nblocks + 7) / 8 * 8);
+  if (CM <= 2) hipLaunchKernelGGL((ppcx_loglik_kernel<2>), grid, dim3(256), lds_bytes, st, a);
+  else if (CM <= 4) hipLaunchKernelGGL((ppcx_loglik_kernel<4>), grid, dim3(256), lds_bytes, st, a);
+  else hipLaunchKernelGGL((ppcx_loglik_kernel<8>), grid, dim3(256), lds_bytes, st, a);
+  return hipGetLastError();
 }
-hipError_t launch_gene_kernel(int CM, const GeneArgs& a, int nchains, hipStream_t st) {
-  const size_t lds_bytes = gene_kernel_lds_bytes(CM, a.d.S, a.d.C, 1 << a.lgL, a.groups_per_wave);
-  const dim3 grid(nchains, (a.ntiles + 7) / 8 * 8);
-  if (CM <= 2) hipLaunchKernelGGL((ppcx_gene_kernel<2>), grid, dim3(256), lds_bytes, st, a);
-  else if (CM <= 4) hipLaunchKernelGGL((ppcx_gene_kernel<4>), grid, dim3(256), lds_bytes, st, a);
-  else hipLaunchKernelGGL((ppcx_gene_kernel<8>), grid, dim3(256), lds_bytes, st, a);
+hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st) {
+  const dim3 grid(nblocks, nchains);
+  if (CM <= 2) hipLaunchKernelGGL((ppcx_close_kernel<2>), grid, dim3(256), 0, st, a);
+  else if (CM <= 4) hipLaunchKernelGGL((ppcx_close_kernel<4>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((ppcx_close_kernel<8>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_step_kernel(const StepArgs& a, int nchains, hipStream_t st) {
@@ -687,6 +625,10 @@ hipError_t launch_step_kernel(const StepArgs& a, int nchains, hipStream_t st) {
 }
 hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(ppcx_sum_shards_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st) {
+  hipLaunchKernelGGL(ppcx_update_kernel, dim3(nblocks, nchains), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_advi_kernel(const AdviArgs& a, int nblocks, hipStream_t st) {

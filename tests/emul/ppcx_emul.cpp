@@ -44,29 +44,25 @@ static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, c
   return m;
 }
 
-// the gene kernel with one lane per gene and one gene per tile: phases P (coordinate work of the command), C, E
 template <int CM>
-static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double* draws, double* red) {
+static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double* red) {
   constexpr int NCM = CM + 1;
   const Dims& d = m.d;
   for (int k = 0; k < PT_COUNT; ++k) red[k] = 0.0;
-  if (c.type == CMD_DONE) return;
+  if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
   for (int g = 0; g < d.G; ++g) {
+    // log-likelihood kernel (one lane per gene here)
     GeneCtx<CM> x;
-    gene_index<CM>(d, g, x);
-    double q[NCM], T0 = 0.0;
-    for (int j = 0; j < NCM; ++j) q[j] = j < x.ncoord ? coord_update(d, c, v, x.idx[j], draws, &T0) : 0.0;
-    if (c.type == CMD_FLUSH) continue;
-    red[PT_T0] += T0;
-    gene_params<CM>(d, q, x);
+    gene_load<CM>(d, c, v, g, x);
     gene_consts<CM>(x, log_table());
     CellAcc<CM> acc; acc.zero();
     gene_cells<CM>(d, x, m.counts.data() + (size_t)g * d.S, m.low.data() + m.low_start[g], m.low_start[g + 1] - m.low_start[g],
                    m.E.data(), m.expo.data(), m.X.data(), log_table(), 0, 1, acc);
     GeneSumsV<CM> o;
     cell_acc_close<CM>(x.gp, acc, log_table(), (double)m.nhi[g], &o);
-    // phase E
-    GeneCtx<CM>& x2 = x;
+    // close kernel
+    GeneCtx<CM> x2;
+    gene_load<CM>(d, c, v, g, x2);
     double pn[NCM], minv[NCM], part[10];
     gene_finish<CM>(d, c, v, x2, o, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.SX.data(), m.ncell.data(), m.Lg1.data(), part, pn, minv);
     for (int k = 0; k < 10; ++k) red[k] += part[k];
@@ -80,16 +76,22 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
     }
   }
 }
-static void gene_pass_dispatch(const EmulModel& m, const Cmd& c, const VecRef& v, double* draws, double* red) {
-  if (m.CM == 2) gene_pass<2>(m, c, v, draws, red);
-  else if (m.CM == 4) gene_pass<4>(m, c, v, draws, red);
-  else gene_pass<8>(m, c, v, draws, red);
+static void gene_pass_dispatch(const EmulModel& m, const Cmd& c, const VecRef& v, double* red) {
+  if (m.CM == 2) gene_pass<2>(m, c, v, red);
+  else if (m.CM == 4) gene_pass<4>(m, c, v, red);
+  else gene_pass<8>(m, c, v, red);
 }
-// step kernel: the state machine
-static void step_pass(const EmulModel& m, ChainState& st, const Cmd& ex, const double* red, bool have_parts,
-                      const VecRef& h, const ChainIO& io, Cmd& nc) {
+// kernel B: state machine, then the per-coordinate operations of the new command; returns T0 of the gene coordinates
+static double update_pass(const EmulModel& m, ChainState& st, const Cmd& ex, const double* red, double T0_prev,
+                          bool have_parts, const VecRef& v, const VecRef& h, const ChainIO& io, Cmd& nc) {
   Reduced rd;
-  chain_step(SerialLanes{}, m.d, st.sc, st.ta, ex, red, have_parts, h, io, rd, nc);
+  std::vector<double> r2(red, red + PT_COUNT);
+  r2[PT_T0] = T0_prev;
+  chain_step(SerialLanes{}, m.d, st.sc, st.ta, ex, r2.data(), have_parts, h, io, rd, nc);
+  double T0 = 0.0;
+  if (nc.type != CMD_DONE)
+    for (int i = 3; i < m.d.off_tail; ++i) coord_update(m.d, nc, v, i, io.draws, &T0);
+  return T0;
 }
 
 struct EmulCfg { int chains, iter, warmup; unsigned long long seed; double adapt_delta; int max_treedepth;
@@ -108,10 +110,10 @@ int emul_log_prob_grad(int G, int S, int C, int K, const int32_t* counts, const 
   Cmd c, n; cmd_clear(c);
   ChainIO io; memset(&io, 0, sizeof io);
   VecRef v{vecs.data(), D}, h{hv.data(), 8};
-  step_pass(m, st, c, red.data(), false, h, io, n); c = n;
+  double T0 = update_pass(m, st, c, red.data(), 0.0, false, v, h, io, n); c = n;
   while (c.type != CMD_DONE) {
-    gene_pass_dispatch(m, c, v, io.draws, red.data());
-    step_pass(m, st, c, red.data(), true, h, io, n); c = n;
+    gene_pass_dispatch(m, c, v, red.data());
+    T0 = update_pass(m, st, c, red.data(), T0, true, v, h, io, n); c = n;
   }
   *lp = st.sc.lp_eval;
   for (int i = 0; i < D; ++i) grad[i] = vecs[(size_t)V_G1 * D + i];
@@ -143,11 +145,11 @@ int emul_fit_nuts(int G, int S, int C, int K, const int32_t* counts, const doubl
     io.out.treedepth = treedepth + (size_t)ch * cfg->iter; io.out.n_leapfrog = n_leapfrog + (size_t)ch * cfg->iter;
     io.out.divergent = divergent + (size_t)ch * cfg->iter; io.out.accept = accept + (size_t)ch * cfg->iter;
     VecRef v{vecs.data(), D}, h{hv.data(), 8};
-    step_pass(m, st, c, red.data(), false, h, io, n); c = n;
+    double T0 = update_pass(m, st, c, red.data(), 0.0, false, v, h, io, n); c = n;
     long guard = 0;
     while (c.type != CMD_DONE) {
-      gene_pass_dispatch(m, c, v, io.draws, red.data());
-      step_pass(m, st, c, red.data(), true, h, io, n); c = n;
+      gene_pass_dispatch(m, c, v, red.data());
+      T0 = update_pass(m, st, c, red.data(), T0, true, v, h, io, n); c = n;
       if (++guard > 50000000L) { rc = -5; break; }
     }
     if (st.sc.error) rc = -3;
