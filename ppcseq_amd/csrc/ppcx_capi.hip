@@ -368,7 +368,7 @@ static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int
 static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
   UpdateArgs ua;
   ua.d = m->d; ua.cmds = w.cmds[w.launches & 1]; ua.vecs = w.vecs; ua.Dpad = w.Dpad;
-  ua.draws = io.draws; ua.draws_chain_stride = io.draws_stride; ua.t0_out = w.t0[0];
+  ua.draws = io.draws; ua.draws_chain_stride = io.draws_stride; ua.t0_out = w.t0[0]; ua.logtab = m->d_logtab;
   hipError_t e = launch_update_kernel(ua, w.nb_update, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("update kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
@@ -724,7 +724,7 @@ static int advi_launch(AdviRun& r, int op, int n_slots, double eta_scaled, int f
   AdviArgs a;
   a.d = r.m->d; a.vecs = r.w->vecs; a.Dpad = r.w->Dpad; a.hyper = r.w->hyper_vecs[0]; a.cmds = r.w->cmds[0]; a.red = r.w->red;
   a.op = op; a.n_slots = n_slots; a.first_iter = first_iter; a.eta_scaled = eta_scaled; a.k0 = r.k0; a.prev_draw = prev_draw;
-  a.draw_base = draw_base; a.out_draws = out_draws; a.out_row0 = out_row0; a.omega_part = r.d_omega;
+  a.draw_base = draw_base; a.out_draws = out_draws; a.out_row0 = out_row0; a.omega_part = r.d_omega; a.logtab = r.m->d_logtab;
   hipError_t e = launch_advi_kernel(a, r.nb_advi, r.w->stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("advi kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
@@ -811,6 +811,7 @@ extern "C" int ppcx_fit_advi(ppcx_model* m, const ppcx_advi_config* cfg, ppcx_fi
     c.hy = make_hyper(c.hyp_q, d.lambda_mu_mu);
     HIPCHK(hipMemcpyAsync(w.vecs + (size_t)V_Q1 * w.Dpad, q0.data(), sizeof(double) * D, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(w.cmds[0], &c, sizeof(Cmd), hipMemcpyHostToDevice, st));
+    { RunIO io0; if ((rc = launch_update(m, w, 1, io0)) != PPCX_OK) return rc; }   // a command without a step: only the constants of the uploaded point
     if ((rc = advi_eval(r, 1)) != PPCX_OK) return rc;
     HIPCHK(hipMemcpyAsync(red.data(), w.red, sizeof(double) * PT_COUNT, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -1,8 +1,9 @@
 // ppcx_gene.h -- the per-gene bodies of the kernels:
-//   log-likelihood kernel : gene_load -> gene_consts -> gene_cells (per lane) -> [L-lane butterfly] -> per-gene sums
+//   log-likelihood kernel : gene_load -> gene_cells (per lane) -> [L-lane butterfly] -> per-gene sums
 //   close kernel          : gene_load -> gene_finish -> tree bookkeeping (coord_merge_dots / coord_store_slot /
 //                           coord_top_dots)
-//   update kernel         : chain_step (scalar state machine) and coord_update (per coordinate)
+//   update kernel         : coord_update (per coordinate: the command's coordinate work + coord_consts)
+//   step kernel           : chain_step (scalar state machine)
 // Shared by the gfx950 kernel (ppcx_kernels.hip) and the CPU emulation harness in tests/emul.
 #pragma once
 #include "ppcx_nuts.h"
@@ -19,8 +20,24 @@ struct GeneCtx {
   GeneParams<CM> gp;
 };
 
-// load the gene's (already drifted) coordinates: coefficients, sigma_raw, phi
-template <int CM>
+// Constants of the cell loop that depend on ONE coordinate, written next to the coordinate by whoever moves it (the
+// update kernel, the ADVI kernel), one thread per coordinate, instead of being recomputed by every lane of every gene
+// in the log-likelihood kernel:  intercept, slopes: exp(q);  sigma_raw: phi = exp(-q) (.stan:203), 1/phi and the
+// Stirling excess of phi (ppcx_math.h). `tab` is the log table (global memory here).
+PPCX_HD void coord_consts(const Dims& d, const VecRef& v, int i, double q, const double* tab) {
+  if (i >= d.off_sigma_raw && i < d.off_tail) {
+    const double phi = fast_exp(-q);
+    double dlt, dps;
+    stirling_excess(phi, -q, tab, PPCX_WAVE_ANY(phi < 8.0), &dlt, &dps);
+    v.at(V_C0, i) = phi; v.at(V_C1, i) = fast_rcp(phi); v.at(V_C2, i) = dlt; v.at(V_C3, i) = dps;
+  } else if (i >= d.off_intercept && i < d.off_sigma_raw) {
+    v.at(V_C0, i) = fast_exp(q);
+  }
+}
+
+// load the gene's (already drifted) coordinates -- coefficients, sigma_raw, phi -- and, for the log-likelihood kernel
+// (CELLS), the constants of the cell loop that coord_consts left next to them
+template <int CM, bool CELLS>
 PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, GeneCtx<CM>& x) {
   constexpr int NCM = CM + 1;
   x.active = g < d.G;
@@ -41,17 +58,13 @@ PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, Gene
 #pragma unroll
   for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < C) ? q[cc + 1] : 0.0;
   x.gp.sigma_raw = q[1];
-  x.gp.phi = fast_exp(-x.gp.sigma_raw);        // sigma = 1 ./ exp(sigma_raw)   (.stan:203)
+  x.gp.phi = x.active ? v.at(V_C0, x.idx[1]) : 1.0;        // sigma = 1 ./ exp(sigma_raw)   (.stan:203)
   x.gp.invphi = 0.0; x.gp.dlt = 0.0; x.gp.dps = 0.0; x.gp.A = 0.0; x.gp.A1 = 0.0;
-}
-// the per-gene constants of the cell loop
-template <int CM>
-PPCX_HD void gene_consts(GeneCtx<CM>& x, const double* tab) {
-  GeneParams<CM>& gp = x.gp;
-  gp.invphi = fast_rcp(gp.phi);
-  stirling_excess(gp.phi, -gp.sigma_raw, tab, PPCX_WAVE_ANY(gp.phi < 8.0), &gp.dlt, &gp.dps);
-  gp.A = fast_exp(gp.coef[0] + gp.sigma_raw);
-  if (PPCX_WAVE_ANY(x.two)) gp.A1 = fast_exp(gp.coef[0] + gp.coef[1] + gp.sigma_raw);
+  if (CELLS && x.active) {
+    x.gp.invphi = v.at(V_C1, x.idx[1]); x.gp.dlt = v.at(V_C2, x.idx[1]); x.gp.dps = v.at(V_C3, x.idx[1]);
+    x.gp.A = v.at(V_C0, x.idx[0]) * x.gp.invphi;           // exp(intercept + sigma_raw)
+    if (x.two) x.gp.A1 = x.gp.A * v.at(V_C0, x.idx[2]);    // ... + slope
+  }
 }
 
 // The gene's cells, split over its L lanes: (1) the row sweep s = sub, sub+L, ... evaluates the cells with y >= 8 --
@@ -167,16 +180,21 @@ PPCX_HD void gene_finish(const Dims& d, const Cmd& c, const VecRef& v, const Gen
   }
 }
 
-// per-coordinate part of kernel B for one gene-owned coordinate: pre-operations of the new command, then the
-// first half kick and the drift of the next leapfrog (written in place into the end being advanced)
+// update kernel, one gene-owned coordinate: pre-operations of the new command, then the first half kick and the drift of
+// the next leapfrog (written in place into the end being advanced) and the constants of the new position. A command
+// without a step (eps = 0: the evaluation of a given point) leaves position and momentum as they are.
 PPCX_HD void coord_update(const Dims& d, const Cmd& nc, const VecRef& v, int i, double* draws, double* T0,
-                          const CoordCache* cc = nullptr) {
+                          const double* tab, const CoordCache* cc = nullptr) {
   const CoordVals cv = coord_pre(nc, v, i, i, global_flat(d, i), true, draws, d.D, nc.k0, nc.k1, T0, cc);
-  if (nc.type != CMD_FLUSH) {
+  if (nc.type == CMD_FLUSH) return;
+  double qn = cv.q;
+  if (nc.eps != 0.0) {
     const double ph = cv.p + 0.5 * nc.eps * cv.g;
+    qn = cv.q + nc.eps * cv.minv * ph;
     v.at(V_P0 + 3 * nc.dir, i) = ph;
-    v.at(V_Q0 + 3 * nc.dir, i) = cv.q + nc.eps * cv.minv * ph;
+    v.at(V_Q0 + 3 * nc.dir, i) = qn;
   }
+  coord_consts(d, v, i, qn, tab);
 }
 
 // Kernel B, serial part (one thread per chain): finish the hyper coordinates of the executed command,

@@ -64,6 +64,7 @@ struct UpdateArgs {
   double* vecs; long Dpad;
   double* draws; long draws_chain_stride;
   double* t0_out;               // [chains][nblocks_update]
+  const double* logtab;         // log table (global memory): coord_consts
 };
 
 enum AdviOp : int { ADVI_DRAW = 0, ADVI_RESET = 1, ADVI_STEP = 2 };
@@ -78,6 +79,7 @@ struct AdviArgs {
   uint32_t k0, prev_draw, draw_base;
   double* out_draws; int out_row0;   // non-null: write the draws to [row][D] instead of the evaluation slots
   double* omega_part;           // [nblocks]
+  const double* logtab;         // log table (global memory): coord_consts
 };
 struct AdviElboArgs { Dims d; const Cmd* cmds; const double* red; int n_slots; double* acc; const double* omega_part; int n_omega_parts; };
 

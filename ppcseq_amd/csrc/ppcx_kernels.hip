@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
   int grp = gblock * 4 + wave;
   GeneCtx<CM> x;
   // the first group's coordinates are requested before the LDS fill, so that the two round trips overlap
-  if (grp < ngroups) { const int p = grp * GPW + gl; gene_load<CM>(d, c, v, p < npos ? a.order[pos0 + p] : d.G, x); }
+  if (grp < ngroups) { const int p = grp * GPW + gl; gene_load<CM, true>(d, c, v, p < npos ? a.order[pos0 + p] : d.G, x); }
   for (int i = tid; i < 2 * kLogTabSize; i += 256) stab[i] = a.logtab[i];
   const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
   for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
@@ -85,8 +85,7 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
   }
   __syncthreads();
   for (; grp < ngroups; grp += nseg * 4) {
-    if (grp != gblock * 4 + wave) { const int p = grp * GPW + gl; gene_load<CM>(d, c, v, p < npos ? a.order[pos0 + p] : d.G, x); }
-    gene_consts<CM>(x, stab);
+    if (grp != gblock * 4 + wave) { const int p = grp * GPW + gl; gene_load<CM, true>(d, c, v, p < npos ? a.order[pos0 + p] : d.G, x); }
     CellAcc<CM> acc; acc.zero();
     const int lo = a.low_start[x.gg];
     gene_cells<CM>(d, x, a.counts + (long)x.gg * S, a.low + lo, a.low_start[x.gg + 1] - lo, sE, sExpo, sX, stab, sub, L, acc);
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
   const int g = blockIdx.x * 256 + tid;
   const bool any_generic = !d.x0_is_one || (d.C >= 2 && d.K > 0);
   GeneCtx<CM> x;
-  gene_load<CM>(d, c, v, g, x);
+  gene_load<CM, false>(d, c, v, g, x);
   GeneSumsV<CM> acc;
   acc.lik = acc.dph = acc.Sr = 0.0;
 #pragma unroll
@@ -236,14 +235,14 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   __shared__ ChainState s_st;
   __shared__ Reduced s_rd;
   constexpr int NST = (int)(sizeof(ChainState) / sizeof(int)), NCMD = (int)(sizeof(Cmd) / sizeof(int)), NHV = V_COUNT * 8;
-  static_assert(NST <= 4 * 256 && NCMD <= 256 && NHV <= 2 * 256 && PT_COUNT <= 96, "step kernel staging sizes");
+  static_assert(NST <= 4 * 256 && NCMD <= 256 && NHV <= 3 * 256 && PT_COUNT <= 96, "step kernel staging sizes");
   const int chain = blockIdx.x, tid = threadIdx.x;
   const ChainState* st_in = a.states_in + chain;
   const bool done = st_in->sc.phase == PH_DONE;
   double* rg = a.red + (long)chain * PT_COUNT;
   // the chain's command, state and hyper vectors are requested now and parked in registers, so that their round trip
   // overlaps the reduction below
-  int r_st[4], r_cmd = 0; double r_hv[2];
+  int r_st[4], r_cmd = 0; double r_hv[3];
   {
     const int* s2 = reinterpret_cast<const int*>(st_in);
 #pragma unroll
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
     if (tid < NCMD) r_cmd = reinterpret_cast<const int*>(a.cmds_in + chain)[tid];
     const double* hvg = a.hyper_in + (long)chain * NHV;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) r_hv[k] = tid + 256 * k < NHV ? hvg[tid + 256 * k] : 0.0;
+    for (int k = 0; k < 3; ++k) r_hv[k] = tid + 256 * k < NHV ? hvg[tid + 256 * k] : 0.0;
   }
   if (a.phases & STEP_REDUCE) {
     const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
@@ -312,7 +311,7 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
     for (int k = 0; k < 4; ++k) if (tid + 256 * k < NST) d2[tid + 256 * k] = r_st[k];
     if (tid < NCMD) reinterpret_cast<int*>(&s_ex)[tid] = r_cmd;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) if (tid + 256 * k < NHV) hv[tid + 256 * k] = r_hv[k];
+    for (int k = 0; k < 3; ++k) if (tid + 256 * k < NHV) hv[tid + 256 * k] = r_hv[k];
   }
   __syncthreads();
   const bool have_parts = s_st.sc.phase != PH_START;
@@ -365,7 +364,7 @@ __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
   if (nc.type != CMD_DONE) {
     const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
     double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
-    for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, nc, v, i, draws, &T0);
+    for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, nc, v, i, draws, &T0, a.logtab);
   }
   // kinetic energy of freshly drawn momenta: only commands that draw momenta leave something (the step kernel's reduce
   // phase reads the slab for exactly those commands)
@@ -427,7 +426,10 @@ __global__ __launch_bounds__(256) void ppcx_advi_kernel(AdviArgs a) {
     for (int c = 0; c < a.n_slots; ++c) {
       const double z = mu + sd * advi_eta(rid, a.draw_base + c, a.k0);
       if (a.out_draws) a.out_draws[(long)(a.out_row0 + c) * d.D + i] = z;
-      else a.vecs[((long)c * V_COUNT + V_Q1) * a.Dpad + i] = z;
+      else {
+        a.vecs[((long)c * V_COUNT + V_Q1) * a.Dpad + i] = z;
+        coord_consts(d, VecRef{a.vecs + (long)c * V_COUNT * a.Dpad, a.Dpad}, i, z, a.logtab);
+      }
     }
   }
   if (blockIdx.x == 0 && tid < 6) {            // the six hyper-parameters (slot 0 of the hyper vectors)

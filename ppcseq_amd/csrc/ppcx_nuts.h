@@ -34,6 +34,7 @@ enum Vec : int {
   V_Q0 = 0, V_P0, V_G0,          // backward end of the trajectory: position, momentum, grad log p
   V_Q1, V_P1, V_G1,              // forward end
   V_RHO, V_PNEAR, V_MINV, V_WM, V_WM2, V_SQ, V_SG,
+  V_C0, V_C1, V_C2, V_C3,        // constants derived from the position being evaluated (ppcx_gene.h coord_consts)
   V_LRHO,                        // slots 0..kLev-1
   V_LPBEG = V_LRHO + kLev,
   V_LPEND = V_LPBEG + kLev,

@@ -53,8 +53,7 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
   for (int g = 0; g < d.G; ++g) {
     // log-likelihood kernel (one lane per gene here)
     GeneCtx<CM> x;
-    gene_load<CM>(d, c, v, g, x);
-    gene_consts<CM>(x, log_table());
+    gene_load<CM, true>(d, c, v, g, x);
     CellAcc<CM> acc; acc.zero();
     gene_cells<CM>(d, x, m.counts.data() + (size_t)g * d.S, m.low.data() + m.low_start[g], m.low_start[g + 1] - m.low_start[g],
                    m.E.data(), m.expo.data(), m.X.data(), log_table(), 0, 1, acc);
@@ -62,7 +61,7 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
     cell_acc_close<CM>(x.gp, acc, log_table(), (double)m.nhi[g], &o);
     // close kernel
     GeneCtx<CM> x2;
-    gene_load<CM>(d, c, v, g, x2);
+    gene_load<CM, false>(d, c, v, g, x2);
     double pn[NCM], minv[NCM], part[10];
     gene_finish<CM>(d, c, v, x2, o, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.SX.data(), m.ncell.data(), m.Lg1.data(), part, pn, minv);
     for (int k = 0; k < 10; ++k) red[k] += part[k];
@@ -90,7 +89,7 @@ static double update_pass(const EmulModel& m, ChainState& st, const Cmd& ex, con
   chain_step(SerialLanes{}, m.d, st.sc, st.ta, ex, r2.data(), have_parts, h, io, rd, nc);
   double T0 = 0.0;
   if (nc.type != CMD_DONE)
-    for (int i = 3; i < m.d.off_tail; ++i) coord_update(m.d, nc, v, i, io.draws, &T0);
+    for (int i = 3; i < m.d.off_tail; ++i) coord_update(m.d, nc, v, i, io.draws, &T0, log_table());
   return T0;
 }
 
