@@ -105,12 +105,21 @@ PPCX_API int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double p_
                  unsigned long long seed, int n_gen, int resample, double* ci, int32_t* counts_rng);
 PPCX_API void ppcx_fit_free(ppcx_fit* f);
 
-/* R .C() convention (all pointers, void): one do_inference() pass end to end.
- * dims = {device, G, S, C, K, n_excl, chains, iter, warmup, n_gen, resample}; reals = {lambda_mu_mu,
- * truncation_compensation, p_lo, p_hi, seed}. Outputs: ci [K*S*4], slope [K] (posterior mean of
- * alpha_sub_1), status[1].                                                                          */
+/* R .C() convention (all pointers, void return; character vectors arrive as char**): one do_inference() pass end to end --
+ * what R/utilities.R:1482-1531 obtains from vb_iterative()/sampling(), summary(fit, "counts_rng"), extract() and
+ * summary(fit, "alpha_sub_1").
+ *   dims[15] = {device, G, S, C, K, n_excl, chains, iter, warmup, n_gen, resample,
+ *               approximate_posterior_inference (0 = NUTS, R/utilities.R:1497-1512; 1 = ADVI through the bounded
+ *               vb_iterative retry, :1487-1494), save_generated_quantities (counts_rng is filled, :796),
+ *               vb_output_samples, vb_iter (0 = 50000)}
+ *   reals[6] = {lambda_mu_mu, truncation_compensation, p_lo, p_hi, seed, vb_tol_rel_obj (0 = 0.005, the value the
+ *               reference hard-codes at :1492)}
+ *   outputs  : ci [K*S*4] (mean, sd, .lower, .upper per checked cell), slope [K] (posterior mean of alpha_sub_1),
+ *              counts_rng [n_draws*K*S] or NULL, status[1] (0 or a PPCX_ERR_* class), errbuf[0] (message, at most
+ *              errlen[0] bytes including the terminator; may be NULL). No exception and no R condition crosses the ABI.   */
 PPCX_API void ppcx_do_inference_C(const int* dims, const int* counts, const double* X, const double* exposure_rate,
-                         const int* excl, const double* reals, double* ci, double* slope, int* status);
+                         const int* excl, const double* reals, double* ci, double* slope, int* counts_rng,
+                         int* status, char** errbuf, const int* errlen);
 
 /* --- ADVI = rstan::vb(model, output_samples, iter = 50000, tol_rel_obj = 0.005) through vb_iterative
  * (R/utilities.R:246-278, :1487-1494): mean-field Gaussian on the unconstrained scale, Stan defaults
@@ -122,6 +131,8 @@ typedef struct {
 } ppcx_advi_config;
 PPCX_API void ppcx_advi_config_default(ppcx_advi_config* cfg);
 PPCX_API int ppcx_fit_advi(ppcx_model* m, const ppcx_advi_config* cfg, ppcx_fit** out);
+/* vb_iterative (R/utilities.R:246-278): retried with seed + attempt while ADVI fails to initialise or to find a step size */
+PPCX_API int ppcx_fit_advi_iterative(ppcx_model* m, const ppcx_advi_config* cfg, int max_attempts, ppcx_fit** out);
 PPCX_API int ppcx_fit_advi_info(const ppcx_fit* f, int* iterations, int* converged, double* elbo, double* eta);
 
 /* --- gene shards = the reference's map_rect over gene shards (inst/stan/negBinomial_MPI.stan:226-240;

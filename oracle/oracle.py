@@ -161,6 +161,15 @@ class Oracle:
                                            C.c_double(truncation_compensation), C.c_uint64(seed), _p(out, C.c_int32))
         return out
 
+    def generated_quantities_approx(self, m, draws, n_gen, truncation_compensation=1.0, seed=1):
+        """Approximated analysis (R/utilities.R:733-784): n_gen predictive draws per checked cell from the resampled posterior."""
+        draws = np.ascontiguousarray(draws, np.float64).reshape(-1, self.dim(m.G, m.C, m.K))
+        out = np.zeros((int(n_gen), m.K, m.S), np.int32)
+        self.lib.ppco_generated_quantities_approx.restype = None
+        self.lib.ppco_generated_quantities_approx(C.byref(m), _p(draws, C.c_double), C.c_int(draws.shape[0]), C.c_int(int(n_gen)),
+                                                  C.c_double(truncation_compensation), C.c_uint64(seed), _p(out, C.c_int32))
+        return out
+
     def summarise(self, x, p_lo, p_hi):
         x = np.ascontiguousarray(x, np.int32)
         nd = x.shape[0]

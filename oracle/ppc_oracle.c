@@ -693,6 +693,33 @@ PPCO_EXPORT void ppco_generated_quantities(const ppco_model* m, const double* dr
   }
 }
 
+/* approximated analysis (fit_to_counts_rng_approximated, R/utilities.R:733-784): per checked cell (s, g <= K) resample the
+ * posterior with replacement -- i_supersampled = sample(seq_len(n_draws), n_gen, replace = TRUE) (:760) -- and draw
+ * rnbinom(mu = exp(lambda_log_param[i, s, g] + exposure_rate[s]), size = exp(-sigma_raw[i, g]) * truncation_compensation)
+ * (:762-766). R's global RNG is replaced by the project's Philox specification: the index of predictive draw j of cell
+ * c = g*S + s is floor(u * n_draws) with u the first uniform of block (j, c, 5, 0) under key (seed32, 'PPC1'); the
+ * count is neg_binomial_2_log_rng on stream (c, j) as in the full analysis. out: [n_gen][K][S]. */
+PPCO_EXPORT void ppco_generated_quantities_approx(const ppco_model* m, const double* draws, int n_draws, int n_gen,
+                                                  double truncation_compensation, uint64_t seed, int32_t* out) {
+  const int G = m->G, S = m->S, C = m->C, K = m->K; const ppco_off o = offsets(G, C, K);
+  const uint32_t k0 = seed32(seed);
+#pragma omp parallel for schedule(static) num_threads(m->n_threads > 0 ? m->n_threads : 1)
+  for (int j = 0; j < n_gen; ++j) {
+    for (int g = 0; g < K; ++g) for (int s = 0; s < S; ++s) {
+      const uint32_t cell = (uint32_t)(g * S + s);
+      const ppco_u4 r = ppco_philox4x32_10((uint32_t)j, cell, 5u, 0u, k0, 0x50504331u);
+      long src = (long)(ppco_u01(r.v[0], r.v[1]) * (double)n_draws);
+      if (src >= n_draws) src = n_draws - 1;
+      const double* u = draws + (size_t)src * o.D;
+      double eta = m->exposure[s] + m->X[s] * u[o.intercept + g];
+      if (C >= 2) eta += m->X[(size_t)S + s] * u[o.alpha1 + g];
+      for (int c = 2; c < C; ++c) eta += m->X[(size_t)c * S + s] * u[o.alpha2 + (c - 2) + (C - 2) * g];
+      const double phi = exp(-u[o.sigma_raw + g]) * truncation_compensation;
+      out[((size_t)j * K + g) * S + s] = ppco_nb2_log_rng(eta, phi, seed, cell, (uint32_t)j);
+    }
+  }
+}
+
 /* ----------------------------------------------------------------------------------- */
 /* credible-interval summary (R/utilities.R:685-703): mean, sd, type-7 quantiles         */
 /* x: [n_draws][n_cells] int32; out: [n_cells][4] = mean, sd, lower, upper               */

@@ -20,7 +20,7 @@ EXPORTS = [
     "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
     "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_bench_gene_kernel",
     "ppcx_model_create_shard", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
-    "ppcx_fit_nuts_comm", "ppcx_advi_config_default", "ppcx_fit_advi", "ppcx_fit_advi_info",
+    "ppcx_fit_nuts_comm", "ppcx_advi_config_default", "ppcx_fit_advi", "ppcx_fit_advi_info", "ppcx_fit_advi_iterative",
 ]
 
 
@@ -79,6 +79,7 @@ def load() -> C.CDLL:
     lib.ppcx_advi_config_default.argtypes = [C.POINTER(AdviConfig)]
     lib.ppcx_advi_config_default.restype = None
     lib.ppcx_fit_advi.argtypes = [C.c_void_p, C.POINTER(AdviConfig), C.POINTER(C.c_void_p)]
+    lib.ppcx_fit_advi_iterative.argtypes = [C.c_void_p, C.POINTER(AdviConfig), C.c_int, C.POINTER(C.c_void_p)]
     lib.ppcx_fit_advi_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ppcx_model_create_shard.argtypes = [C.c_int] * 7 + [ip, dp, dp, C.c_double, C.c_int, ip, C.POINTER(C.c_void_p)]
     lib.ppcx_fit_nuts_shards.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(NutsConfig), C.POINTER(C.c_void_p)]
@@ -170,11 +171,15 @@ class Model:
         return Fit(self, h)
 
     def fit_advi(self, output_samples=1000, iter=50000, tol_rel_obj=0.005, elbo_samples=100, eval_elbo=100, adapt_iter=50,
-                 seed=1, init_radius=2.0) -> "Fit":
-        """Mean-field ADVI (rstan::vb); returns a one-chain Fit holding output_samples draws of the approximation."""
+                 seed=1, init_radius=2.0, max_attempts=1) -> "Fit":
+        """Mean-field ADVI (rstan::vb); returns a one-chain Fit holding output_samples draws of the approximation.
+        max_attempts > 1: the bounded vb_iterative retry (R/utilities.R:246-278), attempt k with seed + k."""
         cfg = AdviConfig(output_samples, iter, tol_rel_obj, 1, elbo_samples, eval_elbo, adapt_iter, seed, init_radius)
         h = C.c_void_p()
-        _check(load().ppcx_fit_advi(self._h, C.byref(cfg), C.byref(h)))
+        if max_attempts > 1:
+            _check(load().ppcx_fit_advi_iterative(self._h, C.byref(cfg), int(max_attempts), C.byref(h)))
+        else:
+            _check(load().ppcx_fit_advi(self._h, C.byref(cfg), C.byref(h)))
         return Fit(self, h)
 
     def fit_nuts_comm(self, comm: "Comm", **kw) -> "Fit":

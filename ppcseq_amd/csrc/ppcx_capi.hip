@@ -1105,43 +1105,85 @@ extern "C" int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double 
   if (m->d.K < 1) return PPCX_OK;
   if (n_gen <= 0) n_gen = (int)n_draws;
   if (!resample && n_gen > n_draws) return fail(PPCX_ERR_ARG, "n_gen exceeds the kept draws (use resample)");
-  // a cell's draws live in LDS (160 KB per CU; 4 KB of it is the kernel's static scratch)
-  if (n_gen > 39680) return fail(PPCX_ERR_LIMIT, "more than 39680 predictive draws per cell: use the approximated analysis with fewer draws");
   if (!(p_lo >= 0.0 && p_hi <= 1.0 && p_lo <= p_hi)) return fail(PPCX_ERR_ARG, "need 0 <= p_lo <= p_hi <= 1");
   HIPCHK(hipSetDevice(m->device));
   const int n_cells = m->d.K * m->d.S;
-  double* d_ci = nullptr; int* d_rng = nullptr;
+  double* d_ci = nullptr; int* d_rng = nullptr; int* d_scratch = nullptr;
   HIPCHK(hipMalloc(&d_ci, sizeof(double) * (size_t)n_cells * 4));
+  // a cell's draws live in LDS (160 KB per CU; 4 KB of it is the kernel's static scratch) when they fit; beyond that
+  // 1024 workgroups share the cells and keep the current cell's draws in their slice of a global scratch buffer
+  const int kLdsDraws = 39680;
+  int nblocks = n_cells;
+  if (n_gen > kLdsDraws) {
+    nblocks = n_cells < 1024 ? n_cells : 1024;
+    hipError_t e = hipMalloc(&d_scratch, sizeof(int) * (size_t)nblocks * n_gen);
+    if (e != hipSuccess) { (void)hipFree(d_ci); return fail(PPCX_ERR_HIP, hipGetErrorString(e)); }
+  }
   if (counts_rng) {
     hipError_t e = hipMalloc(&d_rng, sizeof(int) * (size_t)n_gen * n_cells);
-    if (e != hipSuccess) { (void)hipFree(d_ci); return fail(PPCX_ERR_HIP, hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(d_ci); (void)hipFree(d_scratch); return fail(PPCX_ERR_HIP, hipGetErrorString(e)); }
   }
   PpcArgs pa;
   pa.d = m->d; pa.draws = f->d_draws; pa.n_draws = n_draws; pa.exposure = m->d_expo; pa.X = m->d_X;
   pa.truncation_compensation = truncation_compensation; pa.p_lo = p_lo; pa.p_hi = p_hi; pa.k0 = seed32(seed);
-  pa.n_gen = n_gen; pa.resample = resample ? 1 : 0; pa.n_cells = n_cells; pa.ci = d_ci; pa.counts_rng = d_rng;
-  hipError_t e = launch_ppc_kernel(pa, m->stream);
+  pa.n_gen = n_gen; pa.resample = resample ? 1 : 0; pa.n_cells = n_cells; pa.ci = d_ci; pa.counts_rng = d_rng; pa.scratch = d_scratch;
+  hipError_t e = launch_ppc_kernel(pa, nblocks, m->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
   if (e == hipSuccess) e = hipMemcpy(ci, d_ci, sizeof(double) * (size_t)n_cells * 4, hipMemcpyDeviceToHost);
   if (e == hipSuccess && counts_rng) e = hipMemcpy(counts_rng, d_rng, sizeof(int) * (size_t)n_gen * n_cells, hipMemcpyDeviceToHost);
-  (void)hipFree(d_ci); (void)hipFree(d_rng);
+  (void)hipFree(d_ci); (void)hipFree(d_rng); (void)hipFree(d_scratch);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, hipGetErrorString(e));
   return PPCX_OK;
 }
 
+// vb_iterative (R/utilities.R:246-278): rstan::vb is retried until it returns; the reference passes no seed, so every
+// attempt is a fresh random start. Here attempt k runs with seed + k and the retries are bounded.
+static int fit_advi_iterative(ppcx_model* m, ppcx_advi_config cfg, int max_attempts, ppcx_fit** out) {
+  int rc = PPCX_ERR_ARG;
+  for (int k = 0; k < max_attempts; ++k) {
+    rc = ppcx_fit_advi(m, &cfg, out);
+    if (rc == PPCX_OK || (rc != PPCX_ERR_INIT && rc != PPCX_ERR_STEPSIZE)) return rc;
+    cfg.seed += 1;
+  }
+  return rc;
+}
+extern "C" int ppcx_fit_advi_iterative(ppcx_model* m, const ppcx_advi_config* cfg, int max_attempts, ppcx_fit** out) {
+  if (!m || !cfg || !out || max_attempts < 1) return fail(PPCX_ERR_ARG, "NULL argument");
+  return fit_advi_iterative(m, *cfg, max_attempts, out);
+}
+
 extern "C" void ppcx_do_inference_C(const int* dims, const int* counts, const double* X, const double* exposure,
-                                    const int* excl, const double* reals, double* ci, double* slope, int* status) {
+                                    const int* excl, const double* reals, double* ci, double* slope, int* counts_rng,
+                                    int* status, char** errbuf, const int* errlen) {
   if (!status) return;
-  if (!dims || !reals) { *status = PPCX_ERR_ARG; return; }
+  auto finish = [&](int rc) {
+    *status = rc;
+    if (errbuf && errbuf[0] && errlen && errlen[0] > 0) {
+      const char* msg = rc == PPCX_OK ? "" : g_err.c_str();
+      strncpy(errbuf[0], msg, (size_t)errlen[0] - 1);
+      errbuf[0][errlen[0] - 1] = 0;
+    }
+  };
+  if (!dims || !reals || !ci) { finish(fail(PPCX_ERR_ARG, "dims, reals and ci must not be NULL")); return; }
   const int device = dims[0], G = dims[1], S = dims[2], C = dims[3], K = dims[4], n_excl = dims[5];
+  const int vb = dims[11], save_rng = dims[12];
+  if (save_rng && !counts_rng) { finish(fail(PPCX_ERR_ARG, "save_generated_quantities without a counts_rng buffer")); return; }
   ppcx_model* m = nullptr; ppcx_fit* f = nullptr;
   int rc = ppcx_model_create(device, G, S, C, K, counts, X, exposure, reals[0], n_excl, excl, &m);
   if (rc == PPCX_OK) {
-    ppcx_nuts_config cfg; ppcx_nuts_config_default(&cfg);
-    cfg.chains = dims[6]; cfg.iter = dims[7]; cfg.warmup = dims[8]; cfg.seed = (unsigned long long)reals[4];
-    rc = ppcx_fit_nuts(m, &cfg, &f);
+    if (vb) {
+      ppcx_advi_config ac; ppcx_advi_config_default(&ac);
+      ac.output_samples = dims[13]; ac.iter = dims[14] > 0 ? dims[14] : 50000; ac.seed = (unsigned long long)reals[4];
+      if (reals[5] > 0) ac.tol_rel_obj = reals[5];
+      rc = fit_advi_iterative(m, ac, 5, &f);
+    } else {
+      ppcx_nuts_config cfg; ppcx_nuts_config_default(&cfg);
+      cfg.chains = dims[6]; cfg.iter = dims[7]; cfg.warmup = dims[8]; cfg.seed = (unsigned long long)reals[4];
+      rc = ppcx_fit_nuts(m, &cfg, &f);
+    }
   }
-  if (rc == PPCX_OK) rc = ppcx_fit_ppc(f, reals[1], reals[2], reals[3], (unsigned long long)reals[4], dims[9], dims[10], ci, nullptr);
+  if (rc == PPCX_OK) rc = ppcx_fit_ppc(f, reals[1], reals[2], reals[3], (unsigned long long)reals[4], dims[9], dims[10], ci,
+                                       save_rng ? counts_rng : nullptr);
   if (rc == PPCX_OK && slope && K > 0) {
     std::vector<int32_t> cols(K);
     for (int k = 0; k < K; ++k) cols[k] = m->d.off_alpha1 + k;
@@ -1154,5 +1196,5 @@ extern "C" void ppcx_do_inference_C(const int* dims, const int* counts, const do
     }
   }
   ppcx_fit_free(f); ppcx_model_destroy(m);
-  *status = rc;
+  finish(rc);
 }

@@ -93,6 +93,7 @@ struct PpcArgs {
   int n_gen, resample, n_cells;
   double* ci;                   // [K*S][4] mean, sd, lower, upper
   int* counts_rng;              // [n_gen][K*S] or null
+  int* scratch;                 // null: a cell's draws in LDS (grid = n_cells); else [grid][n_gen] global scratch, cells in turn
 };
 
 hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st);
@@ -102,7 +103,7 @@ hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st);
 hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_advi_kernel(const AdviArgs& a, int nblocks, hipStream_t st);
 hipError_t launch_advi_elbo_kernel(const AdviElboArgs& a, hipStream_t st);
-hipError_t launch_ppc_kernel(const PpcArgs& a, hipStream_t st);
+hipError_t launch_ppc_kernel(const PpcArgs& a, int nblocks, hipStream_t st);
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st);
 hipError_t launch_fill_kernel(double* p, long n, double val, hipStream_t st);
 

@@ -527,67 +527,72 @@ __global__ __launch_bounds__(kPpcThreads) void ppcx_ppc_kernel(PpcArgs a) {
   __shared__ double sred[kPpcThreads];
   __shared__ int s_cnt[kPpcWaves];
   const Dims& d = a.d;
-  const int cell = blockIdx.x;                 // g * S + s
-  const int g = cell / d.S, s = cell % d.S;
   const int tid = threadIdx.x;
-  int* vals = ldsi;
+  // a cell's draws live in LDS when they fit (one workgroup per cell), otherwise in this workgroup's slice of a global
+  // scratch buffer, and the workgroup takes cells in turn (how_many_posterior_draws = draws_after_tail / threshold
+  // reaches 100 000 at the reference's defaults with 200 samples, R/methods.R:166-167)
+  int* vals = a.scratch ? a.scratch + (long)blockIdx.x * a.n_gen : ldsi;
   const int n = a.n_gen;
-  double sum = 0.0;
-  int vmax = 0;
-  for (int j = tid; j < n; j += kPpcThreads) {
-    long src = j;
-    if (a.resample) {                          // R/utilities.R:760: sample(draws, n, replace = TRUE)
-      const double u = coord_uniform((uint32_t)j, (uint32_t)cell, 5u, 0u, a.k0, 0x50504331u);
-      src = (long)(u * (double)a.n_draws); if (src >= a.n_draws) src = a.n_draws - 1;
+  for (int cell = blockIdx.x; cell < a.n_cells; cell += gridDim.x) {   // g * S + s
+    const int g = cell / d.S, s = cell % d.S;
+    double sum = 0.0;
+    int vmax = 0;
+    for (int j = tid; j < n; j += kPpcThreads) {
+      long src = j;
+      if (a.resample) {                          // R/utilities.R:760: sample(draws, n, replace = TRUE)
+        const double u = coord_uniform((uint32_t)j, (uint32_t)cell, 5u, 0u, a.k0, 0x50504331u);
+        src = (long)(u * (double)a.n_draws); if (src >= a.n_draws) src = a.n_draws - 1;
+      }
+      const double* u_ = a.draws + src * (long)d.D;
+      double eta = a.exposure[s] + a.X[s] * u_[d.off_intercept + g];
+      if (d.C >= 2) eta += a.X[(long)d.S + s] * u_[d.off_alpha1 + g];
+      for (int cc = 2; cc < d.C; ++cc) eta += a.X[(long)cc * d.S + s] * u_[coef_index(d, cc, g)];
+      const double phi = exp(-u_[d.off_sigma_raw + g]) * a.truncation_compensation;
+      const int val = nb2_log_rng(eta, phi, a.k0, (uint32_t)cell, (uint32_t)j);
+      sum += (double)val;
+      vmax = val > vmax ? val : vmax;
+      if (a.counts_rng) a.counts_rng[(long)j * a.n_cells + cell] = val;
+      vals[j] = val;
     }
-    const double* u_ = a.draws + src * (long)d.D;
-    double eta = a.exposure[s] + a.X[s] * u_[d.off_intercept + g];
-    if (d.C >= 2) eta += a.X[(long)d.S + s] * u_[d.off_alpha1 + g];
-    for (int cc = 2; cc < d.C; ++cc) eta += a.X[(long)cc * d.S + s] * u_[coef_index(d, cc, g)];
-    const double phi = exp(-u_[d.off_sigma_raw + g]) * a.truncation_compensation;
-    const int val = nb2_log_rng(eta, phi, a.k0, (uint32_t)cell, (uint32_t)j);
-    sum += (double)val;
-    vmax = val > vmax ? val : vmax;
-    if (a.counts_rng) a.counts_rng[(long)j * a.n_cells + cell] = val;
-    vals[j] = val;
-  }
-  // mean (fixed-order block reduction)
-  sred[tid] = sum;
-  __syncthreads();
-  for (int st = kPpcThreads / 2; st > 0; st >>= 1) { if (tid < st) sred[tid] += sred[tid + st]; __syncthreads(); }
-  const double mean = sred[0] / (double)n;
-  __syncthreads();
-  double ss = 0.0;
-  for (int j = tid; j < n; j += kPpcThreads) { const double t = (double)vals[j] - mean; ss += t * t; }
-  sred[tid] = ss;
-  __syncthreads();
-  for (int st = kPpcThreads / 2; st > 0; st >>= 1) { if (tid < st) sred[tid] += sred[tid + st]; __syncthreads(); }
-  const double sd = n > 1 ? sqrt(sred[0] / (double)(n - 1)) : NAN;
-  __syncthreads();
-  // largest draw of the workgroup (upper end of the bisections)
+    // mean (fixed-order block reduction)
+    sred[tid] = sum;
+    __syncthreads();
+    for (int st = kPpcThreads / 2; st > 0; st >>= 1) { if (tid < st) sred[tid] += sred[tid + st]; __syncthreads(); }
+    const double mean = sred[0] / (double)n;
+    __syncthreads();
+    double ss = 0.0;
+    for (int j = tid; j < n; j += kPpcThreads) { const double t = (double)vals[j] - mean; ss += t * t; }
+    sred[tid] = ss;
+    __syncthreads();
+    for (int st = kPpcThreads / 2; st > 0; st >>= 1) { if (tid < st) sred[tid] += sred[tid + st]; __syncthreads(); }
+    const double sd = n > 1 ? sqrt(sred[0] / (double)(n - 1)) : NAN;
+    __syncthreads();
+    // largest draw of the workgroup (upper end of the bisections)
 #pragma unroll
-  for (int msk = 1; msk < 64; msk <<= 1) { const int o = __shfl_xor(vmax, msk, 64); vmax = o > vmax ? o : vmax; }
-  if ((tid & 63) == 0) s_cnt[tid >> 6] = vmax;
-  __syncthreads();
-  vmax = s_cnt[0];
+    for (int msk = 1; msk < 64; msk <<= 1) { const int o = __shfl_xor(vmax, msk, 64); vmax = o > vmax ? o : vmax; }
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = vmax;
+    __syncthreads();
+    vmax = s_cnt[0];
 #pragma unroll
-  for (int w = 1; w < kPpcWaves; ++w) vmax = max(vmax, s_cnt[w]);
-  __syncthreads();
-  // type-7 quantiles (R quantile default; rstan::summary) from the two order statistics around (n-1) p
-  double q[2];
-  const double pr[2] = {a.p_lo, a.p_hi};
-  for (int k = 0; k < 2; ++k) {
-    const double h = (double)(n - 1) * pr[k];
-    int lo = (int)floor(h);
-    if (lo > n - 1) lo = n - 1;
-    if (lo < 0) lo = 0;
-    int v0, v1;
-    block_select_pair(vals, n, lo, vmax, s_cnt, tid, &v0, &v1);
-    q[k] = lo >= n - 1 ? (double)v0 : (double)v0 + (h - (double)lo) * ((double)v1 - (double)v0);
-  }
-  if (tid == 0) {
-    double* o = a.ci + (long)cell * 4;
-    o[0] = mean; o[1] = sd; o[2] = q[0]; o[3] = q[1];
+    for (int w = 1; w < kPpcWaves; ++w) vmax = max(vmax, s_cnt[w]);
+    __syncthreads();
+    // type-7 quantiles (R quantile default; rstan::summary) from the two order statistics around (n-1) p
+    double q[2];
+    const double pr[2] = {a.p_lo, a.p_hi};
+    for (int k = 0; k < 2; ++k) {
+      const double h = (double)(n - 1) * pr[k];
+      int lo = (int)floor(h);
+      if (lo > n - 1) lo = n - 1;
+      if (lo < 0) lo = 0;
+      int v0, v1;
+      block_select_pair(vals, n, lo, vmax, s_cnt, tid, &v0, &v1);
+      q[k] = lo >= n - 1 ? (double)v0 : (double)v0 + (h - (double)lo) * ((double)v1 - (double)v0);
+    }
+    if (tid == 0) {
+      double* o = a.ci + (long)cell * 4;
+      o[0] = mean; o[1] = sd; o[2] = q[0]; o[3] = q[1];
+    }
+    __syncthreads();                             // the next cell reuses vals
   }
 }
 
@@ -641,8 +646,8 @@ hipError_t launch_advi_elbo_kernel(const AdviElboArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(ppcx_advi_elbo_kernel, dim3(1), dim3(64), 0, st, a);
   return hipGetLastError();
 }
-hipError_t launch_ppc_kernel(const PpcArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(ppcx_ppc_kernel, dim3(a.n_cells), dim3(kPpcThreads), sizeof(int) * (size_t)a.n_gen, st, a);
+hipError_t launch_ppc_kernel(const PpcArgs& a, int nblocks, hipStream_t st) {
+  hipLaunchKernelGGL(ppcx_ppc_kernel, dim3(nblocks), dim3(kPpcThreads), a.scratch ? 0 : sizeof(int) * (size_t)a.n_gen, st, a);
   return hipGetLastError();
 }
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st) {

@@ -127,7 +127,8 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *,
     if approximate_posterior_inference:
         # vb_iterative(model, output_samples = draws_practical, iter = 50000, tol_rel_obj = 0.005)
         # (R/utilities.R:1487-1494; the reference passes no seed to vb -- here the run is seeded and reproducible)
-        fit = model.fit_advi(output_samples=int(draws_practical), iter=50000, tol_rel_obj=0.005, seed=seed)
+        # vb_iterative retries a failed vb() call (R/utilities.R:246-278): here bounded, attempt k with seed + k
+        fit = model.fit_advi(output_samples=int(draws_practical), iter=50000, tol_rel_obj=0.005, seed=seed, max_attempts=5)
     else:
         fit = model.fit_nuts(chains=chains, iter=n_iter, warmup=warmup, seed=seed)
     try:

@@ -141,3 +141,41 @@ def test_nb_rng_spec_identical(oracle, emul):
         eta, phi = rng.uniform(-3, 12), np.exp(rng.uniform(-4, 6))
         cell, draw, seed = int(rng.integers(1 << 20)), int(rng.integers(1 << 16)), int(rng.integers(1 << 40))
         assert emul.emul_nb2_log_rng(eta, phi, seed, cell, draw) == oracle.nb2_log_rng(eta, phi, seed, cell, draw)
+
+
+def test_golden_vectors(oracle, emul):
+    """Committed golden vectors (tests/golden/lpgrad_small.npz: mpmath at 60 digits, cross-checked with the oracle, scipy
+    and torch autograd by make_lpgrad_fixture.py): the oracle agrees to its own fp64 rounding (it cancels y - (y + phi)
+    mu / (mu + phi) at the 200 000 count) and the product's arithmetic (CPU emulation) to the parity tolerances."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lpgrad_small.npz"))
+    for n in range(int(z["n_cases"])):
+        g = {k: z[f"c{n}_{k}"] for k in ("counts", "X", "exposure", "K", "excl", "u", "lp", "grad")}
+        K = int(g["K"])
+        m = oracle.model(g["counts"], g["X"], g["exposure"], K, excl=g["excl"])
+        for i in range(g["u"].shape[0]):
+            lp, gr = oracle.log_prob_grad(m, g["u"][i])
+            assert abs(lp - g["lp"][i]) <= 1e-11 * abs(g["lp"][i]) and np.max(np.abs(gr - g["grad"][i]) / (1 + np.abs(gr))) < 1e-9
+            lp2, g2 = emul_lp(emul, g["counts"], g["X"], g["exposure"], K, g["u"][i], g["excl"] if g["excl"].size else None)
+            assert abs(lp2 - g["lp"][i]) <= 1e-11 * max(1.0, abs(g["lp"][i]))
+            assert np.max(np.abs(g2 - g["grad"][i]) / (1 + np.abs(g["grad"][i]))) < 1e-10
+
+
+def test_approximated_analysis_oracle_properties(oracle):
+    """The oracle's restatement of fit_to_counts_rng_approximated (R/utilities.R:733-784): resampling indices are uniform
+    over the posterior draws, a draw equals neg_binomial_2_log_rng on the resampled parameters, and with one posterior
+    draw the approximated and the full analysis see the same parameters."""
+    d = ind.synth(10, 6, K=3, seed=4)
+    m = oracle.model(d["counts"], d["X"], d["exposure"], 3)
+    D = oracle.dim(10, 2, 3)
+    rng = np.random.default_rng(0)
+    dr = rng.normal(0, 0.2, (50, D)); dr[:, 3:13] += 5
+    a = oracle.generated_quantities_approx(m, dr, 4000, 0.7352941, seed=9)
+    assert a.shape == (4000, 3, 6) and a.min() >= 0
+    full = oracle.generated_quantities(m, dr, 0.7352941, seed=9)
+    # same predictive distribution: means of the two estimates agree within Monte-Carlo error of the heavy-tailed draws
+    assert np.all(np.abs(a.mean(0) / full.mean(0) - 1) < 0.5)
+    one = oracle.generated_quantities_approx(m, dr[:1], 7, 1.0, seed=3)
+    ref = np.stack([[[oracle.nb2_log_rng(d["exposure"][s] + dr[0, 3 + g] + d["X"][s, 1] * dr[0, 13 + g], np.exp(-dr[0, 16 + g]), 3, g * 6 + s, j)
+                      for s in range(6)] for g in range(3)] for j in range(7)])
+    assert np.array_equal(one, ref)

@@ -497,10 +497,24 @@ def test_outlier_call_concordance_with_cpu_path():
     assert c["max_upper_ci_diff_in_mc_standard_errors"] < 5.0       # interval ends in units of their MC error
 
 
+def _dot_C(lib, dims, counts, X, expo, excl, reals, ci, slope, rng, status, errlen=256):
+    """Call ppcx_do_inference_C the way R's .C() does: every argument a pointer, character vectors as char**."""
+    import ctypes as C
+    buf = C.create_string_buffer(errlen)
+    errbuf = (C.c_char_p * 1)(C.cast(buf, C.c_char_p))
+    elen = np.array([errlen], np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None   # noqa: E731
+    lib.ppcx_do_inference_C.restype = None
+    lib.ppcx_do_inference_C.argtypes = [C.c_void_p] * 10 + [C.POINTER(C.c_char_p), C.c_void_p]
+    lib.ppcx_do_inference_C(vp(dims), vp(counts), vp(X), vp(expo), vp(excl), vp(reals), vp(ci), vp(slope), vp(rng), vp(status),
+                            errbuf, vp(elen))
+    return buf.value.decode()
+
+
 def test_dot_C_entry_point_matches_handle_api(L):
     """`ppcx_do_inference_C` is the all-pointer / void entry point an R `.C()` call binds: it must give
-    what the handle-level sequence model_create -> fit_nuts -> fit_ppc -> columns gives."""
-    import ctypes as C
+    what the handle-level sequence model_create -> fit_nuts / fit_advi -> fit_ppc -> columns gives, hand back the generated
+    quantities when asked, and report errors as a status plus a message."""
     d = ind.synth(30, 8, K=4, seed=3)
     G, S, Cc, K = 30, 8, 2, 4
     counts = np.ascontiguousarray(d["counts"], np.int32)
@@ -508,30 +522,77 @@ def test_dot_C_entry_point_matches_handle_api(L):
     expo = np.ascontiguousarray(d["exposure"])
     excl = np.array([5, 17], np.int32)
     chains, iter_, warmup, seed = 3, 120, 80, 13
-    dims = np.array([0, G, S, Cc, K, excl.size, chains, iter_, warmup, 0, 0], np.int32)
-    reals = np.array([5.612671, 0.7352941, 0.01, 0.99, float(seed)])
+    n_draws = chains * (iter_ - warmup)
+    dims = np.array([0, G, S, Cc, K, excl.size, chains, iter_, warmup, 0, 0, 0, 1, 0, 0], np.int32)
+    reals = np.array([5.612671, 0.7352941, 0.01, 0.99, float(seed), 0.0])
     ci = np.zeros((K, S, 4)); slope = np.zeros(K); status = np.array([99], np.int32)
+    rng = np.zeros((n_draws, K, S), np.int32)
     lib = L.load()
-    lib.ppcx_do_inference_C.restype = None
-    lib.ppcx_do_inference_C(dims.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), X.ctypes.data_as(C.c_void_p),
-                            expo.ctypes.data_as(C.c_void_p), excl.ctypes.data_as(C.c_void_p), reals.ctypes.data_as(C.c_void_p),
-                            ci.ctypes.data_as(C.c_void_p), slope.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p))
-    assert status[0] == 0
+    msg = _dot_C(lib, dims, counts, X, expo, excl, reals, ci, slope, rng, status)
+    assert status[0] == 0 and msg == ""
     m = L.Model(counts, X, expo, K, excl=excl)
     try:
         f = m.fit_nuts(chains=chains, iter=iter_, warmup=warmup, seed=seed)
-        ci2 = f.ppc(0.7352941, 0.01, 0.99, seed=seed)
+        ci2, rng2 = f.ppc(0.7352941, 0.01, 0.99, seed=seed, return_counts_rng=True)
         slope2 = f.columns(np.arange(3 + G, 3 + G + K)).reshape(-1, K).mean(0)
         f.close()
+        assert np.array_equal(ci, ci2) and np.allclose(slope, slope2, rtol=0, atol=1e-14) and np.array_equal(rng, rng2)
+        # the reference's default mode: ADVI (approximate_posterior_inference = TRUE), approximated analysis
+        dims_vb = dims.copy(); dims_vb[9:15] = [700, 1, 1, 0, 400, 0]
+        msg = _dot_C(lib, dims_vb, counts, X, expo, excl, reals, ci, slope, None, status)
+        assert status[0] == 0 and msg == ""
+        fv = m.fit_advi(output_samples=400, seed=seed)
+        ci3 = fv.ppc(0.7352941, 0.01, 0.99, seed=seed, n_gen=700, resample=True)
+        slope3 = fv.columns(np.arange(3 + G, 3 + G + K)).reshape(-1, K).mean(0)
+        fv.close()
+        assert np.array_equal(ci, ci3) and np.allclose(slope, slope3, rtol=0, atol=1e-14)
     finally:
         m.close()
-    assert np.array_equal(ci, ci2) and np.allclose(slope, slope2, rtol=0, atol=1e-14)
-    # bad arguments come back as a status, never as an exception across the boundary
-    dims[1] = 0
-    lib.ppcx_do_inference_C(dims.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), X.ctypes.data_as(C.c_void_p),
-                            expo.ctypes.data_as(C.c_void_p), excl.ctypes.data_as(C.c_void_p), reals.ctypes.data_as(C.c_void_p),
-                            ci.ctypes.data_as(C.c_void_p), slope.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p))
-    assert status[0] == -1
+    # bad arguments come back as a status and a message, never as an exception across the boundary
+    dims_bad = dims.copy(); dims_bad[1] = 0
+    msg = _dot_C(lib, dims_bad, counts, X, expo, excl, reals, ci, slope, rng, status)
+    assert status[0] == -1 and "G>=1" in msg
+    msg = _dot_C(lib, dims, counts, X, expo, excl, reals, ci, slope, None, status)       # save_generated_quantities without a buffer
+    assert status[0] == -1 and "counts_rng" in msg
+    msg = _dot_C(lib, dims_bad, counts, X, expo, excl, reals, ci, slope, rng, status, errlen=8)   # a short buffer is not overrun
+    assert status[0] == -1 and len(msg) <= 7
+
+
+def test_reference_testthat_cases_through_the_dot_C_entry(L, bundled):
+    """The reference's two testthat cases (tests/testthat/test-ppcSeq.R:7-57: VB inference, approximated and full
+    analysis, 3 checked genes + 50 controls, pfp = 1) with BOTH passes going through the `.C`-style entry the R shim
+    binds (INTEGRATION.md): tot_deleterious_outliers = c(0, 1, 0)."""
+    from tests.conftest import bundled_test_config
+    from ppcseq_amd.inference import _post_process
+    from ppcseq_amd.methods import get_scaled_counts_bulk
+    counts, X, names, K = bundled_test_config(bundled)
+    G, S = counts.shape
+    counts = np.ascontiguousarray(counts, np.int32); Xf = np.asfortranarray(X)
+    mult, _ = get_scaled_counts_bulk(counts, list(range(S)))
+    expo = np.ascontiguousarray(-np.log(np.array([mult[s] for s in range(S)])))
+    thr2 = 1 / 100 / S * 2
+    thr1 = max(0.05, 2 * thr2)
+    lib = L.load()
+    for approx in (True, False):
+        status = np.array([99], np.int32); ci = np.zeros((K, S, 4)); slope = np.zeros(K)
+        # pass 1 (discovery): always the full analysis (R/methods.R:273); draws_1 = max(1000, 10 / thr1) = 1000
+        dims = np.array([0, G, S, 2, K, 0, 0, 0, 0, 0, 0, 1, 0, 1000, 0], np.int32)
+        reals = np.array([5.612671, 1.0, thr1, 1 - thr1, 321.0, 0.0])
+        assert _dot_C(lib, dims, counts, Xf, expo, None, reals, ci, slope, None, status) == "" and status[0] == 0
+        r1 = _post_process(counts[:K], ci.copy(), slope.copy(), X)
+        excl = np.flatnonzero(r1.deleterious_outliers.ravel()).astype(np.int32)
+        # pass 2 (test): exclusions, truncation compensation, draws_2 = 10 / thr2 = 10 500
+        draws2 = int(max(1000, 10 / thr2))
+        if approx:
+            dims2 = np.array([0, G, S, 2, K, excl.size, 0, 0, 0, draws2, 1, 1, 0, 1000, 0], np.int32)
+        else:
+            dims2 = np.array([0, G, S, 2, K, excl.size, 0, 0, 0, 0, 0, 1, 0, draws2, 0], np.int32)
+        reals2 = np.array([5.612671, 0.7352941, thr2, 1 - thr2, 321.0, 0.0])
+        assert _dot_C(lib, dims2, counts, Xf, expo, excl if excl.size else None, reals2, ci, slope, None, status) == ""
+        assert status[0] == 0
+        r2 = _post_process(counts[:K], ci, slope, X)
+        assert names[:3] == ["SLC16A12", "CYP1A1", "ART3"]
+        assert r2.deleterious_outliers.sum(1).tolist() == [0, 1, 0], approx
 
 
 def test_degenerate_shapes(L, oracle):
