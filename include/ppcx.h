@@ -80,6 +80,10 @@ PPCX_API void ppcx_nuts_config_default(ppcx_nuts_config* cfg);
 
 PPCX_API int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fit** out);
 PPCX_API int ppcx_fit_info(const ppcx_fit* f, int* chains, int* n_keep, int* D, int* iter);
+/* a fit holding draws produced elsewhere, [chains][n_keep][D] unconstrained (the host layer gathers the chains of other
+ * ranks): ppcx_fit_ppc / ppcx_fit_get_columns then see the pooled posterior, as rstan::summary does over merged chains
+ * (R/utilities.R:685-703, :1500-1501)                                                                                    */
+PPCX_API int ppcx_fit_from_draws(ppcx_model* m, int chains, int n_keep, const double* draws, ppcx_fit** out);
 /* kept draws, unconstrained, [chains][n_keep][D] */
 PPCX_API int ppcx_fit_get_draws(ppcx_fit* f, double* out);
 /* selected columns of the kept draws, [chains*n_keep][n_cols] */

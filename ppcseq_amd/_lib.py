@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("PPCX_LIB", os.path.join(_HERE, "libppcx.so"))   # PPC
 EXPORTS = [
     "ppcx_version", "ppcx_device_count", "ppcx_last_error", "ppcx_model_create", "ppcx_model_set_exclusions",
     "ppcx_model_set_launch", "ppcx_model_get_launch", "ppcx_model_dim", "ppcx_model_destroy", "ppcx_log_prob_grad",
-    "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
+    "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_from_draws", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
     "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_bench_gene_kernel",
     "ppcx_model_create_shard", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
     "ppcx_fit_nuts_comm", "ppcx_advi_config_default", "ppcx_fit_advi", "ppcx_fit_advi_info", "ppcx_fit_advi_iterative",
@@ -67,6 +67,7 @@ def load() -> C.CDLL:
     lib.ppcx_nuts_config_default.restype = None
     lib.ppcx_fit_nuts.argtypes = [C.c_void_p, C.POINTER(NutsConfig), C.POINTER(C.c_void_p)]
     lib.ppcx_fit_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+    lib.ppcx_fit_from_draws.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.POINTER(C.c_void_p)]
     lib.ppcx_fit_get_draws.argtypes = [C.c_void_p, dp]
     lib.ppcx_fit_get_columns.argtypes = [C.c_void_p, C.c_int, ip, dp]
     lib.ppcx_fit_get_diagnostics.argtypes = [C.c_void_p, dp, dp, ip, ip, ip, dp]
@@ -180,6 +181,15 @@ class Model:
             _check(load().ppcx_fit_advi_iterative(self._h, C.byref(cfg), int(max_attempts), C.byref(h)))
         else:
             _check(load().ppcx_fit_advi(self._h, C.byref(cfg), C.byref(h)))
+        return Fit(self, h)
+
+    def fit_from_draws(self, draws) -> "Fit":
+        """A Fit over draws produced elsewhere ([chains, n_keep, D], unconstrained): pooled chains of other ranks."""
+        draws = np.ascontiguousarray(draws, dtype=np.float64)
+        if draws.ndim != 3 or draws.shape[2] != self.D:
+            raise ValueError("draws must be [chains, n_keep, D]")
+        h = C.c_void_p()
+        _check(load().ppcx_fit_from_draws(self._h, draws.shape[0], draws.shape[1], _p(draws, C.c_double), C.byref(h)))
         return Fit(self, h)
 
     def fit_nuts_comm(self, comm: "Comm", **kw) -> "Fit":

@@ -424,7 +424,24 @@ static int rccl_load() {
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) return fail(PPCX_ERR_HIP, "librccl.so lacks the expected symbols");
   return PPCX_OK;
 }
-struct ppcx_comm { ncclComm_t comm = nullptr; int nranks = 1, rank = 0, device = 0; };
+struct ppcx_comm { ncclComm_t comm = nullptr; int nranks = 1, rank = 0, device = 0; double* d_guard = nullptr; double* h_guard = nullptr; };
+// Every rank of a gene-sharded run replicates the chains' state machines and must issue the same launches. At every
+// poll the ranks compare (rounds issued, chains done, local error) with ONE max-reduction of [x, -x] pairs: if the
+// counts differ anywhere, or any rank failed, every rank leaves the pump with the same status instead of waiting for
+// a collective its peers will never issue.
+static int comm_guard(ppcx_comm* c, hipStream_t st, long long pairs, int n_done, int local_rc, int* all_rc) {
+  double v[5] = {(double)pairs, -(double)pairs, (double)n_done, -(double)n_done, local_rc != PPCX_OK ? (double)(-local_rc) : 0.0};
+  HIPCHK(hipMemcpyAsync(c->d_guard, v, sizeof v, hipMemcpyHostToDevice, st));
+  const int e = g_rccl.AllReduce(c->d_guard, c->d_guard, 5, /*ncclDouble*/ 8, /*ncclMax*/ 2, c->comm, st);
+  if (e != 0) return fail(PPCX_ERR_HIP, std::string("ncclAllReduce (guard): ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"));
+  HIPCHK(hipMemcpyAsync(c->h_guard, c->d_guard, sizeof v, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const double* g = c->h_guard;
+  *all_rc = PPCX_OK;
+  if (g[4] != 0.0) *all_rc = local_rc != PPCX_OK ? local_rc : fail(-(int)g[4], "another rank of the gene-sharded run reported an error");
+  else if (g[0] != -g[1] || g[2] != -g[3]) *all_rc = fail(PPCX_ERR_STALL, "the ranks of the gene-sharded run disagree on the rounds issued or the chains finished");
+  return PPCX_OK;
+}
 
 // One shard of a run: its model (all genes, or a contiguous gene range) and its device scratch.
 struct Shard { ppcx_model* m; Work* w; RunIO io; };
@@ -437,9 +454,15 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
   const int ns = (int)sh.size();
   hipStream_t st = sh[0].w->stream;
   int rc = PPCX_OK;
+  // Several ranks (one gene shard per process): a rank that fails must not leave its peers waiting in a collective. It
+  // stops launching kernels but keeps issuing the per-round all-reduces until the next poll, where comm_guard lets every
+  // rank see the failure (or a disagreement on the rounds issued) and leave together.
+  const bool guarded = comm && comm->comm && comm->nranks > 1;
+  int local_rc = PPCX_OK;
+#define PUMP_TRY(expr) do { if (local_rc == PPCX_OK) { const int r_ = (expr); if (r_ != PPCX_OK) { if (!guarded) return r_; local_rc = r_; } } } while (0)
   for (int k = 0; k < ns; ++k) {                                   // PH_START: first command, then its coordinate work
-    if ((rc = launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_REDUCE | STEP_ADVANCE)) != PPCX_OK) return rc;
-    if ((rc = launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;
+    PUMP_TRY(launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_REDUCE | STEP_ADVANCE));
+    PUMP_TRY(launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io));
   }
   const int batch = 32, sample_every = 16;
   struct Events {                // destroyed on every exit path
@@ -453,15 +476,15 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
   while (true) {
     bool sampled = false;
     for (int i = 0; i < batch; ++i, ++pairs) {
-      const bool smp = time_kernels && !sampled && (pairs / batch) % sample_every == 0 && i == batch / 2;
+      const bool smp = time_kernels && !sampled && (pairs / batch) % sample_every == 0 && i == batch / 2 && local_rc == PPCX_OK;
       if (smp) HIPCHK(hipEventRecord(ev0, st));
-      for (int k = 0; k < ns; ++k) if ((rc = launch_loglik(sh[k].m, *sh[k].w, nchains)) != PPCX_OK) return rc;
+      for (int k = 0; k < ns; ++k) PUMP_TRY(launch_loglik(sh[k].m, *sh[k].w, nchains));
       if (smp) { HIPCHK(hipEventRecord(ev1, st)); sampled = true; }
       const bool exchange = ns > 1 || (comm && comm->comm);
       for (int k = 0; k < ns; ++k) {
-        if ((rc = launch_close(sh[k].m, *sh[k].w, nchains)) != PPCX_OK) return rc;
+        PUMP_TRY(launch_close(sh[k].m, *sh[k].w, nchains));
         if (smp && k == ns - 1) HIPCHK(hipEventRecord(ev2, st));
-        if ((rc = launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, exchange ? STEP_REDUCE : (STEP_REDUCE | STEP_ADVANCE))) != PPCX_OK) return rc;
+        PUMP_TRY(launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, exchange ? STEP_REDUCE : (STEP_REDUCE | STEP_ADVANCE)));
       }
       if (ns > 1) {
         ShardSumArgs sa; sa.n_shards = ns; sa.n = nchains * PT_COUNT;
@@ -469,34 +492,43 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
         hipError_t e = launch_sum_shards_kernel(sa, st);
         if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("shard sum kernel: ") + hipGetErrorString(e));
       }
-      if (comm && comm->nranks >= 1 && comm->comm) {
+      if (comm && comm->nranks >= 1 && comm->comm) {                 // issued by every rank every round, failed or not
         const int e = g_rccl.AllReduce(w0.red, w0.red, (size_t)nchains * PT_COUNT, /*ncclDouble*/ 8, /*ncclSum*/ 0, comm->comm, st);
         if (e != 0) return fail(PPCX_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"));
       }
       for (int k = 0; k < ns; ++k) {
-        if (exchange && (rc = launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_ADVANCE)) != PPCX_OK) return rc;
-        if ((rc = launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io)) != PPCX_OK) return rc;
+        if (exchange) PUMP_TRY(launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_ADVANCE));
+        PUMP_TRY(launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io));
       }
       if (smp) HIPCHK(hipEventRecord(ev3, st));
     }
     HIPCHK(hipMemcpyAsync(w0.done_host, w0.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (sampled && n_done == 0) {               // only launches in which every chain was still active
+    if (sampled && n_done == 0 && local_rc == PPCX_OK) {   // only launches in which every chain was still active
       float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
       stats->kA_ms_sum += ms; stats->kA_samples++; stats->chain_launches += nchains;
       HIPCHK(hipEventElapsedTime(&ms, ev1, ev2)); stats->kC_ms_sum += ms;
       HIPCHK(hipEventElapsedTime(&ms, ev2, ev3)); stats->kU_ms_sum += ms;
     }
     n_done = 0;
+    rc = local_rc;
     for (int c = 0; c < nchains; ++c) {
       if (w0.done_host[c]) ++n_done;
       if (w0.done_host[c] == 2) rc = fail(PPCX_ERR_INIT, "no finite initial point after 100 attempts");
       if (w0.done_host[c] == 3) rc = fail(PPCX_ERR_STEPSIZE, "step-size heuristic diverged");
     }
+    if (pairs > max_pairs && n_done < nchains) rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished");
+    if (guarded) {
+      int all_rc = PPCX_OK;
+      const int grc = comm_guard(comm, st, pairs, n_done, rc, &all_rc);
+      if (grc != PPCX_OK) return grc;
+      if (all_rc != PPCX_OK) { rc = all_rc; break; }
+    } else if (local_rc != PPCX_OK) break;
     if (n_done == nchains) break;
-    if (ns == 1 && w0.retune_launch) set_groups_per_wave(sh[0].m, nchains - n_done);   // fewer chains in the launch: fewer rounds
-    if (pairs > max_pairs) { rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished"); break; }
+    if (rc == PPCX_ERR_STALL) break;
+    if (ns == 1 && w0.retune_launch && !guarded) set_groups_per_wave(sh[0].m, nchains - n_done);   // fewer chains in the launch: fewer rounds
   }
+#undef PUMP_TRY
   stats->pairs = pairs;
   return rc;
 }
@@ -1014,17 +1046,38 @@ extern "C" int ppcx_comm_create(int device, int nranks, int rank, const char* id
   c->nranks = nranks; c->rank = rank; c->device = device;
   const int e = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
   if (e != 0) { delete c; return fail(PPCX_ERR_HIP, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error")); }
+  if (hipMalloc(&c->d_guard, sizeof(double) * 8) != hipSuccess || hipHostMalloc(&c->h_guard, sizeof(double) * 8) != hipSuccess) {
+    ppcx_comm_destroy(c); return fail(PPCX_ERR_HIP, "allocating the communicator's guard buffers failed");
+  }
   *out = c;
   return PPCX_OK;
 }
 extern "C" void ppcx_comm_destroy(ppcx_comm* c) {
   if (!c) return;
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  (void)hipFree(c->d_guard); if (c->h_guard) (void)hipHostFree(c->h_guard);
   delete c;
 }
 extern "C" int ppcx_fit_nuts_comm(ppcx_model* shard, const ppcx_nuts_config* cfg, ppcx_comm* comm, ppcx_fit** out) {
   if (!comm) return fail(PPCX_ERR_ARG, "communicator is NULL");
   return fit_sharded(&shard, 1, cfg, comm, out);
+}
+
+// A fit that holds draws produced elsewhere (other ranks' chains gathered by the host layer): ppcx_fit_ppc and
+// ppcx_fit_get_columns then work on the pooled posterior, as rstan::summary does over merged chains (R/utilities.R:685-703).
+extern "C" int ppcx_fit_from_draws(ppcx_model* m, int chains, int n_keep, const double* draws, ppcx_fit** out) {
+  if (!m || !draws || !out || chains < 1 || n_keep < 1) return fail(PPCX_ERR_ARG, "bad arguments");
+  *out = nullptr;
+  HIPCHK(hipSetDevice(m->device));
+  ppcx_fit* f = new ppcx_fit();
+  fit_attach(f, m); f->chains = chains; f->n_keep = n_keep; f->iter = n_keep;
+  memset(&f->cfg, 0, sizeof f->cfg);
+  const size_t n = (size_t)chains * n_keep * m->d.D;
+  hipError_t e = hipMalloc(&f->d_draws, sizeof(double) * n);
+  if (e == hipSuccess) e = hipMemcpy(f->d_draws, draws, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { ppcx_fit_free(f); return fail(PPCX_ERR_HIP, hipGetErrorString(e)); }
+  *out = f;
+  return PPCX_OK;
 }
 
 extern "C" int ppcx_fit_info(const ppcx_fit* f, int* chains, int* n_keep, int* D, int* iter) {
@@ -1068,8 +1121,8 @@ extern "C" int ppcx_fit_get_diagnostics(ppcx_fit* f, double* lp, double* stepsiz
   if (!f) return fail(PPCX_ERR_ARG, "fit is NULL");
   HIPCHK(hipSetDevice(f->m->device));
   const size_t ni = (size_t)f->chains * f->iter, nk = (size_t)f->chains * f->n_keep;
-  if (lp && nk) HIPCHK(hipMemcpy(lp, f->d_lp, sizeof(double) * nk, hipMemcpyDeviceToHost));
-  if (stepsize) HIPCHK(hipMemcpy(stepsize, f->d_stepsize, sizeof(double) * ni, hipMemcpyDeviceToHost));
+  if (lp && nk && f->d_lp) HIPCHK(hipMemcpy(lp, f->d_lp, sizeof(double) * nk, hipMemcpyDeviceToHost));
+  if (stepsize && f->d_stepsize) HIPCHK(hipMemcpy(stepsize, f->d_stepsize, sizeof(double) * ni, hipMemcpyDeviceToHost));
   if (treedepth && f->d_treedepth) HIPCHK(hipMemcpy(treedepth, f->d_treedepth, sizeof(int) * ni, hipMemcpyDeviceToHost));
   if (n_leapfrog && f->d_nleap) HIPCHK(hipMemcpy(n_leapfrog, f->d_nleap, sizeof(int) * ni, hipMemcpyDeviceToHost));
   if (divergent && f->d_div) HIPCHK(hipMemcpy(divergent, f->d_div, sizeof(int) * ni, hipMemcpyDeviceToHost));

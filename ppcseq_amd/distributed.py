@@ -3,8 +3,9 @@
 Mirrors the reference's chain parallelism (`chains=`/`cores=` of rstan::sampling, R/utilities.R:1500-1501,
 which forks one R worker per chain): chains are independent units, so there is NO per-leapfrog
 collective. torch.distributed (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in CPU tests)
-is used for plumbing only: rank 0 broadcasts the model inputs, and the kept hyper-parameter draws /
-diagnostics are all-gathered for the pooled summaries.
+is used for plumbing only: rank 0 broadcasts the model inputs, and the kept draws of the checked genes /
+diagnostics are all-gathered for the pooled summaries (`do_inference`: credible intervals and flags from the merged
+chains of all ranks, as rstan::summary gives them, R/utilities.R:685-703).
 """
 from __future__ import annotations
 
@@ -65,3 +66,58 @@ def max_over_ranks(value: float, device="cpu") -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def do_inference(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_device="cpu", chains=None, cores=None,
+                 approximate_posterior_analysis=False, lambda_mu_mu=5.612671, adj_prob_theshold=0.05,
+                 how_many_posterior_draws=1000, to_exclude=None, truncation_compensation=1.0, seed=1, launch=None):
+    """One inference pass of ppcseq (ppcseq_amd.inference.do_inference) with the chains partitioned over the ranks of the
+    initialised torch.distributed job, one process per GPU. Every rank holds the inputs, fits its chains with the global
+    chain ids (the Philox stream of chain c does not depend on the rank that runs it), the draws of the checked genes are
+    all-gathered (a few MB) and rank 0 computes the credible intervals and flags from the POOLED draws; the result is
+    broadcast, so every rank returns the same InferenceResult as one fit of all the chains would give.
+    `launch` = (lanes_per_gene, groups_per_wave) pins the kernel geometry (bit-identical results across rank counts need
+    the same geometry: the automatic choice depends on the chains per launch)."""
+    import math
+    from . import _lib
+    from .inference import _to_cell_ids, checked_columns, find_optimal_number_of_chains, pooled_summary
+    dist = _dist()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    counts = np.asarray(counts)
+    G, S = counts.shape
+    K = int(how_many_to_check)
+    X = np.asarray(X, dtype=np.float64).reshape(S, -1)
+    practical = 1000 if approximate_posterior_analysis else how_many_posterior_draws
+    if chains is None:
+        chains = max(3, min(int(cores) if cores else world, find_optimal_number_of_chains(practical)))
+    n_iter = int(math.ceil(practical / chains)) + 150
+    per = int(math.ceil(chains / world))
+    n_local = max(0, min(per, chains - rank * per))
+    cols = checked_columns(G, X.shape[1], K)
+    n_keep = n_iter - 150
+    local = np.zeros((per, n_keep, cols.size))
+    div_local = np.zeros(1)
+    if n_local > 0:
+        m = _lib.Model(counts, X, exposure_rate, K, lambda_mu_mu=lambda_mu_mu, excl=_to_cell_ids(to_exclude, S), device=device)
+        try:
+            if launch is not None:
+                m.set_launch(*launch)
+            f = m.fit_nuts(chains=n_local, iter=n_iter, warmup=150, seed=seed, chain_id_offset=rank * per)
+            try:
+                local[:n_local] = f.columns(cols)
+                div_local[0] = float(f.diagnostics()["divergent"][:, 150:].sum())
+            finally:
+                f.close()
+        finally:
+            m.close()
+    pooled = all_gather_chains(local, device=coll_device)[:chains]        # ranks past the last chain contributed padding
+    res = [None]
+    if rank == 0:
+        r = pooled_summary(counts, X, exposure_rate, K, pooled, lambda_mu_mu=lambda_mu_mu,
+                           approximate_posterior_analysis=approximate_posterior_analysis, adj_prob_theshold=adj_prob_theshold,
+                           how_many_posterior_draws=how_many_posterior_draws, truncation_compensation=truncation_compensation,
+                           seed=seed, device=device)
+        r.chains, r.iter = chains, n_iter
+        res[0] = r
+    dist.broadcast_object_list(res, src=0)
+    return res[0]

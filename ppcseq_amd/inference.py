@@ -89,7 +89,9 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *,
                  seed=1,
                  device=0,
                  model=None,
-                 chains=None):
+                 chains=None,
+                 devices=None,
+                 launch=None):
     """One inference pass (discovery or test) of ppcseq on the GPU.
 
     counts            G x S integer matrix, genes ordered with the `how_many_to_check` checked genes first
@@ -98,6 +100,12 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *,
     exposure_rate     length S, `-log(multiplier)` (R/methods.R:236)
     to_exclude        iterable of (S, G) 1-based pairs as in the reference's tibble (R/methods.R:292-300),
                       or an int array of 0-based cell ids g*S+s
+    devices           several HIP devices of this process: the chains are split over them (the reference runs its chains in
+                      `cores` worker processes, R/utilities.R:1500-1501) and the credible intervals come from the POOLED
+                      draws, as rstan::summary does over merged chains (:685-703). One process per GPU under
+                      torch.distributed: ppcseq_amd.distributed.do_inference.
+    launch            (lanes_per_gene, groups_per_wave) pins the kernel geometry; by default it follows the number of
+                      chains per launch, and results agree to rounding, not bit for bit, between geometries
     Returns an InferenceResult.
     """
     counts = np.asarray(counts)
@@ -119,11 +127,19 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *,
     warmup = 150                                                    # R/utilities.R:1503
 
     excl = _to_cell_ids(to_exclude, S)
+    if devices is not None and len(devices) > 1 and not approximate_posterior_inference:
+        return _do_inference_devices(counts, X, exposure_rate, K, list(devices), chains, n_iter, warmup, excl,
+                                     lambda_mu_mu, approximate_posterior_analysis, adj_prob_theshold,
+                                     how_many_posterior_draws, truncation_compensation, seed, launch)
+    if devices is not None and len(devices) >= 1 and model is None:
+        device = devices[0]
     own_model = model is None
     if own_model:
         model = _lib.Model(counts, X, exposure_rate, K, lambda_mu_mu=lambda_mu_mu, excl=excl, device=device)
     else:
         model.set_exclusions(excl)
+    if launch is not None:
+        model.set_launch(*launch)
     if approximate_posterior_inference:
         # vb_iterative(model, output_samples = draws_practical, iter = 50000, tol_rel_obj = 0.005)
         # (R/utilities.R:1487-1494; the reference passes no seed to vb -- here the run is seeded and reproducible)
@@ -187,3 +203,88 @@ def _post_process(counts_checked, ci, slope, X):
     return InferenceResult(K=K, S=S, mean=mean, sd=sd, lower=lower, upper=upper, ppc=ppc,
                            is_higher_than_mean=higher, slope=slope, is_group_high=is_group_high,
                            deleterious_outliers=delet, total_draws=0, chains=0, iter=0)
+
+
+def checked_columns(G, C, K):
+    """Columns of the unconstrained vector that belong to the K checked genes and the hyper-parameters, in the order of
+    the unconstrained vector of a model that holds ONLY those K genes (Stan declaration order, .stan:183-197)."""
+    n2 = max(C - 2, 0)
+    off_a1, off_a2 = 3 + G, 3 + G + K
+    off_sr = off_a2 + n2 * K
+    return np.concatenate([np.arange(3), 3 + np.arange(K), off_a1 + np.arange(K), off_a2 + np.arange(n2 * K),
+                           off_sr + np.arange(K), off_sr + G + np.arange(3)]).astype(np.int32)
+
+
+def pooled_summary(counts, X, exposure_rate, K, draws_checked, *, lambda_mu_mu, approximate_posterior_analysis,
+                   adj_prob_theshold, how_many_posterior_draws, truncation_compensation, seed, device=0):
+    """Credible intervals, slopes and flags from the pooled draws of all chains (rstan::summary over merged chains,
+    R/utilities.R:685-703): `draws_checked` is [chains, n_keep, len(checked_columns)] in global chain order. The
+    posterior-predictive kernel runs on a model that holds the K checked genes only -- cell ids g*S+s and draw indices are
+    those of the full model, so the result is what a single fit of all the chains gives, bit for bit."""
+    counts = np.asarray(counts)
+    X = np.asarray(X, dtype=np.float64).reshape(counts.shape[1], -1)
+    small = _lib.Model(counts[:K], X, exposure_rate, K, lambda_mu_mu=lambda_mu_mu, device=device)
+    try:
+        fit = small.fit_from_draws(draws_checked)
+        try:
+            p = float(adj_prob_theshold)
+            if approximate_posterior_analysis:
+                ci = fit.ppc(truncation_compensation, p, 1 - p, seed=seed, n_gen=int(how_many_posterior_draws), resample=True)
+            else:
+                ci = fit.ppc(truncation_compensation, p, 1 - p, seed=seed, n_gen=0, resample=False)
+            slope = fit.columns(np.arange(3 + K, 3 + 2 * K)).reshape(-1, K).mean(axis=0) if K else np.zeros(0)
+        finally:
+            fit.close()
+    finally:
+        small.close()
+    res = _post_process(counts[:K], ci, slope, X)
+    res.total_draws = counts.shape[1] * K * int(how_many_posterior_draws)
+    return res
+
+
+def _do_inference_devices(counts, X, exposure_rate, K, devices, chains, n_iter, warmup, excl, lambda_mu_mu,
+                          approximate_posterior_analysis, adj_prob_theshold, how_many_posterior_draws,
+                          truncation_compensation, seed, launch=None):
+    """Chains split over several devices of this process (one host thread per device; the C ABI allows different handles
+    on different threads), pooled summary on the first device."""
+    import threading
+    G, S = counts.shape
+    nd = min(len(devices), chains)
+    per = int(math.ceil(chains / nd))
+    cols = checked_columns(G, X.shape[1], K)
+    parts, errs = [None] * nd, [None] * nd
+
+    def work(r):
+        n = min(per, chains - r * per)
+        if n <= 0:
+            return
+        try:
+            m = _lib.Model(counts, X, exposure_rate, K, lambda_mu_mu=lambda_mu_mu, excl=excl, device=devices[r])
+            try:
+                if launch is not None:
+                    m.set_launch(*launch)
+                f = m.fit_nuts(chains=n, iter=n_iter, warmup=warmup, seed=seed, chain_id_offset=r * per)
+                try:
+                    parts[r] = f.columns(cols)
+                finally:
+                    f.close()
+            finally:
+                m.close()
+        except Exception as e:          # re-raised on the calling thread
+            errs[r] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nd)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    pooled = np.concatenate([p for p in parts if p is not None], axis=0)
+    res = pooled_summary(counts, X, exposure_rate, K, pooled, lambda_mu_mu=lambda_mu_mu,
+                         approximate_posterior_analysis=approximate_posterior_analysis, adj_prob_theshold=adj_prob_theshold,
+                         how_many_posterior_draws=how_many_posterior_draws, truncation_compensation=truncation_compensation,
+                         seed=seed, device=devices[0])
+    res.chains, res.iter = chains, n_iter
+    return res

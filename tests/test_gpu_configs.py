@@ -42,9 +42,23 @@ def _points(d, G, K, D, seed):
     return u
 
 
-def _assert_lp_grad(lp, g, lpo, go, what):
+def _assert_lp_grad(lp, g, lpo, go, what, noise=None):
+    """noise: the fp64 rounding floor of the ORACLE's gradient per coordinate. It sums y - (y + phi) mu / (mu + phi) cell
+    by cell: terms of the size of the counts that cancel to a gradient near 0 at the posterior mode, i.e. an absolute error
+    of a few eps * sum_s y (1e-9 for a gene with 2e7 reads); the product's phi (sum rho - n) does not cancel (the golden
+    vectors, computed with mpmath, show it closer to the truth than the oracle there)."""
     assert abs(lp - lpo) <= 1e-11 * max(1.0, abs(lpo)), (what, lp, lpo)
-    assert np.max(np.abs(g - go) / (1 + np.abs(go))) <= 1e-10, what
+    tol = 1e-10 * (1 + np.abs(go)) + (0.0 if noise is None else noise)
+    assert np.all(np.abs(g - go) <= tol), (what, float(np.max(np.abs(g - go) / tol)))
+
+
+def _oracle_noise(counts, G, K, D):
+    sy = counts.sum(1).astype(np.float64)
+    n = np.zeros(D)
+    n[3:3 + G] = sy
+    n[3 + G:3 + G + K] = sy[:K]
+    n[D - 3 - G:D - 3] = sy
+    return 4 * np.finfo(np.float64).eps * n
 
 
 def test_golden_vectors(L):
@@ -71,25 +85,26 @@ def test_density_and_gradient_at_baseline_size(L, oracle, name):
     m = L.Model(d["counts"], d["X"], d["exposure"], K)
     try:
         u = _points(d, G, K, m.D, seed)
+        noise = _oracle_noise(d["counts"], G, K, m.D)
         ref = [oracle.log_prob_grad(mo, u[i]) for i in range(2)]
         geometries = [(0, 0)] if name != "cfg3" else [(0, 0), (8, 1), (4, 2), (16, 0)]
         for lanes, gpw in geometries:
             m.set_launch(lanes, gpw)
             lp, g = m.log_prob_grad(u)
             for i in range(2):
-                _assert_lp_grad(lp[i], g[i], ref[i][0], ref[i][1], (name, lanes, gpw, i))
+                _assert_lp_grad(lp[i], g[i], ref[i][0], ref[i][1], (name, lanes, gpw, i), noise)
         if name == "cfg3":                       # the two-segment launch is what 8 chains per launch run with
             m.set_launch(0, 0)
             lp8, g8 = m.log_prob_grad(np.repeat(u[:1], 8, axis=0))
             for i in range(8):
-                _assert_lp_grad(lp8[i], g8[i], ref[0][0], ref[0][1], (name, "8 points", i))
+                _assert_lp_grad(lp8[i], g8[i], ref[0][0], ref[0][1], (name, "8 points", i), noise)
         # excluded cells (pass 2 of identify_outliers) at full size
         excl = np.array([7, S + 3, (G // 2) * S + S - 1, G * S - 1], np.int32)
         m.set_exclusions(excl)
         lpx, gx = m.log_prob_grad(u[0])
         mox = oracle.model(d["counts"], d["X"], d["exposure"], K, excl=excl, n_threads=min(16, os.cpu_count() or 1))
         lpo, go = oracle.log_prob_grad(mox, u[0])
-        _assert_lp_grad(lpx, gx, lpo, go, (name, "exclusions"))
+        _assert_lp_grad(lpx, gx, lpo, go, (name, "exclusions"), noise)
     finally:
         m.close()
 
