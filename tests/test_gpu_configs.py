@@ -111,15 +111,15 @@ def test_density_and_gradient_at_baseline_size(L, oracle, name):
 
 def test_cfg2_nuts_decisions_follow_oracle(L, oracle):
     """cfg2 (5 000 x 50, 4 chains): same Philox streams, same algorithm => identical tree sizes, depths and divergences
-    for the first iterations of warm-up (tree depth capped at 6 to bound the oracle's time; the caps bind: depth 6 occurs)."""
+    for the first iterations of warm-up (before floating-point chaos separates any two implementations)."""
     G, S, seed = CONFIGS["cfg2"]
     d = ind.synth(G, S, seed=seed)
     K = d["K"]
     mo = oracle.model(d["counts"], d["X"], d["exposure"], K, n_threads=min(16, os.cpu_count() or 1))
-    r = oracle.nuts_model(mo, oracle.cfg(chains=4, iter=10, warmup=10, seed=20252, max_treedepth=6))
+    r = oracle.nuts_model(mo, oracle.cfg(chains=4, iter=12, warmup=12, seed=20252))
     m = L.Model(d["counts"], d["X"], d["exposure"], K)
     try:
-        f = m.fit_nuts(chains=4, iter=10, warmup=10, seed=20252, max_treedepth=6)
+        f = m.fit_nuts(chains=4, iter=12, warmup=12, seed=20252)
         dg = f.diagnostics()
         f.close()
     finally:
@@ -129,7 +129,7 @@ def test_cfg2_nuts_decisions_follow_oracle(L, oracle):
     assert np.array_equal(dg["divergent"], r.divergent)
     assert np.max(np.abs(dg["stepsize"] - r.stepsize) / r.stepsize) < 1e-8
     assert np.max(np.abs(dg["accept"] - r.accept)) < 1e-6
-    assert r.treedepth.max() == 6
+    assert r.treedepth.max() >= 4 and r.n_leapfrog.sum() > 300
 
 
 def test_cfg4_gene_shards_and_ppc_kernel(L, oracle):
