@@ -7,20 +7,18 @@
 // (multinomial NUTS with the generalised U-turn criterion and its two cross-subtree checks, diagonal
 // Euclidean metric, dual-averaging step size, windowed variance adaptation).
 //
-// MI355X-first structure (DESIGN.md "NUTS on the device"):
-//   * kernel A (`ppcx_gene_kernel`)  : one launch = the gradient evaluation of one leapfrog for every chain.
-//     Each gene's coordinates (intercept, sigma_raw, slopes) live with the lanes that stream that gene's
-//     counts, so the likelihood+prior gradient, the second half kick and the tree bookkeeping of those
-//     coordinates (U-turn dot products, subtree slots) are fused into the one pass over the count matrix.
-//   * kernel B (`ppcx_update_kernel`): every workgroup reduces the per-block partial sums of A in the same
-//     fixed order and runs the scalar NUTS / adaptation state machine (`chain_step`) redundantly -- no
-//     grid barrier, no extra launch -- then applies the per-coordinate operations the new command asks for
-//     (proposal / sample copies, draw storage, Welford / metric updates, momentum refresh) and the first
-//     half kick + drift of the next leapfrog to its slice of the coordinates. State and commands are
-//     double-buffered between launches so that no workgroup can read what another has already advanced.
-//   The host only pumps (A,B) launch pairs and polls a done flag: no per-leapfrog host round trip.
-//   Stan's recursive build_tree is evaluated iteratively: a completed left subtree of level d parks
-//   its (rho, p_begin, p_end, proposal, log weight) in slot d until its right sibling completes.
+// MI355X-first structure: one leapfrog round = four launches on one stream.
+//   * log-likelihood kernel : the gradient evaluation of one leapfrog for every chain -- the count matrix streamed once,
+//     a handful of sums per gene (ppcx_gene.h gene_cells);
+//   * close kernel          : per gene: priors, gradient, second half kick, tree bookkeeping of the gene's coordinates
+//     (U-turn dot products, subtree slots), per-workgroup partial sums into a slab;
+//   * step kernel           : one workgroup per chain reduces the slab in a fixed order and runs the scalar NUTS /
+//     adaptation state machine (`chain_step` / `chain_advance`), emitting the next command;
+//   * update kernel         : applies the command to every gene-owned coordinate (proposal / sample copies, draw
+//     storage, Welford / metric updates, momentum refresh, first half kick + drift, the constants of the new position).
+//   State and commands are double-buffered between rounds. The host only pumps the launches and polls a done flag: no
+//   per-leapfrog host round trip. Stan's recursive build_tree is evaluated iteratively: a completed left subtree of
+//   level d parks its (rho, p_begin, p_end, proposal, log weight) in slot d until its right sibling completes.
 #pragma once
 #include "ppcx_model.h"
 
