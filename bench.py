@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--draws-per-chain", type=int, default=250)
     ap.add_argument("--nuts-warmup", type=int, default=150)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per gene override (0 = automatic)")
-    ap.add_argument("--groups-per-wave", type=int, default=0)
+    ap.add_argument("--workgroups", type=int, default=0, help="persistent workgroups of the log-likelihood launch (0 = automatic)")
     ap.add_argument("--mode", choices=["chains", "shards"], default="chains",
                     help="chains: BASELINE cfg3, chains partitioned over GPUs (default, weak scaling); shards: BASELINE cfg4 style, "
                          "genes partitioned over GPUs with an RCCL all-reduce of the partial sums every leapfrog (strong scaling)")
@@ -92,8 +92,8 @@ def main():
                            shard=(G, K, g0, g1))
     else:
         model = _lib.Model(arrays["counts"], arrays["X"], arrays["exposure"], K, device=dev_index)
-    if args.lanes or args.groups_per_wave:
-        model.set_launch(args.lanes, args.groups_per_wave)
+    if args.lanes or args.workgroups:
+        model.set_launch(args.lanes, args.workgroups)
     Dm = model.D
     model_G = (g1 - g0) if args.mode == "shards" else G
     hyper_cols = [0, 1, 2, Dm - 3, Dm - 2, Dm - 1]
@@ -212,7 +212,7 @@ def main():
                                    (f"BASELINE cfg4 style: synthetic {G} genes x {S} samples (seed {seed_data}), C=2, K={K}, genes "
                                     f"sharded over {world} GPU(s) with an RCCL all-reduce of the partial sums per leapfrog; NUTS "
                                     f"(Stan defaults) warm-up {args.nuts_warmup} + {args.draws_per_chain} kept draws/chain, {nch} chains"),
-                       "mode": args.mode, "chains_total": nch * world if args.mode == "chains" else nch, "lanes_per_gene": model.get_launch()[0], "blocks_per_chain": model.get_launch()[1],
+                       "mode": args.mode, "chains_total": nch * world if args.mode == "chains" else nch, "lanes_per_gene": model.get_launch()[0], "loglik_workgroups": model.get_launch()[1],
                        "ess_estimator": "rank-normalised split-chain bulk-ESS, min over 6 hyper-parameters and lp__",
                        "ess_last_step": [round(float(x), 1) for x in ess_detail],
                        "ess_median_intercept_sigma_raw_rank0_chains": round(ess_gene_median, 1),

@@ -55,7 +55,7 @@ PPCX_API int ppcx_model_create(int device, int G, int S, int C, int K, const int
                       const double* exposure_rate, double lambda_mu_mu, int n_excl, const int32_t* excl,
                       ppcx_model** out);
 PPCX_API int ppcx_model_set_exclusions(ppcx_model* m, int n_excl, const int32_t* excl);   /* pass 2 of R/methods.R:320-342 */
-PPCX_API int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int groups_per_wave); /* 0 = automatic */
+PPCX_API int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int workgroups); /* 0 = automatic; lanes: power of two <= 64 */
 PPCX_API int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int* nblocks);
 PPCX_API int ppcx_model_dim(const ppcx_model* m);          /* D = 2G + K*max(C-1,1) + 6 */
 PPCX_API void ppcx_model_destroy(ppcx_model* m);

@@ -727,7 +727,7 @@ PPCO_EXPORT void ppco_generated_quantities_approx(const ppco_model* m, const dou
 static int cmp_i32(const void* a, const void* b) { int32_t x = *(const int32_t*)a, y = *(const int32_t*)b; return (x > y) - (x < y); }
 static double quantile7(const int32_t* sorted, int n, double p) {
   double h = (n - 1) * p; int lo = (int)floor(h); if (lo >= n - 1) return sorted[n - 1];
-  return sorted[lo] + (h - lo) * ((double)sorted[lo + 1] - (double)sorted[lo]);
+  return fma(h - lo, (double)sorted[lo + 1] - (double)sorted[lo], (double)sorted[lo]);   /* one rounding, whatever the compiler contracts */
 }
 PPCO_EXPORT void ppco_summarise(const int32_t* x, int n_draws, int n_cells, double p_lo, double p_hi, double* out) {
 #pragma omp parallel

@@ -146,8 +146,10 @@ class Model:
         excl = np.ascontiguousarray(excl if excl is not None else np.zeros(0), dtype=np.int32)
         _check(load().ppcx_model_set_exclusions(self._h, int(excl.size), _p(excl, C.c_int32)))
 
-    def set_launch(self, lanes_per_gene=0, groups_per_wave=0):
-        _check(load().ppcx_model_set_launch(self._h, int(lanes_per_gene), int(groups_per_wave)))
+    def set_launch(self, lanes_per_gene=0, workgroups=0):
+        """Pin the log-likelihood kernel's lanes per gene (a power of two <= 64) and/or its number of persistent
+        workgroups; 0 = automatic. Results depend on lanes_per_gene only (summation order inside a gene)."""
+        _check(load().ppcx_model_set_launch(self._h, int(lanes_per_gene), int(workgroups)))
 
     def get_launch(self):
         a, b = C.c_int(), C.c_int()

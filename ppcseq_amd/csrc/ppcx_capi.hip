@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <chrono>
 #include <dlfcn.h>
+#include <map>
+#include <mutex>
 #include <stdlib.h>
 #include <string>
 #include <thread>
@@ -29,16 +31,23 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct ppcx_model {
   int device;
   Dims d;
-  int CM, L, groups_per_wave, nblocks, nb0, nb1, G0;
-  int nblocks_chosen = 0;        // workgroups per chain chosen for the full chain count (what ppcx_model_get_launch reports)
-  int split_override = -1;       // 0: never split a launch into two segments (development aid, PPCX_SPLIT)
-  int L_override, gpw_override;
+  int CM, L = 64;
+  int L_override = 0, wgs_override = 0;        // ppcx_model_set_launch
+  int n_cu = 256, wgs_per_cu = 4;              // resident workgroups of the log-likelihood kernel = n_cu * wgs_per_cu
+  int nblocks_chosen = 0;                      // workgroups of the last planned launch (what ppcx_model_get_launch reports)
+  // gene order of the log-likelihood launch (upload_counts): per position, the length of the gene's low-count list
+  // and whether it has slopes -- what a pass of a wavefront costs (plan_launch)
+  std::vector<int> pos_low; std::vector<char> pos_slope;
+  struct Plan { int nbpc = 0; int* d_bounds = nullptr; };
+  std::map<std::pair<int, int>, Plan> plans;   // (chains in the launch, resident workgroups it may use) -> ranges
+  std::mutex plan_mutex;
   std::vector<int32_t> counts_host;            // original counts (exclusions are re-applied on a copy)
   std::vector<double> X_host, expo_host;
   int* d_counts = nullptr;
   double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_SX = nullptr, *d_ncell = nullptr, *d_Lg1 = nullptr;
   unsigned* d_low = nullptr; size_t low_cap = 0;   // low-count cell list (ppcx_gene.h gene_cells) and its capacity
   int *d_low_start = nullptr, *d_nhi = nullptr;
+  unsigned short* d_low_m = nullptr;           // [G][8] entry k < 7: number of list cells with count > k
   double* d_logtab = nullptr;
   int* d_order = nullptr;        // gene_order: position in the log-likelihood kernel's launch -> gene
   hipStream_t stream = nullptr;
@@ -63,73 +72,95 @@ extern "C" int ppcx_version(void) { return 100; }
 extern "C" int ppcx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" const char* ppcx_last_error(void) { return g_err.c_str(); }
 
-// choose lanes-per-gene L and workgroups per chain: minimise (duration of one wavefront) x (rounds of resident
-// wavefronts the launch needs). A wavefront executes ~400 instructions of per-gene overhead plus, per cell of a lane,
-// ~80 and ~2 more per doubling of the genes that share the wavefront (they must agree on the lgamma regime) -- the
-// measured instruction counts of the kernel (SQ_INSTS_VALU vs S, profiles/). 1024 SIMDs x 4 resident wavefronts make a
-// round; a launch that does not fill one takes a wavefront's duration whatever L is, and because workgroups leave and
-// enter one by one a partly filled last round costs about half of what strict rounds would.
-// A launch may have two segments: whole rounds with L lanes per gene, and the remaining genes with 2L lanes per gene
-// -- twice as many wavefronts of half the duration -- so that the last, partial round is a short one.
-// groups per wavefront for `nactive` chains in the launch (L and the segments stay as chosen, so every gene keeps its
-// summation order and the results do not change): with four or more rounds of resident wavefronts (two or more in the
-// whole-round segment of a split launch) every wavefront takes two groups in turn -- half as many workgroup prologues
-// (LDS fill, barrier, first loads) for the same balance. Measured on cfg3: 8 chains 14.4 -> 13.4 us per chain gradient
-// (single segment), 13.6 -> 12.6 (two segments); 16 chains 12.4 -> 11.7; cfg4 72.6 -> 70.5; at 2.4 rounds (4 chains) it
-// costs 2 % and is not used. The pump calls this again as chains finish: fewer chains, fewer rounds.
-static void set_groups_per_wave(ppcx_model* m, int nactive) {
-  const int G = m->d.G;
-  const double slots = 4096.0;
-  const int gpw = 64 / m->L;
-  const int ngroups0 = (m->G0 + gpw - 1) / gpw;
-  const double rounds0 = ceil((double)ngroups0 / 4.0) * 4.0 * (nactive < 1 ? 1 : nactive) / slots;
-  int r = (m->G0 < G ? rounds0 >= 1.99 : rounds0 >= 4.0) ? 2 : 1;
-  if (m->gpw_override > 0) r = m->gpw_override;
-  const int cap = 65528;                       // grid.y limit (the launcher pads to a multiple of 8)
-  const int gpw1 = gpw > 1 ? gpw / 2 : 1;
-  const int ngroups1 = (G - m->G0 + gpw1 - 1) / gpw1;
-  int nb0 = (ngroups0 + 4 * r - 1) / (4 * r), nb1 = (ngroups1 + 3) / 4;
-  while (nb0 + nb1 > cap) { ++r; nb0 = (ngroups0 + 4 * r - 1) / (4 * r); nb1 = (ngroups1 + 4 * r - 1) / (4 * r); }
-  m->groups_per_wave = r;
-  m->nb0 = nb0 < 1 ? 1 : nb0; m->nb1 = m->G0 < G ? nb1 : 0;
-  m->nblocks = m->nb0 + m->nb1;
+// Launch geometry of the log-likelihood kernel. The launch is resident: n_res = (workgroups the chip holds at once)
+// divided among the chains of the launch, four wavefronts each; wavefront j of a chain walks the gene positions
+// bounds[j] .. bounds[j + 1] of the gene order, 64 / L genes per pass.
+//   pass cost (in row-sweep iterations of a lane): 5.8 for loading and closing the genes, ceil(S / L) for the row sweep
+//   (a little more on the two-group path, 2.5 x on the generic path with an exp per cell), 0.75 per iteration of the
+//   low-count loop, which lasts as long as the longest list of the pass needs -- from the kernel's instruction counts
+//   (profiles/, SQ_INSTS_VALU: ~50 per row-sweep cell, ~100 per list cell, ~250 per pass).
+//   L: minimise passes x pass cost for the full chain count (chosen once per fit: a gene's sums depend on L).
+//   bounds: contiguous ranges of whole passes of (nearly) equal cost -- the boundary of wavefront j is where the running
+//   cost crosses j / (wavefronts per chain) of the total; recomputed when chains finish and the others get their slots.
+static double pass_cost(const ppcx_model* m, int L, int p, int n) {
+  const int S = m->d.S;
+  int lowmax = 0; bool slope = false;
+  for (int i = p; i < p + n; ++i) { if (m->pos_low[i] > lowmax) lowmax = m->pos_low[i]; slope = slope || m->pos_slope[i]; }
+  const double sweep = (double)((S + L - 1) / L) * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? 1.15 : 1.0));
+  return 5.8 + sweep + 0.75 * (double)((lowmax + L - 1) / L);
 }
-
-static double launch_wave_time(int S, int L) {
-  const int iters = (S + L - 1) / L;
-  return 400.0 + iters * (80.0 + 2.0 * log2(64.0 / L));
+static int resident_workgroups(const ppcx_model* m, int share) {
+  int n = m->wgs_override > 0 ? m->wgs_override : m->n_cu * m->wgs_per_cu;
+  n /= share < 1 ? 1 : share;
+  return n < 1 ? 1 : n;
 }
-static double launch_eff_rounds(double rounds) { return rounds <= 1.0 ? 1.0 : 0.5 * rounds + 0.5 * ceil(rounds); }
+// workgroups per chain: all of the resident ones, a multiple of 8 (the kernel deals runs of 8 to the XCDs), not more
+// than there are passes to hand out
+static int workgroups_per_chain(const ppcx_model* m, int L, int nch, int n_res) {
+  int nbpc = n_res / (nch < 1 ? 1 : nch);
+  if (nbpc >= 8) nbpc = nbpc / 8 * 8;
+  if (nbpc < 1) nbpc = 1;
+  const int gpw = 64 / L, npass = (m->d.G + gpw - 1) / gpw;
+  if (nbpc > (npass + 3) / 4) nbpc = (npass + 3) / 4;
+  return nbpc;
+}
 static void choose_launch(ppcx_model* m, int nchains) {
   const int G = m->d.G, S = m->d.S;
-  const double slots = 4096.0;
-  int bestL = 64, bestG0 = G; double best = 1e300;
+  int bestL = 64; double best = 1e300;
   for (int L = 1; L <= 64; L <<= 1) {
-    const int gpb = 4 * (64 / L);                                      // genes per workgroup
-    const double rounds = ceil((double)G / gpb) * 4.0 * nchains / slots;
-    const double t = launch_wave_time(S, L) * launch_eff_rounds(rounds);
+    const int gpw = 64 / L;
+    const int wpc = 4 * workgroups_per_chain(m, L, nchains, resident_workgroups(m, 1));
+    const double npass = ceil((double)G / gpw) / wpc, pass = 5.8 + (double)((S + L - 1) / L);
+    const double t = (npass < 1.0 ? 1.0 : npass + 0.5) * pass;   // + 0.5: ranges are whole passes, some wavefronts get one more
     if (t < best) { best = t; bestL = L; }
   }
-  // two segments only where the model promises at least 3 % and the 2L segment still has >= 24 cells per lane (below
-  // that its per-gene overhead eats the gain). Measured on cfg3: 8 chains (4 + 8 lanes) -6 %; 4 chains (8 + 16 lanes)
-  // and 16 chains (2 + 4 lanes against a single 4-lane launch of 4.9 rounds) +2 % -- both excluded by these conditions.
-  double best_split = 0.97 * best;
-  for (int L = 1; L < 64 && m->split_override != 0; L <<= 1) {
-    const int gpb = 4 * (64 / L);
-    const double rounds = ceil((double)G / gpb) * 4.0 * nchains / slots;
-    if (rounds <= 1.0 || (S + 2 * L - 1) / (2 * L) < 24) continue;
-    const long nb0 = (long)(floor(rounds) * slots / (4.0 * nchains));
-    const long G0 = nb0 * gpb;
-    if (G0 <= 0 || G0 >= G) continue;
-    const double r1 = ceil((double)(G - G0) / (gpb / 2)) * 4.0 * nchains / slots;
-    const double t2 = launch_wave_time(S, L) * floor(rounds) + launch_wave_time(S, 2 * L) * launch_eff_rounds(r1);
-    if (t2 < best_split) { best_split = t2; bestL = L; bestG0 = (int)G0; }
+  const int L = m->L_override > 0 ? m->L_override : bestL;
+  if (L != m->L) {
+    std::lock_guard<std::mutex> lk(m->plan_mutex);
+    for (auto& kv : m->plans) (void)hipFree(kv.second.d_bounds);
+    m->plans.clear();
+    m->L = L;
   }
-  if (m->L_override > 0) { bestL = m->L_override; bestG0 = G; }
-  m->L = bestL;
-  m->G0 = bestG0;
-  set_groups_per_wave(m, nchains);
-  m->nblocks_chosen = m->nblocks;
+  m->nblocks_chosen = workgroups_per_chain(m, m->L, nchains, resident_workgroups(m, 1)) * nchains;
+}
+static void drop_plans(ppcx_model* m) {
+  std::lock_guard<std::mutex> lk(m->plan_mutex);
+  for (auto& kv : m->plans) (void)hipFree(kv.second.d_bounds);
+  m->plans.clear();
+}
+// the ranges for a launch of `nch` chains that may use 1 / share of the chip (share > 1: stream groups)
+static int plan_launch(ppcx_model* m, int nch, int share, ppcx_model::Plan* out) {
+  std::lock_guard<std::mutex> lk(m->plan_mutex);
+  const int n_res = resident_workgroups(m, share);
+  const auto key = std::make_pair(nch, n_res);
+  auto it = m->plans.find(key);
+  if (it != m->plans.end()) { *out = it->second; return PPCX_OK; }
+  const int G = m->d.G, L = m->L, gpw = 64 / L;
+  const int nbpc = workgroups_per_chain(m, L, nch, n_res), wpc = 4 * nbpc, npass = (G + gpw - 1) / gpw;
+  std::vector<double> cost(npass);
+  double total = 0;
+  for (int k = 0; k < npass; ++k) {
+    const int p = k * gpw;
+    cost[k] = pass_cost(m, L, p, G - p < gpw ? G - p : gpw);
+    total += cost[k];
+  }
+  // boundary j where the running cost crosses j / wpc of the total, at the nearest whole pass
+  std::vector<int> bounds(wpc + 1, G);
+  bounds[0] = 0;
+  {
+    int k = 0; double cum = 0.0;
+    for (int j = 1; j < wpc; ++j) {
+      const double target = total * (double)j / (double)wpc;
+      while (k < npass && cum + 0.5 * cost[k] < target) cum += cost[k++];
+      bounds[j] = k * gpw < G ? k * gpw : G;
+    }
+  }
+  ppcx_model::Plan pl; pl.nbpc = nbpc;
+  HIPCHK(hipMalloc(&pl.d_bounds, sizeof(int) * (size_t)(wpc + 1)));
+  HIPCHK(hipMemcpy(pl.d_bounds, bounds.data(), sizeof(int) * (size_t)(wpc + 1), hipMemcpyHostToDevice));
+  m->plans[key] = pl;
+  *out = pl;
+  return PPCX_OK;
 }
 
 static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
@@ -141,6 +172,7 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
   }
   std::vector<double> Sy(G, 0.0), SyE(G, 0.0), SyX((size_t)C * G, 0.0), SX((size_t)C * G, 0.0), ncell(G, 0.0), Lg1(G, 0.0);
   std::vector<unsigned> low; std::vector<int> low_start(G + 1, 0), nhi(G, 0);
+  std::vector<unsigned short> low_m((size_t)G * 8, 0);
   for (int g = 0; g < G; ++g) {
     double sy = 0, sye = 0, nc = 0, lg1 = 0;
     low_start[g] = (int)low.size();
@@ -148,7 +180,7 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
       const int y = cnt[(size_t)g * S + s];
       if (y < 0) continue;
       sy += y; sye += (double)y * m->expo_host[s]; nc += 1.0; lg1 += lgamma((double)y + 1.0);
-      if (y < kLowCount) low.push_back(((unsigned)y << 16) | (unsigned)s); else nhi[g]++;
+      if (y < kLowCount) { low.push_back(((unsigned)y << 16) | (unsigned)s); for (int k = 0; k < y; ++k) low_m[(size_t)g * 8 + k]++; } else nhi[g]++;
       for (int c = 0; c < C; ++c) { SyX[(size_t)c * G + g] += (double)y * m->X_host[(size_t)c * S + s]; SX[(size_t)c * G + g] += m->X_host[(size_t)c * S + s]; }
     }
     Sy[g] = sy; SyE[g] = sye; ncell[g] = nc; Lg1[g] = lg1;
@@ -163,6 +195,7 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
   HIPCHK(hipMemcpy(m->d_low, low.data(), sizeof(unsigned) * low.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_low_start, low_start.data(), sizeof(int) * (size_t)(G + 1), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_nhi, nhi.data(), sizeof(int) * (size_t)G, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->d_low_m, low_m.data(), sizeof(unsigned short) * low_m.size(), hipMemcpyHostToDevice));
   // gene_order: a wavefront holds several genes, runs the plain and the slope cell paths one after the other when it
   // holds genes of both kinds, and stays in the low-count loop (ppcx_gene.h gene_cells) for as long as its gene with the
   // longest list needs. So neighbours in the launch should be alike: genes with slopes first, then by the length of
@@ -177,6 +210,9 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
       return low_start[a + 1] - low_start[a] > low_start[b + 1] - low_start[b];
     });
     HIPCHK(hipMemcpy(m->d_order, ord.data(), sizeof(int) * (size_t)G, hipMemcpyHostToDevice));
+    m->pos_low.resize(G); m->pos_slope.resize(G);
+    for (int p = 0; p < G; ++p) { m->pos_low[p] = low_start[ord[p] + 1] - low_start[ord[p]]; m->pos_slope[p] = ord[p] < K && C >= 2; }
+    drop_plans(m);
   }
   HIPCHK(hipMemcpy(m->d_counts, cnt.data(), sizeof(int32_t) * cnt.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_Sy, Sy.data(), sizeof(double) * G, hipMemcpyHostToDevice));
@@ -197,7 +233,7 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   if (C > kMaxC) return fail(PPCX_ERR_LIMIT, "C exceeds the 8 design columns this build supports");
   if ((long long)G * S > 2000000000LL) return fail(PPCX_ERR_LIMIT, "G*S exceeds int32 cell ids");
   // the log-likelihood kernel stages the log table and the per-sample constants (exp(exposure), exposure, X) in LDS
-  if (sizeof(double) * (2 * (size_t)kLogTabSize + (size_t)S * (2 + C)) > 160u * 1024u)
+  if (loglik_lds_bytes(S, C) > 160u * 1024u)
     return fail(PPCX_ERR_LIMIT, "S * (2 + C) doubles of per-sample constants do not fit the 160 KB of LDS of a compute unit");
   if (!counts || !X || !exposure || (n_excl > 0 && !excl)) return fail(PPCX_ERR_ARG, "NULL input buffer");
   for (long long i = 0; i < (long long)G * S; ++i) if (counts[i] < 0) return fail(PPCX_ERR_ARG, "negative count");
@@ -209,8 +245,13 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   m->device = device;
   m->d = make_dims(G, S, C, K, lambda_mu_mu);
   m->CM = C <= 2 ? 2 : (C <= 4 ? 4 : 8);
-  m->L_override = 0; m->gpw_override = 0;
-  if (const char* e = getenv("PPCX_SPLIT")) m->split_override = atoi(e);
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    m->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    m->wgs_per_cu = loglik_resident_workgroups_per_cu(m->CM, S, C);
+    if (m->wgs_per_cu < 1) { delete m; return fail(PPCX_ERR_LIMIT, "the log-likelihood kernel cannot be resident with S * (2 + C) doubles of per-sample constants in LDS"); }
+  }
   m->counts_host.assign(counts, counts + (size_t)G * S);
   m->X_host.assign(X, X + (size_t)S * C);
   m->expo_host.assign(exposure, exposure + S);
@@ -226,8 +267,8 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
 #define MCHK(expr) do { int rc_ = (expr); if (rc_ != PPCX_OK) { ppcx_model_destroy(m); return rc_; } } while (0)
 #define MHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ppcx_model_destroy(m); return fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
   MHIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-  MHIP(hipMalloc(&m->d_counts, sizeof(int32_t) * ((size_t)G * S + 64)));   // + 64: the cell loop requests the next cell before testing s < S
-  MHIP(hipMemset(m->d_counts, 0, sizeof(int32_t) * ((size_t)G * S + 64)));
+  MHIP(hipMalloc(&m->d_counts, sizeof(int32_t) * ((size_t)G * S + 512)));   // + 512: the row sweep requests counts up to two trips of 4 x 64 lanes past the end
+  MHIP(hipMemset(m->d_counts, 0, sizeof(int32_t) * ((size_t)G * S + 512)));
   MHIP(hipMalloc(&m->d_E, sizeof(double) * S));
   MHIP(hipMalloc(&m->d_expo, sizeof(double) * S));
   MHIP(hipMalloc(&m->d_X, sizeof(double) * (size_t)S * C));
@@ -238,6 +279,7 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   MHIP(hipMalloc(&m->d_ncell, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_low_start, sizeof(int) * (size_t)(G + 1)));
   MHIP(hipMalloc(&m->d_nhi, sizeof(int) * (size_t)G));
+  MHIP(hipMalloc(&m->d_low_m, sizeof(unsigned short) * (size_t)G * 8));
   MHIP(hipMalloc(&m->d_Lg1, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_logtab, sizeof(double) * 2 * kLogTabSize));
   { double tab[2 * kLogTabSize]; fill_log_table(tab); MHIP(hipMemcpy(m->d_logtab, tab, sizeof(tab), hipMemcpyHostToDevice)); }
@@ -256,11 +298,14 @@ extern "C" int ppcx_model_set_exclusions(ppcx_model* m, int n_excl, const int32_
   HIPCHK(hipSetDevice(m->device));
   return upload_counts(m, n_excl, excl);
 }
-extern "C" int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int groups_per_wave) {
+extern "C" int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int workgroups) {
   if (!m) return fail(PPCX_ERR_ARG, "model is NULL");
   if (lanes_per_gene != 0 && (lanes_per_gene < 1 || lanes_per_gene > 64 || (lanes_per_gene & (lanes_per_gene - 1))))
     return fail(PPCX_ERR_ARG, "lanes_per_gene must be 0 or a power of two <= 64");
-  m->L_override = lanes_per_gene; m->gpw_override = groups_per_wave > 0 ? groups_per_wave : 0;
+  if (workgroups < 0 || workgroups > (1 << 20)) return fail(PPCX_ERR_ARG, "workgroups must be 0 (automatic) or a positive count");
+  HIPCHK(hipSetDevice(m->device));
+  m->L_override = lanes_per_gene; m->wgs_override = workgroups;
+  drop_plans(m);
   choose_launch(m, 1);
   return PPCX_OK;
 }
@@ -276,7 +321,7 @@ extern "C" void ppcx_model_destroy(ppcx_model* m) {
   if (m->live_fits > 0) { m->destroy_requested = true; return; }   // freed by the last ppcx_fit_free
   (void)hipSetDevice(m->device);
   (void)hipFree(m->d_counts); (void)hipFree(m->d_E); (void)hipFree(m->d_expo); (void)hipFree(m->d_X);
-  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_SX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_low); (void)hipFree(m->d_low_start); (void)hipFree(m->d_nhi); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_order);
+  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_SX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_low); (void)hipFree(m->d_low_start); (void)hipFree(m->d_nhi); (void)hipFree(m->d_low_m); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_order);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -296,11 +341,13 @@ struct Work {
   int* done_host = nullptr;
   long Dpad = 0; int nb_update = 1, nb_close = 1; long launches = 0;
   hipStream_t stream = nullptr; bool own_stream = false;
-  bool retune_launch = true;     // the pump may adapt the model's groups per wavefront (not when several pumps share the model)
+  int share = 1;                 // pumps that run on the model at the same time (stream groups): each plans for 1/share of the chip
+  int *active = nullptr, *active_host = nullptr; int n_active = 0;   // chains still running (pump), 0 = all
   ~Work() {
     (void)hipFree(vecs); (void)hipFree(partials); (void)hipFree(done); (void)hipFree(sums); (void)hipFree(red);
     for (int i = 0; i < 2; ++i) { (void)hipFree(hyper_vecs[i]); (void)hipFree(t0[i]); (void)hipFree(cmds[i]); (void)hipFree(states[i]); }
     if (done_host) (void)hipHostFree(done_host);
+    (void)hipFree(active); if (active_host) (void)hipHostFree(active_host);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -319,6 +366,8 @@ static int work_alloc(Work& w, ppcx_model* m, int nchains) {
   HIPCHK(hipMalloc(&w.red, sizeof(double) * (size_t)nchains * PT_COUNT));
   HIPCHK(hipMemsetAsync(w.red, 0, sizeof(double) * (size_t)nchains * PT_COUNT, w.stream));
   HIPCHK(hipHostMalloc(&w.done_host, sizeof(int) * nchains));
+  HIPCHK(hipHostMalloc(&w.active_host, sizeof(int) * nchains));
+  HIPCHK(hipMalloc(&w.active, sizeof(int) * nchains));
   for (int i = 0; i < 2; ++i) {
     HIPCHK(hipMalloc(&w.hyper_vecs[i], sizeof(double) * (size_t)nchains * V_COUNT * 8));
     HIPCHK(hipMalloc(&w.t0[i], sizeof(double) * (size_t)nchains * w.nb_update));
@@ -373,11 +422,19 @@ static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("update kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
 }
+// `nchains` chains of the work area, of which the first w.n_active entries of w.active are still running (all of
+// them when w.active is not in use)
 static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
+  const int nact = w.n_active > 0 ? w.n_active : nchains;
+  ppcx_model::Plan pl;
+  int rc = plan_launch(m, nact, w.share, &pl);
+  if (rc != PPCX_OK) return rc;
   LoglikArgs la;
-  la.d = m->d; la.counts = m->d_counts; la.low = m->d_low; la.low_start = m->d_low_start; la.n_hi = m->d_nhi; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
-  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order; la.lgL = 0; while ((1 << la.lgL) < m->L) ++la.lgL; la.nb0 = m->nb0; la.G0 = m->G0; la.nb1 = m->nb1;
-  hipError_t e = launch_loglik_kernel(m->CM, la, m->nblocks, nchains, w.stream);
+  la.d = m->d; la.cd.counts = m->d_counts; la.cd.low = m->d_low; la.cd.low_start = m->d_low_start; la.cd.n_hi = m->d_nhi; la.cd.low_m = m->d_low_m; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
+  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order;
+  la.lgL = 0; while ((1 << la.lgL) < m->L) ++la.lgL;
+  la.nchains = nact; la.active = w.n_active > 0 ? w.active : nullptr; la.nbpc = pl.nbpc; la.bounds = pl.d_bounds;
+  hipError_t e = launch_loglik_kernel(m->CM, la, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("loglik kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
 }
@@ -526,7 +583,17 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
     } else if (local_rc != PPCX_OK) break;
     if (n_done == nchains) break;
     if (rc == PPCX_ERR_STALL) break;
-    if (ns == 1 && w0.retune_launch && !guarded) set_groups_per_wave(sh[0].m, nchains - n_done);   // fewer chains in the launch: fewer rounds
+    // fewer chains in the launch: the others get their wavefronts (the stream is idle here, the list can be rewritten)
+    if (n_done > 0) {
+      int na = 0;
+      for (int c = 0; c < nchains; ++c) if (!w0.done_host[c]) w0.active_host[na++] = c;
+      for (int k = 0; k < ns; ++k) {
+        Work& wk = *sh[k].w;
+        HIPCHK(hipMemcpyAsync(wk.active, w0.active_host, sizeof(int) * na, hipMemcpyHostToDevice, st));
+        wk.n_active = na;
+      }
+      HIPCHK(hipStreamSynchronize(st));
+    }
   }
 #undef PUMP_TRY
   stats->pairs = pairs;
@@ -690,7 +757,7 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
     Group& G = grp[g];
     G.c0 = (int)((long long)nch * g / ngrp); G.n = (int)((long long)nch * (g + 1) / ngrp) - G.c0;
     if (g > 0) { FHIP(hipStreamCreateWithFlags(&G.w.stream, hipStreamNonBlocking)); G.w.own_stream = true; }
-    G.w.retune_launch = ngrp == 1;
+    G.w.share = ngrp;
     int rc = work_alloc(G.w, m, G.n);
     if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }
     std::vector<ChainState> states(G.n);

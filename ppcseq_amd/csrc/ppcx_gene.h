@@ -1,5 +1,5 @@
 // ppcx_gene.h -- the per-gene bodies of the kernels:
-//   log-likelihood kernel : gene_load -> gene_cells (per lane) -> [L-lane butterfly] -> per-gene sums
+//   log-likelihood kernel : lane_gene_sums (per lane) -> [L-lane butterfly] -> per-gene sums
 //   close kernel          : gene_load -> gene_finish -> tree bookkeeping (coord_merge_dots / coord_store_slot /
 //                           coord_top_dots)
 //   update kernel         : coord_update (per coordinate: the command's coordinate work + coord_consts)
@@ -35,9 +35,8 @@ PPCX_HD void coord_consts(const Dims& d, const VecRef& v, int i, double q, const
   }
 }
 
-// load the gene's (already drifted) coordinates -- coefficients, sigma_raw, phi -- and, for the log-likelihood kernel
-// (CELLS), the constants of the cell loop that coord_consts left next to them
-template <int CM, bool CELLS>
+// load the gene's (already drifted) coordinates -- coefficients, sigma_raw, phi -- for the close kernel
+template <int CM>
 PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, GeneCtx<CM>& x) {
   constexpr int NCM = CM + 1;
   x.active = g < d.G;
@@ -60,85 +59,153 @@ PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, Gene
   x.gp.sigma_raw = q[1];
   x.gp.phi = x.active ? v.at(V_C0, x.idx[1]) : 1.0;        // sigma = 1 ./ exp(sigma_raw)   (.stan:203)
   x.gp.invphi = 0.0; x.gp.dlt = 0.0; x.gp.dps = 0.0; x.gp.A = 0.0; x.gp.A1 = 0.0;
-  if (CELLS && x.active) {
-    x.gp.invphi = v.at(V_C1, x.idx[1]); x.gp.dlt = v.at(V_C2, x.idx[1]); x.gp.dps = v.at(V_C3, x.idx[1]);
-    x.gp.A = v.at(V_C0, x.idx[0]) * x.gp.invphi;           // exp(intercept + sigma_raw)
-    if (x.two) x.gp.A1 = x.gp.A * v.at(V_C0, x.idx[2]);    // ... + slope
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The log-likelihood kernel's work on one gene, as seen by ONE of the L lanes that share the gene (sub = 0 .. L - 1):
+//   (1) the row sweep: cells s = sub, sub + L, ... with y >= 8 -- one regime, straight-line code (cell_eval); cells with
+//       smaller or excluded (-1) counts are passed over. Four cells per trip, the counts of the next trip requested
+//       before the current one is evaluated; L is a compile-time constant, so the four loads of a trip differ by
+//       immediate offsets and a trip costs one address update;
+//   (2) the gene's low-count list (0 <= y <= 7; entries (y << 16) | s, built by the host in sample order): cell_eval_low;
+//   (3) the count part of the list cells, low_terms, term k by lane k (mod L).
+// Genes with slopes in a two-group design take the same route with e^t = E_s A or E_s A1 by the sample's group; any
+// other gene with slopes, and every gene when X[,1] != 1, forms eta per cell (generic_cells: an exp per cell).
+// `counts` must be readable 4 L entries past the end of the matrix, `sE` / `sX` (LDS) 4 L entries past S, `low` L past
+// its end: the host and the kernel pad them.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kLowCount = 8;     // counts below this are list cells
+struct CellData {                // the chain-independent inputs of the log-likelihood kernel (device pointers)
+  const int* counts;             // G x S gene-major, excluded cells = -1
+  const unsigned* low;           // the cells with 0 <= count <= 7, gene after gene: (count << 16) | sample
+  const int* low_start;          // [G + 1] a gene's range in `low`
+  const int* n_hi;               // [G] number of cells with count >= 8
+  const unsigned short* low_m;   // [G][8] entry k < 7: number of list cells with count > k
+};
+
+template <int CM, int L, bool TWO>
+PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* sX1, int sub, double A, double A1,
+                         const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& acc) {
+  const int nmin = S / L;                                  // cells every lane of the gene has
+  const int nlane = nmin + (sub < S - nmin * L ? 1 : 0);
+  const int* p = row + sub;
+  const double* q = sE + sub;
+  const double* qx = sX1 + sub;
+  int y0 = p[0], y1 = p[L], y2 = p[2 * L], y3 = p[3 * L];
+  int k = 0;
+#define PPCX_SWEEP_CELL(Y, E, XB, COND)                                                         \
+  if ((COND) && (Y) >= kLowCount) {                                                             \
+    if (TWO) { const double rho_ = cell_eval<CM>(Y, E, (XB) != 0.0 ? A1 : A, gp, tab, acc);     \
+               acc.Tx[1] = fma(XB, rho_, acc.Tx[1]); }                                          \
+    else (void)cell_eval<CM>(Y, E, A, gp, tab, acc);                                            \
+  }
+  for (; k + 4 <= nmin; k += 4) {
+    const double e0 = q[0], e1 = q[L], e2 = q[2 * L], e3 = q[3 * L];
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+    if (TWO) { x0 = qx[0]; x1 = qx[L]; x2 = qx[2 * L]; x3 = qx[3 * L]; }
+    p += 4 * L; q += 4 * L; qx += 4 * L;
+    const int n0 = p[0], n1 = p[L], n2 = p[2 * L], n3 = p[3 * L];
+    PPCX_SWEEP_CELL(y0, e0, x0, true)
+    PPCX_SWEEP_CELL(y1, e1, x1, true)
+    PPCX_SWEEP_CELL(y2, e2, x2, true)
+    PPCX_SWEEP_CELL(y3, e3, x3, true)
+    PPCX_KEEP_BRANCH();
+    acc.renorm();
+    y0 = n0; y1 = n1; y2 = n2; y3 = n3;
+  }
+  if (k < nlane) {                                         // the last, partial trip
+    const double e0 = q[0], e1 = q[L], e2 = q[2 * L], e3 = q[3 * L];
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+    if (TWO) { x0 = qx[0]; x1 = qx[L]; x2 = qx[2 * L]; x3 = qx[3 * L]; }
+    PPCX_SWEEP_CELL(y0, e0, x0, true)
+    PPCX_SWEEP_CELL(y1, e1, x1, k + 1 < nlane)
+    PPCX_SWEEP_CELL(y2, e2, x2, k + 2 < nlane)
+    PPCX_SWEEP_CELL(y3, e3, x3, k + 3 < nlane)
+    acc.renorm();
+  }
+#undef PPCX_SWEEP_CELL
+}
+
+template <int CM, int L, bool TWO>
+PPCX_HD void low_cells(const unsigned* low, int low_n, const double* sE, const double* sX1, int sub, double A, double A1,
+                       const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& acc) {
+  unsigned en = low[sub];
+  for (int i = sub; i < low_n; i += L) {
+    const unsigned ec = en;
+    en = low[i + L];
+    const int sl = (int)(ec & 0xffffu);
+    if (TWO) {
+      const double xb = sX1[sl];
+      const double rho = cell_eval_low<CM>((int)(ec >> 16), sE[sl], xb != 0.0 ? A1 : A, gp, tab, acc);
+      acc.Tx[1] = fma(xb, rho, acc.Tx[1]);
+    } else (void)cell_eval_low<CM>((int)(ec >> 16), sE[sl], A, gp, tab, acc);
   }
 }
 
-// The gene's cells, split over its L lanes: (1) the row sweep s = sub, sub+L, ... evaluates the cells with y >= 8 --
-// one regime, straight-line code; cells with smaller or excluded (-1) counts are passed over; (2) the gene's low-count
-// list (0 <= y <= 7; entries (y << 16) | s, built by the host in sample order) goes through cell_eval_low.
-// `row`, `sE`, `sX` and `low` must be readable up to L entries past their end: the next cell is requested
-// unconditionally before the current one is evaluated (the host pads the arrays).
-constexpr int kLowCount = 8;     // counts below this are list cells
-template <int CM>
-PPCX_HD void gene_cells(const Dims& d, const GeneCtx<CM>& x, const int* row, const unsigned* low, int low_n,
-                        const double* sE, const double* sExpo, const double* sX, const double* tab, int sub, int L,
-                        CellAcc<CM>& acc) {
+// a gene whose linear predictor has to be formed per cell: t = exposure_s + X_s . coef + sigma_raw, u = exp(t)
+template <int CM, int L>
+PPCX_HD void generic_cells(const Dims& d, const Cmd& c, const VecRef& v, int g, bool has_slopes, const int* row,
+                           const double* sExpo, const double* sX, int sub, GeneParams<CM>& gp, const double* tab,
+                           CellAcc<CM>& acc) {
   const int S = d.S, C = d.C;
-  const GeneParams<CM>& gp = x.gp;
-  if (!x.active) return;
+  gp.sigma_raw = v.at(V_Q0 + 3 * c.dir, d.off_sigma_raw + g);
+  gp.coef[0] = v.at(V_Q0 + 3 * c.dir, d.off_intercept + g);
+#pragma unroll
+  for (int cc = 1; cc < CM; ++cc) gp.coef[cc] = (has_slopes && cc < C) ? v.at(V_Q0 + 3 * c.dir, coef_index(d, cc, g)) : 0.0;
   int it = 0;
-  if (x.fast) {
-    int s = sub;
-    int yn = row[s];
-    double en = sE[s];
-    if (!PPCX_WAVE_ANY(x.two)) {
-      while (s < S) {
-        const int y = yn;
-        const double e = en;
-        s += L;
-        yn = row[s]; en = sE[s];
-        if (y >= kLowCount) (void)cell_eval<CM>(y, e, gp.A, gp, tab, acc);
-        if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
-      }
-      for (int i = sub; i < low_n; i += L) {
-        const unsigned en2 = low[i];
-        const int sl = (int)(en2 & 0xffffu);
-        (void)cell_eval_low<CM>((int)(en2 >> 16), sE[sl], gp.A, gp, tab, acc);
-        if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
-      }
-    } else {
-      // two-group design, wavefront with slope genes: e^t = E_s A or E_s A1 by the sample's group (X[,2] is 0 or 1)
-      const double* sX1 = sX + S;
-      double xn = sX1[s];
-      while (s < S) {
-        const int y = yn;
-        const double e = en, xb = xn;
-        s += L;
-        yn = row[s]; en = sE[s]; xn = sX1[s];
-        if (y >= kLowCount) {
-          const double rho = cell_eval<CM>(y, e, (x.two && xb != 0.0) ? gp.A1 : gp.A, gp, tab, acc);
-          acc.Tx[1] = fma(xb, rho, acc.Tx[1]);
-        }
-        if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
-      }
-      for (int i = sub; i < low_n; i += L) {
-        const unsigned en2 = low[i];
-        const int sl = (int)(en2 & 0xffffu);
-        const double xb = sX1[sl];
-        const double rho = cell_eval_low<CM>((int)(en2 >> 16), sE[sl], (x.two && xb != 0.0) ? gp.A1 : gp.A, gp, tab, acc);
-        acc.Tx[1] = fma(xb, rho, acc.Tx[1]);
-        if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
-      }
+  for (int s = sub; s < S; s += L) {
+    const int y = row[s];
+    if (y >= 0) {
+      double t = sExpo[s] + gp.sigma_raw;
+#pragma unroll
+      for (int cc = 0; cc < CM; ++cc) if (cc < C) t += sX[cc * S + s] * gp.coef[cc];
+      const double u = fast_exp(t);
+      const double rho = y >= kLowCount ? cell_eval<CM>(y, u, 1.0, gp, tab, acc) : cell_eval_low<CM>(y, u, 1.0, gp, tab, acc);
+#pragma unroll
+      for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.Tx[cc] = fma(sX[cc * S + s], rho, acc.Tx[cc]);
     }
-  } else {
-    for (int s = sub; s < S; s += L) {
-      const int y = row[s];
-      if (y >= 0) {
-        double t = sExpo[s] + gp.sigma_raw;
-#pragma unroll
-        for (int cc = 0; cc < CM; ++cc) if (cc < C) t += sX[cc * S + s] * gp.coef[cc];
-        const double u = fast_exp(t);
-        const double rho = y >= kLowCount ? cell_eval<CM>(y, u, 1.0, gp, tab, acc) : cell_eval_low<CM>(y, u, 1.0, gp, tab, acc);
-#pragma unroll
-        for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.Tx[cc] = fma(sX[cc * S + s], rho, acc.Tx[cc]);
+    if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
+  }
+}
+
+// one lane's share of gene g: the hand-over sums before the L-lane reduction
+template <int CM, int L>
+PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const CellData& m, int g, int sub,
+                            const double* sE, const double* sExpo, const double* sX, const double* tab,
+                            GeneSumsV<CM>& o) {
+  const int S = d.S;
+  const int i_sr = d.off_sigma_raw + g;
+  const bool has_slopes = g < d.K && d.C >= 2;
+  const bool two = has_slopes && d.x0_is_one && d.x1_binary;
+  const bool generic = !d.x0_is_one || (has_slopes && !two);
+  GeneParams<CM> gp;
+  gp.phi = v.at(V_C0, i_sr); gp.invphi = v.at(V_C1, i_sr); gp.dlt = v.at(V_C2, i_sr); gp.dps = v.at(V_C3, i_sr);
+  const double A = v.at(V_C0, d.off_intercept + g) * gp.invphi;       // exp(intercept + sigma_raw)
+  const int lo = m.low_start[g], low_n = m.low_start[g + 1] - lo;
+  const double nhi = sub == 0 ? (double)m.n_hi[g] : 0.0;
+  const int* row = m.counts + (long)g * S;
+  CellAcc<CM> acc; acc.zero();
+  if (PPCX_WAVE_ANY(generic)) {
+    if (generic) generic_cells<CM, L>(d, c, v, g, has_slopes, row, sExpo, sX, sub, gp, tab, acc);
+  }
+  if (PPCX_WAVE_ANY(!generic)) {
+    if (!generic) {
+      if (PPCX_WAVE_ANY(two)) {                            // e^t = E_s A or E_s A1 by the sample's group (X[,2] is 0 or 1)
+        const double A1 = two ? A * v.at(V_C0, coef_index(d, 1, g)) : A;
+        sweep_cells<CM, L, true>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc);
+        low_cells<CM, L, true>(m.low + lo, low_n, sE, sX + S, sub, A, A1, gp, tab, acc);
+      } else {
+        sweep_cells<CM, L, false>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+        low_cells<CM, L, false>(m.low + lo, low_n, sE, sX, sub, A, A, gp, tab, acc);
       }
-      if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
     }
   }
+  double low_lik = 0.0, low_dph = 0.0;
+  if (PPCX_WAVE_ANY(low_n > 0)) {
+    if (low_n > 0)
+      for (int k = sub; k < kLowCount - 1; k += L) low_terms(k, (double)m.low_m[(long)g * 8 + k], gp.invphi, tab, &low_lik, &low_dph);
+  }
+  cell_acc_close<CM>(gp, acc, tab, nhi, low_lik, low_dph, &o);
 }
 
 // close the gene with its reduced sums: gradient, second half kick, stores, partial sums part[0..9]

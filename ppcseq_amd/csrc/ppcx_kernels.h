@@ -5,12 +5,10 @@
 
 namespace ppcx {
 
+constexpr int kLdsPad = 256;     // entries the sweep may read past the per-sample arrays in LDS (4 x 64 lanes)
 struct LoglikArgs {
   Dims d;
-  const int* counts;            // G x S gene-major, excluded cells = -1
-  const unsigned* low;          // the cells with 0 <= count <= 7, gene after gene: (count << 16) | sample
-  const int* low_start;         // [G + 1] a gene's range in `low`
-  const int* n_hi;              // [G] number of cells with count >= 8
+  CellData cd;                  // counts, low-count lists (ppcx_gene.h)
   const double* sampleE;        // exp(exposure_s)
   const double* exposure;       // S
   const double* X;              // S x C column-major
@@ -20,9 +18,11 @@ struct LoglikArgs {
   double* sums;                 // [chains][3+CM][G] (GeneSumsV)
   const double* logtab;         // 2 x 256 doubles (device), ppcx_math.h table_log
   const int* order;             // [G] launch position -> gene (host: gene_order)
-  int lgL;                      // log2 of the lanes per gene of the first segment
-  int nb0, G0, nb1;             // launch segments (choose_launch): nb0 workgroups per chain cover the first G0 gene positions
-                                // with L lanes per gene, nb1 workgroups the rest with 2L (nb1 = 0: one segment, G0 = G)
+  int lgL;                      // log2 of the lanes per gene
+  int nchains;                  // chains of this launch
+  const int* active;            // [nchains] their indices in cmds / vecs / sums (null: 0 .. nchains - 1)
+  int nbpc;                     // workgroups per chain; wavefront j = 0 .. 4 nbpc - 1 of a chain takes the gene positions
+  const int* bounds;            // [4 nbpc + 1]  bounds[j] .. bounds[j + 1] - 1 (host: plan_launch, balanced by cost)
 };
 
 struct CloseArgs {
@@ -96,7 +96,9 @@ struct PpcArgs {
   int* scratch;                 // null: a cell's draws in LDS (grid = n_cells); else [grid][n_gen] global scratch, cells in turn
 };
 
-hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st);
+hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, hipStream_t st);
+int loglik_resident_workgroups_per_cu(int CM, int S, int C);   // 0: the kernel cannot be launched with this much LDS
+size_t loglik_lds_bytes(int S, int C);
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_step_kernel(const StepArgs& a, int nchains, hipStream_t st);
 hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st);

@@ -37,45 +37,70 @@ __device__ __forceinline__ double wave_xor_add_rt(double v, int lane_xor_mask) {
   const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
   return v + __hiloint2double(hi, lo);
 }
-// The launch has up to two segments (host: choose_launch): the first a.nb0 workgroups per chain take the first a.G0
-// gene positions of the host's gene order with L = 2^lgL lanes per gene -- whole rounds of resident wavefronts -- and
-// the remaining a.nb1 workgroups take the rest with 2L lanes per gene: twice as many wavefronts of half the duration,
-// which fill the last, partial round (a single-L launch of 2.4 rounds idles through 0.6 of a round; 2 + 0.9 half
-// rounds does not). L is a run-time value of the workgroup, so both segments run the same code.
+// A resident launch (host: plan_launch): as many workgroups as the chip holds at once (4 per CU at 128 VGPRs), divided
+// among the chains; every wavefront owns a contiguous range of the host's gene order -- bounds[j] .. bounds[j + 1] --
+// chosen on the host so that all ranges cost the same, and walks it 64 / L genes at a time. All wavefronts start
+// together and finish together: no partly filled last round of workgroups, one LDS fill per resident workgroup.
+// Wavefronts are independent after the LDS fill (no barrier, no atomic), and a gene's sums depend on L only.
+template <int CM, int LG>
+__device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c, const VecRef& v, double* sums, int p0, int p1,
+                                              const double* stab, const double* sE, const double* sExpo, const double* sX,
+                                              int lane, bool any_generic) {
+  constexpr int L = 1 << LG, GPW = 64 >> LG;     // lanes per gene, genes per wavefront and pass
+  const Dims& d = a.d;
+  const int sub = lane & (L - 1), gl = lane >> LG;
+  int g_next = a.order[p0 + gl < p1 ? p0 + gl : p1 - 1];
+  for (int p = p0; p < p1; p += GPW) {
+    const bool act = p + gl < p1;                // lanes past the end of the range repeat its last gene and store nothing
+    const int g = g_next;
+    const int pn = p + GPW + gl;
+    if (p + GPW < p1) g_next = a.order[pn < p1 ? pn : p1 - 1];
+    GeneSumsV<CM> o;
+    lane_gene_sums<CM, L>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, o);
+    // L-lane butterfly: every lane of the gene ends with the gene totals
+#pragma unroll
+    for (int msk = 1; msk < L; msk <<= 1) {
+      o.lik = wave_xor_add_rt(o.lik, msk); o.dph = wave_xor_add_rt(o.dph, msk); o.Sr = wave_xor_add_rt(o.Sr, msk);
+      if (any_generic) {
+#pragma unroll
+        for (int cc = 0; cc < CM; ++cc) if (cc < d.C) o.Tx[cc] = wave_xor_add_rt(o.Tx[cc], msk);
+      }
+    }
+    if (act && sub == 0) {
+      const long G = d.G;
+      sums[0 * G + g] = o.lik; sums[1 * G + g] = o.dph; sums[2 * G + g] = o.Sr;
+      if (any_generic) {
+#pragma unroll
+        for (int cc = 0; cc < CM; ++cc) if (cc < d.C) sums[(3 + cc) * G + g] = o.Tx[cc];
+      }
+    }
+  }
+}
+
 template <int CM>
 __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(LoglikArgs a) {
   extern __shared__ double lds[];
-  // grid = (chains, gene blocks): the chain is the fast index, so the dispatch order is the host's gene order
-  // (expensive genes first) for all chains together, and the tail of the launch consists of cheap workgroups
-  // and workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids c*8 + (gblock & 7) inside every run
-  // of 8 gene blocks x chains put the chains of one gene block on ONE XCD, so its L2 fetches the rows once
-  const int nch = gridDim.x, ngblocks = a.nb0 + a.nb1;
-  const int lin = blockIdx.y * nch + blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
-  const int chain = r >> 3, gb0 = run * 8 + (r & 7);
-  if (gb0 >= ngblocks) return;
+  // workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids chain * 8 + (jb & 7) inside every run of
+  // 8 range blocks x chains put the chains of one range block on ONE XCD, so its L2 fetches the rows once
+  const int nch = a.nchains;
+  const int lin = blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
+  const int jb = run * 8 + (r & 7);
+  if (jb >= a.nbpc) return;
+  const int chain = a.active ? a.active[r >> 3] : r >> 3;
   const Cmd& c = a.cmds[chain];
   if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
-  const bool seg1 = gb0 >= a.nb0;
-  const int lgL = seg1 ? (a.lgL < 6 ? a.lgL + 1 : 6) : a.lgL;
-  const int L = 1 << lgL, GPW = 64 >> lgL;       // lanes per gene, genes per wavefront
-  const int gblock = seg1 ? gb0 - a.nb0 : gb0, nseg = seg1 ? a.nb1 : a.nb0;
-  const int pos0 = seg1 ? a.G0 : 0, npos = seg1 ? a.d.G - a.G0 : a.G0;
   constexpr int NS = GeneSums<CM>::N;
   const Dims& d = a.d;
   const int S = d.S, C = d.C;
   double* stab = lds;                          // log table: 256 x 1/c then 256 x log c (4 KB)
-  double* sE = lds + 2 * kLogTabSize;          // exp(exposure_s)
-  double* sExpo = sE + S;
-  double* sX = sExpo + S;                      // S x C column-major
+  double* sE = lds + 2 * kLogTabSize;          // exp(exposure_s), readable kLdsPad entries past S (sweep_cells)
+  double* sExpo = sE + S + kLdsPad;
+  double* sX = sExpo + S;                      // S x C column-major, readable kLdsPad entries past its end
   const int tid = threadIdx.x;
   const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
   double* sums = a.sums + (long)chain * NS * d.G;
-  const int wave = tid >> 6, lane = tid & 63, sub = lane & (L - 1), gl = lane >> lgL;
-  const int ngroups = (npos + GPW - 1) >> (6 - lgL);
-  int grp = gblock * 4 + wave;
-  GeneCtx<CM> x;
-  // the first group's coordinates are requested before the LDS fill, so that the two round trips overlap
-  if (grp < ngroups) { const int p = grp * GPW + gl; gene_load<CM, true>(d, c, v, p < npos ? a.order[pos0 + p] : d.G, x); }
+  const int wave = tid >> 6, lane = tid & 63;
+  const int p0 = a.bounds[jb * 4 + wave], p1 = a.bounds[jb * 4 + wave + 1];
   for (int i = tid; i < 2 * kLogTabSize; i += 256) stab[i] = a.logtab[i];
   const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
   for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
@@ -84,29 +109,15 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
     for (int i = tid; i < S * C; i += 256) sX[i] = a.X[i];
   }
   __syncthreads();
-  for (; grp < ngroups; grp += nseg * 4) {
-    if (grp != gblock * 4 + wave) { const int p = grp * GPW + gl; gene_load<CM, true>(d, c, v, p < npos ? a.order[pos0 + p] : d.G, x); }
-    CellAcc<CM> acc; acc.zero();
-    const int lo = a.low_start[x.gg];
-    gene_cells<CM>(d, x, a.counts + (long)x.gg * S, a.low + lo, a.low_start[x.gg + 1] - lo, sE, sExpo, sX, stab, sub, L, acc);
-    GeneSumsV<CM> o;
-    cell_acc_close<CM>(x.gp, acc, stab, sub == 0 ? (double)a.n_hi[x.gg] : 0.0, &o);
-    // L-lane butterfly: every lane of the gene ends with the gene totals
-    for (int msk = 1; msk < L; msk <<= 1) {
-      o.lik = wave_xor_add_rt(o.lik, msk); o.dph = wave_xor_add_rt(o.dph, msk); o.Sr = wave_xor_add_rt(o.Sr, msk);
-      if (any_generic) {
-#pragma unroll
-        for (int cc = 0; cc < CM; ++cc) if (cc < C) o.Tx[cc] = wave_xor_add_rt(o.Tx[cc], msk);
-      }
-    }
-    if (x.active && sub == 0) {
-      const long G = d.G;
-      sums[0 * G + x.gg] = o.lik; sums[1 * G + x.gg] = o.dph; sums[2 * G + x.gg] = o.Sr;
-      if (any_generic) {
-#pragma unroll
-        for (int cc = 0; cc < CM; ++cc) if (cc < C) sums[(3 + cc) * G + x.gg] = o.Tx[cc];
-      }
-    }
+  if (p0 >= p1) return;
+  switch (a.lgL) {
+    case 0: loglik_passes<CM, 0>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 1: loglik_passes<CM, 1>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 2: loglik_passes<CM, 2>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 3: loglik_passes<CM, 3>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 4: loglik_passes<CM, 4>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 5: loglik_passes<CM, 5>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    default: loglik_passes<CM, 6>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
   }
 }
 
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
   const int g = blockIdx.x * 256 + tid;
   const bool any_generic = !d.x0_is_one || (d.C >= 2 && d.K > 0);
   GeneCtx<CM> x;
-  gene_load<CM, false>(d, c, v, g, x);
+  gene_load<CM>(d, c, v, g, x);
   GeneSumsV<CM> acc;
   acc.lik = acc.dph = acc.Sr = 0.0;
 #pragma unroll
@@ -580,13 +591,14 @@ __global__ __launch_bounds__(kPpcThreads) void ppcx_ppc_kernel(PpcArgs a) {
     double q[2];
     const double pr[2] = {a.p_lo, a.p_hi};
     for (int k = 0; k < 2; ++k) {
-      const double h = (double)(n - 1) * pr[k];
+      double h = (double)(n - 1) * pr[k];
+      PPCX_OPAQUE(h);                            // rounded here: the product must not be fused into h - lo below
       int lo = (int)floor(h);
       if (lo > n - 1) lo = n - 1;
       if (lo < 0) lo = 0;
       int v0, v1;
       block_select_pair(vals, n, lo, vmax, s_cnt, tid, &v0, &v1);
-      q[k] = lo >= n - 1 ? (double)v0 : (double)v0 + (h - (double)lo) * ((double)v1 - (double)v0);
+      q[k] = lo >= n - 1 ? (double)v0 : fma(h - (double)lo, (double)v1 - (double)v0, (double)v0);   // one rounding, as in the oracle
     }
     if (tid == 0) {
       double* o = a.ci + (long)cell * 4;
@@ -611,9 +623,26 @@ __global__ void ppcx_fill_kernel(double* p, long n, double val) {
 // -----------------------------------------------------------------------------------------------------
 // launch helpers (host)
 // -----------------------------------------------------------------------------------------------------
-hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, int nblocks, int nchains, hipStream_t st) {
-  const size_t lds_bytes = sizeof(double) * (2 * kLogTabSize + (size_t)a.d.S * (2 + a.d.C));
-  const dim3 grid(nchains, (nblocks + 7) / 8 * 8);
+size_t loglik_lds_bytes(int S, int C) { return sizeof(double) * (2 * kLogTabSize + (size_t)S * (2 + C) + 2 * kLdsPad); }
+int loglik_resident_workgroups_per_cu(int CM, int S, int C) {
+  int n = 0;
+  const size_t lds_bytes = loglik_lds_bytes(S, C);
+  hipError_t e = hipSuccess;
+  if (lds_bytes > 64u * 1024u) {               // more than the default limit of dynamic LDS: ask for it once
+    if (CM <= 2) e = hipFuncSetAttribute((const void*)ppcx_loglik_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    else if (CM <= 4) e = hipFuncSetAttribute((const void*)ppcx_loglik_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    else e = hipFuncSetAttribute((const void*)ppcx_loglik_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  }
+  if (CM <= 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<2>, 256, lds_bytes);
+  else if (CM <= 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<4>, 256, lds_bytes);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<8>, 256, lds_bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, hipStream_t st) {
+  const size_t lds_bytes = loglik_lds_bytes(a.d.S, a.d.C);
+  const dim3 grid((unsigned)((a.nbpc + 7) / 8 * 8) * (unsigned)a.nchains);
   if (CM <= 2) hipLaunchKernelGGL((ppcx_loglik_kernel<2>), grid, dim3(256), lds_bytes, st, a);
   else if (CM <= 4) hipLaunchKernelGGL((ppcx_loglik_kernel<4>), grid, dim3(256), lds_bytes, st, a);
   else hipLaunchKernelGGL((ppcx_loglik_kernel<8>), grid, dim3(256), lds_bytes, st, a);

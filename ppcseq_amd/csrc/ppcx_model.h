@@ -17,14 +17,13 @@
 //     the tails are degree-4 polynomials in 1/x^2 valid for every x >= 8 (ppcx_math.h stirling_tails);
 //   * sum_s y eta, sum_s y are per-gene SUFFICIENT STATISTICS (SyE, SyX, Sy) precomputed once, so the large
 //     cancelling terms never go through the per-cell loop; sum_s lgamma(y+1) is a per-gene constant of the data (Lg1);
-//   * cells with x < 8 (then y <= 7) use the exact recurrences instead of Stirling at x:
-//       lgamma(x) - lgamma(phi) = ln P, P = prod_{k<y}(phi+k);  psi(x) - psi(phi) = P'/P
-//     with the same instruction stream: the logarithm's argument is 1/w instead of rho, the product takes P^-2;
+//   * cells with y <= 7 do not use Stirling at x: lgamma(y + phi) - lgamma(phi) = sum_{k<y} ln(phi + k) depends on the
+//     count and on phi only, so the gene adds it once per k = 0..6, weighted by the number M_k of such cells with y > k
+//     (counted at upload); per cell only - (y + phi) ln w and rho remain: one reciprocal, one logarithm;
 //   * for genes without slope terms (g >= K, X[,1] == 1) exp(t) factorises into E_s * A_g with
 //     E_s = exp(exposure_s) staged in LDS and A_g = exp(intercept_g + sigma_raw_g): no per-cell exp;
 //   * the row sweep evaluates only the cells with y >= 8 (then x >= 8 whatever phi is: one regime, no test); the cells
-//     with 0 <= y <= 7 are kept in a per-gene list built at upload and evaluated by a second, short loop that chooses
-//     per lane between the recurrences and the tails;
+//     with 0 <= y <= 7 are kept in a per-gene list built at upload and evaluated by a second, short loop;
 //   * excluded cells (to_exclude, R/utilities.R:321-359, subtracted at .stan:105-115) are stored as count = -1, are in
 //     neither loop, and are left out of the sufficient statistics.
 #pragma once
@@ -108,12 +107,12 @@ struct GeneParams {
 // per-lane partial sums over the cells of one gene (see the header comment for the algebra)
 template <int CM>
 struct CellAcc {
-  double SA;                    // sum y ln(arg)  (+ (sigma_raw + 1) y for the cells with x < 8); arg = rho, or 1/w when x < 8
+  double SA;                    // sum y ln(arg); arg = rho for the cells of the row sweep (y >= 8), 1/w for the list cells
   double SL;                    // sum ln(arg)
-  double TL;                    // sum lg_tail(1/x) over the cells with x >= 8 (the row sweep leaves their - dlt to the gene's
-                                // epilogue, which knows their number; the low-count loop subtracts it per cell)
-  double TD;                    // sum dg_tail(1/x) over the cells with x >= 8 (- dps likewise), minus sum P'/P over the others
-  double Px; int Pxe;           // running product of xf (x >= 8) and P^-2 (x < 8): mantissa and binary exponent
+  double TL;                    // sum lg_tail(1/x) over the cells of the row sweep (their - dlt is left to the gene's
+                                // epilogue, which knows their number)
+  double TD;                    // sum dg_tail(1/x) over the cells of the row sweep (- dps likewise)
+  double Px; int Pxe;           // running product of xf over the cells of the row sweep: mantissa and binary exponent
   double Sr;                    // sum rho
   double Tx[CM];                // sum X_sc rho  (paths with a per-cell design row only)
   PPCX_HD void zero() { SA = SL = TL = TD = Sr = 0.0; Px = 1.0; Pxe = 0;
@@ -255,39 +254,31 @@ PPCX_HD double cell_eval(int y, double e, double A, const GeneParams<CM>& gp, co
 #endif
 }
 
-// One cell of the low-count list (0 <= y <= 7). Per lane: x = y + phi < 8 takes the exact recurrences
-//   lgamma(x) - lgamma(phi) = ln P, P = prod_{k<y}(phi+k);  psi(x) - psi(phi) = P'/P
-// with the same instruction stream as the Stirling form -- the logarithm's argument is 1/w instead of rho, the product
-// takes P^-2, and y (sigma_raw + 1) makes up for the terms the analytic cancellation assumed -- otherwise (phi > 8 - y)
-// the tails as in cell_eval, with the Stirling excess of phi subtracted here, per cell.
+// One cell of the low-count list (0 <= y <= 7). lgamma(y + phi) - lgamma(phi) = sum_{k<y} ln(phi + k) depends on the
+// count and on phi, not on the sample: the gene adds it once per value of k, weighted by the number of its list
+// cells with y > k (low_terms below). What is left per cell is the sample part,
+//   - (y + phi) ln w   and   rho = (1 + y/phi)/w :
+// one reciprocal, one logarithm (of 1/w), no product, no tails.
 template <int CM>
 PPCX_HD double cell_eval_low(int y, double e, double A, const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& a) {
   const double yd = (double)y;
   const double w = fma(e, A, 1.0);
-  const double xf = fma(yd, gp.invphi, 1.0);
-  const bool small = yd + gp.phi < 8.0;
-  double P = 1.0, dP = 0.0, f = gp.phi;   // P = prod_{k<y}(phi+k), dP = dP/dphi  (y = 0: P = 1, dP = 0)
-#pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    if (small && k < y) {
-      dP = fma(dP, f, P);
-      P = P * f;
-    }
-    f += 1.0;
-  }
-  const double arg = small ? P : xf;
-  const double q = fast_rcp(w * arg), rw = q * arg, ra = q * w;
-  const double rho = xf * rw;
-  const double l = table_log(small ? rw : rho, tab);
-  a.SA = fma(yd, small ? l + (gp.sigma_raw + 1.0) : l, a.SA);
+  const double q = fast_rcp(w);
+  const double l = table_log(q, tab);                    // - ln w
+  a.SA = fma(yd, l, a.SA);
   a.SL += l;
+  const double rho = fma(yd, gp.invphi, 1.0) * q;
   a.Sr += rho;
-  a.Px *= small ? ra * ra : xf;
-  double lgt, dgt;
-  stirling_tails(ra * gp.invphi, &lgt, &dgt);            // meaningful for the lanes with x >= 8 only
-  a.TL += small ? 0.0 : lgt - gp.dlt;
-  a.TD += small ? -dP * ra : dgt - gp.dps;
   return rho;
+}
+// The count part of the gene's list cells, term k = 0..6 (M = number of list cells with y > k):
+//   sum over the cells of [lgamma(y + phi) - lgamma(phi) + y sigma_raw + y] = sum_k M_k [ln(1 + k/phi) + 1]
+//   (sigma_raw = - ln phi; the "+ y" undoes the "- y" that gene_close subtracts for every cell, a Stirling term)
+//   sum over the cells of [psi(y + phi) - psi(phi)]                        = sum_k M_k (1/phi) / (1 + k/phi)
+PPCX_HD void low_terms(int k, double M, double invphi, const double* tab, double* lik, double* dph) {
+  const double z = fma((double)k, invphi, 1.0);
+  *lik = fma(M, table_log(z, tab) + 1.0, *lik);
+  *dph = fma(M * invphi, fast_rcp(z), *dph);
 }
 
 // What the log-likelihood kernel hands to the close kernel per gene (sums over the gene's non-excluded cells):
@@ -302,13 +293,13 @@ template <int CM> struct GeneSums { static constexpr int N = 3 + CM; };
 // that every cell of the row sweep owes (n_hi = their number in the whole gene) is added by ONE lane of the gene.
 template <int CM>
 PPCX_HD void cell_acc_close(const GeneParams<CM>& gp, CellAcc<CM>& a, const double* tab, double n_hi_if_first_lane,
-                            GeneSumsV<CM>* o) {
+                            double low_lik, double low_dph, GeneSumsV<CM>* o) {
   a.renorm();
   a.TL = fma(-n_hi_if_first_lane, gp.dlt, a.TL);
   a.TD = fma(-n_hi_if_first_lane, gp.dps, a.TD);
   const double lPx = fma((double)a.Pxe, 6.93147180559945286227e-01, table_log(a.Px, tab));
-  o->lik = (a.SA + gp.phi * a.SL) - 0.5 * lPx + a.TL;
-  o->dph = a.SL - a.TD;
+  o->lik = ((a.SA + gp.phi * a.SL) - 0.5 * lPx + a.TL) + low_lik;
+  o->dph = (a.SL - a.TD) + low_dph;
   o->Sr = a.Sr;
 #pragma unroll
   for (int c = 0; c < CM; ++c) o->Tx[c] = a.Tx[c];

@@ -3,7 +3,7 @@
 #   1. kernel trace + stats of the default bench command (one fit)
 #   2./3. PMC passes (FETCH_SIZE, WRITE_SIZE separately: TCC slots) on a shortened fit to bound the CSV size
 set -e
-R=${1:-r01}
+R=${1:-r02}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -15,14 +15,14 @@ static const double* log_table() { static double t[2 * kLogTabSize]; static bool
 struct EmulModel {
   Dims d; int CM;
   std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, SX, ncell, Lg1;
-  std::vector<unsigned> low; std::vector<int> low_start, nhi;
+  std::vector<unsigned> low; std::vector<int> low_start, nhi; std::vector<unsigned short> low_m;
 };
 
 static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, const double* X, const double* expo,
                             double lmm, int n_excl, const int32_t* excl) {
   EmulModel m; m.d = make_dims(G, S, C, K, lmm); m.CM = C <= 2 ? 2 : (C <= 4 ? 4 : 8);
   m.counts.assign(counts, counts + (size_t)G * S);
-  m.counts.resize((size_t)G * S + 64, 0);      // the cell loop requests the next cell before testing s < S
+  m.counts.resize((size_t)G * S + 64, 0);      // the row sweep requests counts up to two trips of 4 lanes past the end
   for (int e = 0; e < n_excl; ++e) m.counts[excl[e]] = -1;
   m.X.assign(X, X + (size_t)S * C); m.X.resize((size_t)S * C + 64, 0.0); m.expo.assign(expo, expo + S); m.E.assign(S + 64, 0.0);
   int x0 = 1;
@@ -32,10 +32,10 @@ static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, c
   for (int s = 0; s < S && x1b; ++s) if (X[(size_t)S + s] != 0.0 && X[(size_t)S + s] != 1.0) x1b = 0;
   m.d.x1_binary = x1b;
   m.Sy.assign(G, 0); m.SyE.assign(G, 0); m.SyX.assign((size_t)C * G, 0); m.SX.assign((size_t)C * G, 0); m.ncell.assign(G, 0); m.Lg1.assign(G, 0);
-  m.low_start.assign(G + 1, 0); m.nhi.assign(G, 0);
+  m.low_start.assign(G + 1, 0); m.nhi.assign(G, 0); m.low_m.assign((size_t)G * 8, 0);
   for (int g = 0; g < G; ++g) { m.low_start[g] = (int)m.low.size(); for (int s = 0; s < S; ++s) {
     int y = m.counts[(size_t)g * S + s]; if (y < 0) continue;
-    if (y < kLowCount) m.low.push_back(((unsigned)y << 16) | (unsigned)s); else m.nhi[g]++;
+    if (y < kLowCount) { m.low.push_back(((unsigned)y << 16) | (unsigned)s); for (int k = 0; k < y; ++k) m.low_m[(size_t)g * 8 + k]++; } else m.nhi[g]++;
     m.Sy[g] += y; m.SyE[g] += (double)y * expo[s]; m.ncell[g] += 1; m.Lg1[g] += lgamma((double)y + 1.0);
     for (int c = 0; c < C; ++c) { m.SyX[(size_t)c * G + g] += (double)y * X[(size_t)c * S + s]; m.SX[(size_t)c * G + g] += X[(size_t)c * S + s]; }
   } }
@@ -52,16 +52,12 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
   if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
   for (int g = 0; g < d.G; ++g) {
     // log-likelihood kernel (one lane per gene here)
-    GeneCtx<CM> x;
-    gene_load<CM, true>(d, c, v, g, x);
-    CellAcc<CM> acc; acc.zero();
-    gene_cells<CM>(d, x, m.counts.data() + (size_t)g * d.S, m.low.data() + m.low_start[g], m.low_start[g + 1] - m.low_start[g],
-                   m.E.data(), m.expo.data(), m.X.data(), log_table(), 0, 1, acc);
+    CellData cd; cd.counts = m.counts.data(); cd.low = m.low.data(); cd.low_start = m.low_start.data(); cd.n_hi = m.nhi.data(); cd.low_m = m.low_m.data();
     GeneSumsV<CM> o;
-    cell_acc_close<CM>(x.gp, acc, log_table(), (double)m.nhi[g], &o);
+    lane_gene_sums<CM, 1>(d, c, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), o);
     // close kernel
     GeneCtx<CM> x2;
-    gene_load<CM, false>(d, c, v, g, x2);
+    gene_load<CM>(d, c, v, g, x2);
     double pn[NCM], minv[NCM], part[10];
     gene_finish<CM>(d, c, v, x2, o, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.SX.data(), m.ncell.data(), m.Lg1.data(), part, pn, minv);
     for (int k = 0; k < 10; ++k) red[k] += part[k];

@@ -14,7 +14,7 @@ from oracle import independent as ind
 
 pytestmark = pytest.mark.gpu
 KW = dict(adj_prob_theshold=0.01, how_many_posterior_draws=1200, truncation_compensation=0.7352941, seed=31)
-LAUNCH = (8, 1)
+LAUNCH = (8, 0)
 
 
 def _free_port():

@@ -43,8 +43,8 @@ def test_log_prob_grad_matches_oracle(L, oracle, G, S, C, K, seed):
     mo = oracle.model(d["counts"], d["X"], d["exposure"], K, excl=excl)
     m = L.Model(d["counts"], d["X"], d["exposure"], K, excl=excl)
     try:
-        for lanes in [0, 1, 2, 8, 32, 64]:           # every lanes-per-gene instantiation reduces differently
-            m.set_launch(lanes, 0)
+        for lanes, wgs in [(0, 0), (1, 0), (2, 3), (8, 0), (32, 1), (64, 0)]:   # lanes per gene: different reductions; workgroups: schedules
+            m.set_launch(lanes, wgs)
             lp, g = m.log_prob_grad(u)
             for i in range(u.shape[0]):
                 lpo, go = oracle.log_prob_grad(mo, u[i])
@@ -659,27 +659,3 @@ def test_posterior_and_intervals_match_cpu_path_within_monte_carlo_error(L, orac
     for (gi, si) in d["injected"]:
         if flag_c[gi, si]:
             assert flag_g[gi, si]
-
-
-def test_two_segment_launch_gives_the_same_density(L, monkeypatch):
-    """cfg3 size, 8 points per launch: the launch geometry splits into a 4-lane and an 8-lane segment (choose_launch).
-    Same sums up to the order of additions: lp to 1e-12 relative, gradient to 1e-9."""
-    d = ind.synth(20000, 200, seed=20253)
-    K = d["K"]
-    rng = np.random.default_rng(3)
-    out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("PPCX_SPLIT", flag)
-        m = L.Model(d["counts"], d["X"], d["exposure"], K)
-        try:
-            if flag == "0":
-                u = rng.uniform(-0.3, 0.3, (8, m.D))
-                u[:, 3:20003] += d["truth"]["intercept"]
-                u[:, 3 + 20000 + K:3 + 20000 + K + 20000] += d["truth"]["sigma_raw"]
-            out[flag] = m.log_prob_grad(u) + (m.get_launch(),)
-        finally:
-            m.close()
-    (lp0, g0, l0), (lp1, g1, l1) = out["0"], out["1"]
-    assert l0 != l1, "the split geometry was not chosen: the test does not exercise it"
-    assert np.max(np.abs(lp0 - lp1) / np.abs(lp0)) < 1e-12
-    assert np.max(np.abs(g0 - g1) / (1 + np.abs(g0))) < 1e-9
