@@ -356,7 +356,12 @@ static int work_alloc(Work& w, ppcx_model* m, int nchains) {
   const int D = m->d.D;
   if (!w.stream) w.stream = m->stream;
   w.Dpad = ((long)D + 31) / 32 * 32;
-  w.nb_update = (D + 255) / 256; if (w.nb_update > 1024) w.nb_update = 1024; if (w.nb_update < 1) w.nb_update = 1;
+  // workgroups per chain of the step / update launches: every one of them repeats the step (reads the close kernel's
+  // partial sums), so not too many, each with several coordinates per thread. The number does not depend on the chains
+  // of the launch: it fixes the summation order of the kinetic energy, and a chain's results must not depend on its company.
+  w.nb_update = (D + 255) / 256;
+  if (w.nb_update > 80) w.nb_update = 80;
+  if (w.nb_update < 1) w.nb_update = 1;
   HIPCHK(hipMalloc(&w.vecs, sizeof(double) * (size_t)nchains * V_COUNT * w.Dpad));
   w.nb_close = (m->d.G + 255) / 256;
   HIPCHK(hipMalloc(&w.partials, sizeof(double) * (size_t)nchains * w.nb_close * PT_COUNT));
@@ -398,32 +403,37 @@ struct RunIO {                  // output buffers of a run (device pointers, may
 };
 
 // step kernel: reduce (+ optional) advance. After an ADVANCE launch the "current" buffers are the ones it wrote.
-static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int phases) {
+// The kinetic energy of freshly drawn momenta travels from the update of one round to the step of the next through the
+// T0 slab, double-buffered like the states: a step launched at generation g (= w.launches) reads buffer g & 1, the
+// update that belongs to the command it decides writes buffer (g + 1) & 1.
+// with_update: the per-coordinate work of the new command in the same launch (ppcx_kernels.hip, ppcx_step_kernel).
+static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int phases, bool with_update = false) {
   const int in = (int)(w.launches & 1), out = in ^ 1;
   StepArgs sa;
   sa.d = m->d; sa.phases = phases;
   sa.states_in = w.states[in]; sa.states_out = w.states[out];
   sa.cmds_in = w.cmds[in]; sa.cmds_out = w.cmds[out];
   sa.hyper_in = w.hyper_vecs[in]; sa.hyper_out = w.hyper_vecs[out];
-  sa.partials = w.partials; sa.nblocks_close = w.nb_close; sa.t0 = w.t0[0]; sa.nblocks_update = w.nb_update; sa.red = w.red;
+  sa.partials = w.partials; sa.nblocks_close = w.nb_close; sa.t0 = w.t0[in]; sa.nblocks_update = w.nb_update; sa.red = w.red;
   sa.draws = io.draws; sa.draws_chain_stride = io.draws_stride; sa.n_keep = io.n_keep; sa.iter = io.iter;
   sa.out_lp = io.lp; sa.out_stepsize = io.stepsize; sa.out_treedepth = io.treedepth; sa.out_n_leapfrog = io.nleap;
   sa.out_divergent = io.div; sa.out_accept = io.accept; sa.done = w.done;
-  hipError_t e = launch_step_kernel(sa, nchains, w.stream);
+  sa.upd_vecs = nullptr; sa.upd_Dpad = 0; sa.upd_t0_out = nullptr; sa.upd_logtab = nullptr;
+  if (with_update && (phases & STEP_ADVANCE)) { sa.upd_vecs = w.vecs; sa.upd_Dpad = w.Dpad; sa.upd_t0_out = w.t0[out]; sa.upd_logtab = m->d_logtab; }
+  hipError_t e = launch_step_kernel(sa, w.nb_update, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("step kernel: ") + hipGetErrorString(e));
   if (phases & STEP_ADVANCE) w.launches++;
   return PPCX_OK;
 }
+// the per-coordinate work of the current command in a launch of its own (after a step without with_update)
 static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
   UpdateArgs ua;
   ua.d = m->d; ua.cmds = w.cmds[w.launches & 1]; ua.vecs = w.vecs; ua.Dpad = w.Dpad;
-  ua.draws = io.draws; ua.draws_chain_stride = io.draws_stride; ua.t0_out = w.t0[0]; ua.logtab = m->d_logtab;
+  ua.draws = io.draws; ua.draws_chain_stride = io.draws_stride; ua.t0_out = w.t0[w.launches & 1]; ua.logtab = m->d_logtab;
   hipError_t e = launch_update_kernel(ua, w.nb_update, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("update kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
 }
-// `nchains` chains of the work area, of which the first w.n_active entries of w.active are still running (all of
-// them when w.active is not in use)
 static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
   const int nact = w.n_active > 0 ? w.n_active : nchains;
   ppcx_model::Plan pl;
@@ -541,7 +551,7 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       for (int k = 0; k < ns; ++k) {
         PUMP_TRY(launch_close(sh[k].m, *sh[k].w, nchains));
         if (smp && k == ns - 1) HIPCHK(hipEventRecord(ev2, st));
-        PUMP_TRY(launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, exchange ? STEP_REDUCE : (STEP_REDUCE | STEP_ADVANCE)));
+        PUMP_TRY(launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, exchange ? STEP_REDUCE : (STEP_REDUCE | STEP_ADVANCE), !exchange));
       }
       if (ns > 1) {
         ShardSumArgs sa; sa.n_shards = ns; sa.n = nchains * PT_COUNT;
@@ -554,8 +564,7 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
         if (e != 0) return fail(PPCX_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"));
       }
       for (int k = 0; k < ns; ++k) {
-        if (exchange) PUMP_TRY(launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_ADVANCE));
-        PUMP_TRY(launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io));
+        if (exchange) PUMP_TRY(launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_ADVANCE, true));   // step + coordinate update in one launch
       }
       if (smp) HIPCHK(hipEventRecord(ev3, st));
     }
@@ -655,7 +664,7 @@ extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, 
 // same work.
 extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs, int reps, int n_merge,
                                       double* ms_per_launch, int* cmd_type) {
-  const int which = n_merge >= 100 ? (n_merge / 100) : 0;      // 0 loglik, 1 close, 2 both, 3 step, 4 update, 5 step:reduce, 6 step:advance (development aid)
+  const int which = n_merge >= 100 ? (n_merge / 100) : 0;      // 0 loglik, 1 close, 2 both, 3 step, 4 update, 5 step:reduce, 6 step:advance, 7 step + update in one launch (development aid)
   if (n_merge >= 100) n_merge %= 100;
   if (!m || nchains < 1 || reps < 1 || !ms_per_launch) return fail(PPCX_ERR_ARG, "bad arguments");
   HIPCHK(hipSetDevice(m->device));
@@ -692,7 +701,7 @@ extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) if ((rc = (which == 1 ? launch_close(m, w, nchains) : (which == 2 ? launch_gene(m, w, nchains) : (which == 3 ? launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE) : (which == 4 ? launch_update(m, w, nchains, io) : (which == 5 ? launch_step(m, w, nchains, io, STEP_REDUCE) : (which == 6 ? launch_step(m, w, nchains, io, STEP_ADVANCE) : launch_loglik(m, w, nchains)))))))) != PPCX_OK) return rc;
+  for (int i = 0; i < reps; ++i) if ((rc = (which == 1 ? launch_close(m, w, nchains) : (which == 2 ? launch_gene(m, w, nchains) : (which == 3 ? launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE) : (which == 4 ? launch_update(m, w, nchains, io) : (which == 5 ? launch_step(m, w, nchains, io, STEP_REDUCE) : (which == 6 ? launch_step(m, w, nchains, io, STEP_ADVANCE) : (which == 7 ? launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE, true) : launch_loglik(m, w, nchains))))))))) != PPCX_OK) return rc;
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));

@@ -53,6 +53,9 @@ struct StepArgs {
   int n_keep, iter;
   double* out_lp; double* out_stepsize; int* out_treedepth; int* out_n_leapfrog; int* out_divergent; double* out_accept;
   int* done;                    // [chains]
+  // the per-coordinate work of the new command in the same launch (null upd_vecs: a separate ppcx_update_kernel does
+  // it): grid.x workgroups per chain, each runs the step redundantly and updates its share of the coordinates
+  double* upd_vecs; long upd_Dpad; double* upd_t0_out; const double* upd_logtab;
 };
 
 constexpr int kMaxShards = 16;
@@ -100,7 +103,7 @@ hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, hipStream_t st);
 int loglik_resident_workgroups_per_cu(int CM, int S, int C);   // 0: the kernel cannot be launched with this much LDS
 size_t loglik_lds_bytes(int S, int C);
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st);
-hipError_t launch_step_kernel(const StepArgs& a, int nchains, hipStream_t st);
+hipError_t launch_step_kernel(const StepArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st);
 hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_advi_kernel(const AdviArgs& a, int nblocks, hipStream_t st);

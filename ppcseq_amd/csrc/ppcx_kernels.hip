@@ -247,7 +247,10 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   __shared__ Reduced s_rd;
   constexpr int NST = (int)(sizeof(ChainState) / sizeof(int)), NCMD = (int)(sizeof(Cmd) / sizeof(int)), NHV = V_COUNT * 8;
   static_assert(NST <= 4 * 256 && NCMD <= 256 && NHV <= 3 * 256 && PT_COUNT <= 96, "step kernel staging sizes");
-  const int chain = blockIdx.x, tid = threadIdx.x;
+  __shared__ Cmd s_nc;
+  const int chain = blockIdx.y, tid = threadIdx.x;
+  const bool lead = blockIdx.x == 0;           // with a.upd_vecs the grid has several workgroups per chain: all of them run the
+                                               // step on the same inputs, the first one writes what the step leaves in memory
   const ChainState* st_in = a.states_in + chain;
   const bool done = st_in->sc.phase == PH_DONE;
   double* rg = a.red + (long)chain * PT_COUNT;
@@ -303,13 +306,14 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
       if (tid == 0) red[PT_T0] = sT0[0];
     }
     __syncthreads();
-    if (!(a.phases & STEP_ADVANCE)) { for (int i = tid; i < PT_COUNT; i += 256) rg[i] = red[i]; return; }
+    if (!(a.phases & STEP_ADVANCE)) { if (lead) for (int i = tid; i < PT_COUNT; i += 256) rg[i] = red[i]; return; }
   } else {
     for (int i = tid; i < PT_COUNT; i += 256) red[i] = rg[i];     // sums completed by the shard exchange
     __syncthreads();
   }
   // ---- phase STEP
   if (done) {                                  // finished chain: carry its final state across the double buffer
+    if (!lead) return;
     if (tid == 0) { a.states_out[chain] = *st_in; a.cmds_out[chain] = a.cmds_in[chain]; }
     const double* hi = a.hyper_in + (long)chain * V_COUNT * 8;
     double* ho = a.hyper_out + (long)chain * V_COUNT * 8;
@@ -330,27 +334,49 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   if (tid < 8) {
     ChainScalars st = s_st.sc;                 // scalars in registers; the run-time-indexed arrays stay in LDS
     ChainIO io;
-    io.draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
-    io.out.lp = a.out_lp ? a.out_lp + (long)chain * a.n_keep : nullptr;
-    io.out.stepsize = a.out_stepsize ? a.out_stepsize + (long)chain * a.iter : nullptr;
-    io.out.treedepth = a.out_treedepth ? a.out_treedepth + (long)chain * a.iter : nullptr;
-    io.out.n_leapfrog = a.out_n_leapfrog ? a.out_n_leapfrog + (long)chain * a.iter : nullptr;
-    io.out.divergent = a.out_divergent ? a.out_divergent + (long)chain * a.iter : nullptr;
-    io.out.accept = a.out_accept ? a.out_accept + (long)chain * a.iter : nullptr;
+    io.draws = (lead && a.draws) ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
+    io.out.lp = (lead && a.out_lp) ? a.out_lp + (long)chain * a.n_keep : nullptr;
+    io.out.stepsize = (lead && a.out_stepsize) ? a.out_stepsize + (long)chain * a.iter : nullptr;
+    io.out.treedepth = (lead && a.out_treedepth) ? a.out_treedepth + (long)chain * a.iter : nullptr;
+    io.out.n_leapfrog = (lead && a.out_n_leapfrog) ? a.out_n_leapfrog + (long)chain * a.iter : nullptr;
+    io.out.divergent = (lead && a.out_divergent) ? a.out_divergent + (long)chain * a.iter : nullptr;
+    io.out.accept = (lead && a.out_accept) ? a.out_accept + (long)chain * a.iter : nullptr;
     Cmd nc;
     chain_step(WaveLanes{tid}, a.d, st, s_st.ta, s_ex, red, have_parts, VecRef{hv, 8}, io, s_rd, nc);
     if (tid == 0) {
       s_st.sc = st;
-      *nc_out = nc;
-      if (st.phase == PH_DONE) a.done[chain] = 1 + st.error;
+      s_nc = nc;
+      if (lead) {
+        *nc_out = nc;
+        if (st.phase == PH_DONE) a.done[chain] = 1 + st.error;
+      }
     }
   }
   __syncthreads();
-  double* hvo = a.hyper_out + (long)chain * V_COUNT * 8;
-  for (int i = tid; i < V_COUNT * 8; i += 256) hvo[i] = hv[i];
-  const int* s2 = reinterpret_cast<const int*>(&s_st); int* d2 = reinterpret_cast<int*>(a.states_out + chain);
-  for (int i = tid; i < (int)(sizeof(ChainState) / sizeof(int)); i += 256) d2[i] = s2[i];
+  if (lead) {
+    double* hvo = a.hyper_out + (long)chain * V_COUNT * 8;
+    for (int i = tid; i < V_COUNT * 8; i += 256) hvo[i] = hv[i];
+    const int* s2 = reinterpret_cast<const int*>(&s_st); int* d2 = reinterpret_cast<int*>(a.states_out + chain);
+    for (int i = tid; i < (int)(sizeof(ChainState) / sizeof(int)); i += 256) d2[i] = s2[i];
+  }
+  if (!a.upd_vecs) return;
+  // ---- the per-coordinate work of the command just decided (what ppcx_update_kernel does after a separate step launch)
+  const Dims& d = a.d;
+  double T0 = 0.0;
+  if (s_nc.type != CMD_DONE) {
+    const VecRef v{a.upd_vecs + (long)chain * V_COUNT * a.upd_Dpad, a.upd_Dpad};
+    double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
+    for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, s_nc, v, i, draws, &T0, a.upd_logtab);
+  }
+  if ((s_nc.pre_flags & (PRE_NEW_TRANSITION | PRE_EPS_TRY)) == 0) return;
+  __syncthreads();                             // sT0 was used by the reduction above
+  sT0[tid] = T0;
+  __syncthreads();
+  for (int stp = 128; stp > 0; stp >>= 1) { if (tid < stp) sT0[tid] += sT0[tid + stp]; __syncthreads(); }
+  if (tid == 0) a.upd_t0_out[(long)chain * gridDim.x + blockIdx.x] = sT0[0];
 }
+
+
 
 // in-process gene shards: every shard ends with the sum over shards (fixed order => identical bits everywhere)
 __global__ void ppcx_sum_shards_kernel(ShardSumArgs a) {
@@ -655,8 +681,8 @@ hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int ncha
   else hipLaunchKernelGGL((ppcx_close_kernel<8>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
-hipError_t launch_step_kernel(const StepArgs& a, int nchains, hipStream_t st) {
-  hipLaunchKernelGGL(ppcx_step_kernel, dim3(nchains), dim3(256), 0, st, a);
+hipError_t launch_step_kernel(const StepArgs& a, int nblocks, int nchains, hipStream_t st) {
+  hipLaunchKernelGGL(ppcx_step_kernel, dim3(a.upd_vecs ? nblocks : 1, nchains), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st) {
