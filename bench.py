@@ -43,6 +43,8 @@ def main():
                          "genes partitioned over GPUs with an RCCL all-reduce of the partial sums every leapfrog (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--stream-group-steps", type=int, default=1,
+                    help="extra fits with PPCX_STREAM_GROUPS=3, reported beside the headline (0 = skip)")
     ap.add_argument("--as-named-steps", type=int, default=1,
                     help="fits of the configuration AS BASELINE cfg3 names it (1 chain per GPU), reported beside the headline "
                          "(0 = skip); outside the timed region of the headline")
@@ -155,6 +157,7 @@ def main():
         div_total += int(dg["divergent"][:, args.nuts_warmup:].sum())
         fit.close()
 
+    launch_used = model.get_launch()           # (lanes per gene, workgroups) of the timed fits' log-likelihood launches
     # BASELINE cfg3 as named: 8 chains, ONE per GPU (at N GPUs: N chains). A lone chain leaves the GPU mostly idle (a
     # leapfrog round costs the same for 1 chain as for 8), so this line scales strongly with nothing to gain from it; it is
     # reported for completeness, never as `value`.
@@ -178,6 +181,34 @@ def main():
             t_an += dt
         as_named = {"chains_per_gpu": 1, "chains_total": world, "value": round(ess_an / t_an, 3), "unit": "ESS/s",
                     "ms_per_step": round(1e3 * t_an / args.as_named_steps, 2), "steps": args.as_named_steps}
+
+    # The same fit with the chains in three groups on their own streams (PPCX_STREAM_GROUPS=3): one group's log-likelihood
+    # launch overlaps the other groups' latency-bound close / step kernels. Reported beside the headline, not as `value`:
+    # the headline keeps one in-order stream, on which the per-kernel timings of `roofline` are clean.
+    grouped = None
+    if args.mode == "chains" and args.stream_group_steps > 0 and nch >= 3:
+        os.environ["PPCX_STREAM_GROUPS"] = "3"
+        try:
+            t_g, ess_g = 0.0, 0.0
+            for k in range(args.stream_group_steps):
+                barrier()
+                t0 = time.perf_counter()
+                fg = one_fit(1 + k)
+                barrier()
+                dt = time.perf_counter() - t0
+                if dist_on:
+                    dt = D.max_over_ranks(dt, device=dev)
+                hypg, lpg = fg.columns(hyper_cols), fg.diagnostics()["lp"]
+                fg.close()
+                if dist_on:
+                    hypg = D.all_gather_chains(hypg, device=dev)
+                    lpg = D.all_gather_chains(lpg, device=dev)
+                ess_g += float(np.nanmin([ess_bulk(hypg[:, :, j]) for j in range(6)] + [ess_bulk(lpg)]))
+                t_g += dt
+            grouped = {"stream_groups": 3, "chains_total": nch * world, "value": round(ess_g / t_g, 3), "unit": "ESS/s",
+                       "ms_per_step": round(1e3 * t_g / args.stream_group_steps, 2), "steps": args.stream_group_steps}
+        finally:
+            del os.environ["PPCX_STREAM_GROUPS"]
 
     if rank == 0:
         E = 0
@@ -212,7 +243,7 @@ def main():
                                    (f"BASELINE cfg4 style: synthetic {G} genes x {S} samples (seed {seed_data}), C=2, K={K}, genes "
                                     f"sharded over {world} GPU(s) with an RCCL all-reduce of the partial sums per leapfrog; NUTS "
                                     f"(Stan defaults) warm-up {args.nuts_warmup} + {args.draws_per_chain} kept draws/chain, {nch} chains"),
-                       "mode": args.mode, "chains_total": nch * world if args.mode == "chains" else nch, "lanes_per_gene": model.get_launch()[0], "loglik_workgroups": model.get_launch()[1],
+                       "mode": args.mode, "chains_total": nch * world if args.mode == "chains" else nch, "lanes_per_gene": launch_used[0], "loglik_workgroups": launch_used[1],
                        "ess_estimator": "rank-normalised split-chain bulk-ESS, min over 6 hyper-parameters and lp__",
                        "ess_last_step": [round(float(x), 1) for x in ess_detail],
                        "ess_median_intercept_sigma_raw_rank0_chains": round(ess_gene_median, 1),
@@ -220,7 +251,7 @@ def main():
                        "divergent_after_warmup": div_total,
                        "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
                        "us_per_grad_eval_per_chain": round(1e6 * tot_time * world * nch / max(tot_grad, 1), 2)},
-            "roofline": roof, "cpu_baseline": cpu, "as_named_cfg3_one_chain_per_gpu": as_named,
+            "roofline": roof, "cpu_baseline": cpu, "as_named_cfg3_one_chain_per_gpu": as_named, "chain_groups_on_streams": grouped,
             "concordance": None if (args.no_cpu_baseline or world > 1) else outlier_concordance(),
         }
         print(json.dumps(out))

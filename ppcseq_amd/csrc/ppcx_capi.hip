@@ -110,8 +110,7 @@ static void choose_launch(ppcx_model* m, int nchains) {
   for (int L = 1; L <= 64; L <<= 1) {
     const int gpw = 64 / L;
     const int wpc = 4 * workgroups_per_chain(m, L, nchains, resident_workgroups(m, 1));
-    const double npass = ceil((double)G / gpw) / wpc, pass = 5.8 + (double)((S + L - 1) / L);
-    const double t = (npass < 1.0 ? 1.0 : npass + 0.5) * pass;   // + 0.5: ranges are whole passes, some wavefronts get one more
+    const double t = ceil(ceil((double)G / gpw) / wpc) * (5.8 + (double)((S + L - 1) / L));   // passes of the busiest wavefront x pass cost
     if (t < best) { best = t; bestL = L; }
   }
   const int L = m->L_override > 0 ? m->L_override : bestL;
@@ -154,6 +153,15 @@ static int plan_launch(ppcx_model* m, int nch, int share, ppcx_model::Plan* out)
       while (k < npass && cum + 0.5 * cost[k] < target) cum += cost[k++];
       bounds[j] = k * gpw < G ? k * gpw : G;
     }
+  }
+  // no wavefront gets more than its share of passes rounded up: the four wavefronts of a SIMD take turns on its fp64
+  // unit, so the launch lasts as long as the SIMD with the most passes (measured: the 8 SIMDs whose wavefronts all had
+  // one pass more than the rest finished 8 us after the others, profiles/r02_wave_trace.txt)
+  {
+    const long pmax = ((long)(npass + wpc - 1) / wpc) * gpw;
+    for (int j = 0; j < wpc; ++j) if (bounds[j + 1] - bounds[j] > pmax) bounds[j + 1] = (int)(bounds[j] + pmax);
+    bounds[wpc] = G;
+    for (int j = wpc - 1; j >= 0; --j) if (bounds[j + 1] - bounds[j] > pmax) bounds[j] = (int)(bounds[j + 1] - pmax);
   }
   ppcx_model::Plan pl; pl.nbpc = nbpc;
   HIPCHK(hipMalloc(&pl.d_bounds, sizeof(int) * (size_t)(wpc + 1)));
@@ -755,8 +763,10 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   FHIP(hipMemsetAsync(f->d_div, 0, sizeof(int) * (size_t)nch * iter, m->stream));
   FHIP(hipStreamSynchronize(m->stream));
   // Chains can be split into groups that run on their own streams from their own host threads
-  // (PPCX_STREAM_GROUPS=n): while one group sits in its latency-bound close/update kernels the other group's
-  // log-likelihood kernel has the CUs. Default 1: a single in-order stream keeps per-kernel timings clean.
+  // (PPCX_STREAM_GROUPS=n): while one group sits in its latency-bound close / step kernels another group's
+  // log-likelihood kernel has the CUs. Measured on cfg3, 8 chains: 4.1 s per fit with one stream, 3.8 s with two groups,
+  // 3.6 s with three (each launch planned for the whole chip), 5.2 s with four (more streams than hardware queues).
+  // Default 1: a single in-order stream keeps the per-kernel timings of the bench clean.
   int ngrp = 1;
   if (const char* e = getenv("PPCX_STREAM_GROUPS")) { int v = atoi(e); if (v >= 1) ngrp = v < nch ? v : nch; }
   struct Group { int c0 = 0, n = 0; Work w; RunIO io; PumpStats ps; int rc = PPCX_OK; std::string err; long long leap = 0; };
@@ -766,7 +776,6 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
     Group& G = grp[g];
     G.c0 = (int)((long long)nch * g / ngrp); G.n = (int)((long long)nch * (g + 1) / ngrp) - G.c0;
     if (g > 0) { FHIP(hipStreamCreateWithFlags(&G.w.stream, hipStreamNonBlocking)); G.w.own_stream = true; }
-    G.w.share = ngrp;
     int rc = work_alloc(G.w, m, G.n);
     if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }
     std::vector<ChainState> states(G.n);
