@@ -57,11 +57,14 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
     if (p + GPW < p1) g_next = a.order[pn < p1 ? pn : p1 - 1];
     GeneSumsV<CM> o;
     lane_gene_sums<CM, L>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, o);
+    // sum X_sc rho is needed of genes with slopes only (and of every gene when X[,1] != 1): a pass without such genes
+    // neither reduces nor stores it (the close kernel does not use those entries of a plain gene)
+    const bool with_tx = any_generic && (!d.x0_is_one || PPCX_WAVE_ANY(g < d.K));
     // L-lane butterfly: every lane of the gene ends with the gene totals
 #pragma unroll
     for (int msk = 1; msk < L; msk <<= 1) {
       o.lik = wave_xor_add_rt(o.lik, msk); o.dph = wave_xor_add_rt(o.dph, msk); o.Sr = wave_xor_add_rt(o.Sr, msk);
-      if (any_generic) {
+      if (with_tx) {
 #pragma unroll
         for (int cc = 0; cc < CM; ++cc) if (cc < d.C) o.Tx[cc] = wave_xor_add_rt(o.Tx[cc], msk);
       }
@@ -69,7 +72,7 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
     if (act && sub == 0) {
       const long G = d.G;
       sums[0 * G + g] = o.lik; sums[1 * G + g] = o.dph; sums[2 * G + g] = o.Sr;
-      if (any_generic) {
+      if (with_tx) {
 #pragma unroll
         for (int cc = 0; cc < CM; ++cc) if (cc < d.C) sums[(3 + cc) * G + g] = o.Tx[cc];
       }
@@ -248,6 +251,7 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   constexpr int NST = (int)(sizeof(ChainState) / sizeof(int)), NCMD = (int)(sizeof(Cmd) / sizeof(int)), NHV = V_COUNT * 8;
   static_assert(NST <= 4 * 256 && NCMD <= 256 && NHV <= 3 * 256 && PT_COUNT <= 96, "step kernel staging sizes");
   __shared__ Cmd s_nc;
+  __shared__ double s_tab[2 * kLogTabSize];    // log table for coord_consts (with a.upd_vecs)
   const int chain = blockIdx.y, tid = threadIdx.x;
   const bool lead = blockIdx.x == 0;           // with a.upd_vecs the grid has several workgroups per chain: all of them run the
                                                // step on the same inputs, the first one writes what the step leaves in memory
@@ -266,6 +270,9 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) r_hv[k] = tid + 256 * k < NHV ? hvg[tid + 256 * k] : 0.0;
   }
+  double r_tab[2] = {0.0, 0.0};                // the table's round trip overlaps the reduction too
+  if (a.upd_vecs) { r_tab[0] = a.upd_logtab[tid]; r_tab[1] = a.upd_logtab[tid + 256]; }
+  static_assert(2 * kLogTabSize == 512, "two table entries per thread");
   if (a.phases & STEP_REDUCE) {
     const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
     // one pass: thread (c, ch) sums rows ch, ch+8, ... of columns c, c+32, c+64, loads of several rows in flight; then
@@ -327,6 +334,7 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
     if (tid < NCMD) reinterpret_cast<int*>(&s_ex)[tid] = r_cmd;
 #pragma unroll
     for (int k = 0; k < 3; ++k) if (tid + 256 * k < NHV) hv[tid + 256 * k] = r_hv[k];
+    s_tab[tid] = r_tab[0]; s_tab[tid + 256] = r_tab[1];
   }
   __syncthreads();
   const bool have_parts = s_st.sc.phase != PH_START;
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   if (s_nc.type != CMD_DONE) {
     const VecRef v{a.upd_vecs + (long)chain * V_COUNT * a.upd_Dpad, a.upd_Dpad};
     double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
-    for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, s_nc, v, i, draws, &T0, a.upd_logtab);
+    for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, s_nc, v, i, draws, &T0, s_tab);
   }
   if ((s_nc.pre_flags & (PRE_NEW_TRANSITION | PRE_EPS_TRY)) == 0) return;
   __syncthreads();                             // sT0 was used by the reduction above
