@@ -289,6 +289,9 @@ struct SerialLanes {
 template <class Lanes>
 PPCX_HD void chain_step(const Lanes& ln, const Dims& d, ChainScalars& st, TreeArrays& ta, const Cmd& ex,
                         const double* red, bool have_parts, const VecRef& hv, const ChainIO& io, Reduced& rd, Cmd& nc) {
+  // a lane's own coordinates sit in small per-lane arrays; with one coordinate per lane (the device) the slot is the
+  // constant 0, so that the arrays stay in registers instead of becoming run-time-indexed stack objects
+#define PPCX_SLOT(k, kb_) (Lanes::kPerLane == 1 ? 0 : (k) - (kb_))
   double lp = 0.0; bool finite = true;
   if (have_parts && ex.type != CMD_FLUSH) {
     double g6[6], hs[6];
@@ -304,7 +307,7 @@ PPCX_HD void chain_step(const Lanes& ln, const Dims& d, ChainScalars& st, TreeAr
       hv.at(V_P0 + 3 * ex.dir, k) = pn; hv.at(V_G0 + 3 * ex.dir, k) = g6[k];
       T1h += pn * pn * minv;
       bad += isfinite(g6[k]) ? 0.0 : 1.0;
-      pn_k[k - kb] = pn; mv_k[k - kb] = minv;
+      pn_k[PPCX_SLOT(k, kb)] = pn; mv_k[PPCX_SLOT(k, kb)] = minv;
     }
     T1h = ln.sum(T1h); bad = ln.sum(bad);
     finite = red[PT_NONFINITE] == 0.0 && bad == 0.0;
@@ -315,17 +318,17 @@ PPCX_HD void chain_step(const Lanes& ln, const Dims& d, ChainScalars& st, TreeAr
     }
     if (ex.type == CMD_LEAF) {                 // tree terms of the hyper coordinates, level by level
       NodeVals nv[NK];
-      for (int k = ln.k_begin(); k < ln.k_end(); ++k) nv[k - kb] = NodeVals{pn_k[k - kb], pn_k[k - kb]};
+      for (int k = ln.k_begin(); k < ln.k_end(); ++k) nv[PPCX_SLOT(k, kb)] = NodeVals{pn_k[PPCX_SLOT(k, kb)], pn_k[PPCX_SLOT(k, kb)]};
       for (int l = 0; l < ex.n_merge; ++l) {
         double dots[6] = {0, 0, 0, 0, 0, 0};
-        for (int k = ln.k_begin(); k < ln.k_end(); ++k) coord_merge_dots(hv, k, l, pn_k[k - kb], mv_k[k - kb], &nv[k - kb], dots);
+        for (int k = ln.k_begin(); k < ln.k_end(); ++k) coord_merge_dots(hv, k, l, pn_k[PPCX_SLOT(k, kb)], mv_k[PPCX_SLOT(k, kb)], &nv[PPCX_SLOT(k, kb)], dots);
         for (int j = 0; j < 6; ++j) { const double t = ln.sum(dots[j]); if (ln.leader()) rd.dots[l][j] = red[PT_DOTS + 6 * l + j] + t; }
       }
       if (!ex.subtree_complete) {
-        for (int k = ln.k_begin(); k < ln.k_end(); ++k) coord_store_slot(hv, k, ex.n_merge, pn_k[k - kb], nv[k - kb]);
+        for (int k = ln.k_begin(); k < ln.k_end(); ++k) coord_store_slot(hv, k, ex.n_merge, pn_k[PPCX_SLOT(k, kb)], nv[PPCX_SLOT(k, kb)]);
       } else {
         double top[6] = {0, 0, 0, 0, 0, 0};
-        for (int k = ln.k_begin(); k < ln.k_end(); ++k) coord_top_dots(hv, k, ex.dir, pn_k[k - kb], mv_k[k - kb], nv[k - kb], top);
+        for (int k = ln.k_begin(); k < ln.k_end(); ++k) coord_top_dots(hv, k, ex.dir, pn_k[PPCX_SLOT(k, kb)], mv_k[PPCX_SLOT(k, kb)], nv[PPCX_SLOT(k, kb)], top);
         for (int j = 0; j < 6; ++j) { const double t = ln.sum(top[j]); if (ln.leader()) rd.top[j] = red[PT_TOP + j] + t; }
       }
     }
@@ -342,11 +345,11 @@ PPCX_HD void chain_step(const Lanes& ln, const Dims& d, ChainScalars& st, TreeAr
     for (int k = ln.k_begin(); k < ln.k_end(); ++k) {
       const int hcol = hyper_index(d, k);
       const CoordVals cv = coord_pre(nc, hv, k, hcol, global_flat(d, hcol), true, io.draws, d.D, st.k0, st.k1, &T0h);
-      hq[k - kb2] = cv.q;
+      hq[PPCX_SLOT(k, kb2)] = cv.q;
       if (nc.type != CMD_FLUSH) {
         const double ph = cv.p + 0.5 * nc.eps * cv.g;
-        hq[k - kb2] = cv.q + nc.eps * cv.minv * ph;
-        hv.at(V_Q0 + 3 * nc.dir, k) = hq[k - kb2]; hv.at(V_P0 + 3 * nc.dir, k) = ph;
+        hq[PPCX_SLOT(k, kb2)] = cv.q + nc.eps * cv.minv * ph;
+        hv.at(V_Q0 + 3 * nc.dir, k) = hq[PPCX_SLOT(k, kb2)]; hv.at(V_P0 + 3 * nc.dir, k) = ph;
       }
     }
     st.T0h = ln.sum(T0h);
@@ -357,5 +360,6 @@ PPCX_HD void chain_step(const Lanes& ln, const Dims& d, ChainScalars& st, TreeAr
     nc.hy = make_hyper(nc.hyp_q, d.lambda_mu_mu);
   }
 }
+#undef PPCX_SLOT
 
 }  // namespace ppcx

@@ -251,7 +251,9 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   constexpr int NST = (int)(sizeof(ChainState) / sizeof(int)), NCMD = (int)(sizeof(Cmd) / sizeof(int)), NHV = V_COUNT * 8;
   static_assert(NST <= 4 * 256 && NCMD <= 256 && NHV <= 3 * 256 && PT_COUNT <= 96, "step kernel staging sizes");
   __shared__ Cmd s_nc;
-  __shared__ double s_tab[2 * kLogTabSize];    // log table for coord_consts (with a.upd_vecs)
+  double* s_tab = &sm[0][0][0];                // log table for coord_consts (with a.upd_vecs): takes the reduction's scratch once that is
+                                               // done -- three workgroups of this kernel fit a CU only below 21 KB of LDS each
+  static_assert(3 * 8 * 32 >= 2 * kLogTabSize, "the table fits the reduction's scratch");
   const int chain = blockIdx.y, tid = threadIdx.x;
   const bool lead = blockIdx.x == 0;           // with a.upd_vecs the grid has several workgroups per chain: all of them run the
                                                // step on the same inputs, the first one writes what the step leaves in memory
