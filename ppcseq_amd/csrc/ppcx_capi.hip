@@ -257,8 +257,6 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     m->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    m->wgs_per_cu = loglik_resident_workgroups_per_cu(m->CM, S, C);
-    if (m->wgs_per_cu < 1) { delete m; return fail(PPCX_ERR_LIMIT, "the log-likelihood kernel cannot be resident with S * (2 + C) doubles of per-sample constants in LDS"); }
   }
   m->counts_host.assign(counts, counts + (size_t)G * S);
   m->X_host.assign(X, X + (size_t)S * C);
@@ -270,6 +268,8 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   for (int s = 0; s < S && x1b; ++s) if (X[(size_t)S + s] != 0.0 && X[(size_t)S + s] != 1.0) x1b = 0;
   if (const char* e = getenv("PPCX_TWO_GROUP")) if (atoi(e) == 0) x1b = 0;     // development aid: force the generic cell path
   m->d.x1_binary = x1b;
+  m->wgs_per_cu = loglik_resident_workgroups_per_cu(m->CM, m->d);      // of the instantiation this model runs
+  if (m->wgs_per_cu < 1) { delete m; return fail(PPCX_ERR_LIMIT, "the log-likelihood kernel cannot be resident with S * (2 + C) doubles of per-sample constants in LDS"); }
   std::vector<double> E(S);
   for (int s = 0; s < S; ++s) E[s] = exp(exposure[s]);
 #define MCHK(expr) do { int rc_ = (expr); if (rc_ != PPCX_OK) { ppcx_model_destroy(m); return rc_; } } while (0)

@@ -169,7 +169,9 @@ PPCX_HD void generic_cells(const Dims& d, const Cmd& c, const VecRef& v, int g, 
 }
 
 // one lane's share of gene g: the hand-over sums before the L-lane reduction
-template <int CM, int L>
+// GEN = false: a model in which every gene factorises (X[,1] == 1 and slopes only in a two-group design) -- the
+// per-cell-eta path is not compiled in, which leaves the registers to the sweep
+template <int CM, int L, bool GEN = true>
 PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const CellData& m, int g, int sub,
                             const double* sE, const double* sExpo, const double* sX, const double* tab,
                             GeneSumsV<CM>& o) {
@@ -177,7 +179,7 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   const int i_sr = d.off_sigma_raw + g;
   const bool has_slopes = g < d.K && d.C >= 2;
   const bool two = has_slopes && d.x0_is_one && d.x1_binary;
-  const bool generic = !d.x0_is_one || (has_slopes && !two);
+  const bool generic = GEN && (!d.x0_is_one || (has_slopes && !two));
   GeneParams<CM> gp;
   gp.phi = v.at(V_C0, i_sr); gp.invphi = v.at(V_C1, i_sr); gp.dlt = v.at(V_C2, i_sr); gp.dps = v.at(V_C3, i_sr);
   const double A = v.at(V_C0, d.off_intercept + g) * gp.invphi;       // exp(intercept + sigma_raw)
@@ -185,10 +187,12 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   const double nhi = sub == 0 ? (double)m.n_hi[g] : 0.0;
   const int* row = m.counts + (long)g * S;
   CellAcc<CM> acc; acc.zero();
-  if (PPCX_WAVE_ANY(generic)) {
-    if (generic) generic_cells<CM, L>(d, c, v, g, has_slopes, row, sExpo, sX, sub, gp, tab, acc);
+  if (GEN) {
+    if (PPCX_WAVE_ANY(generic)) {
+      if (generic) generic_cells<CM, L>(d, c, v, g, has_slopes, row, sExpo, sX, sub, gp, tab, acc);
+    }
   }
-  if (PPCX_WAVE_ANY(!generic)) {
+  if (!GEN || PPCX_WAVE_ANY(!generic)) {
     if (!generic) {
       if (PPCX_WAVE_ANY(two)) {                            // e^t = E_s A or E_s A1 by the sample's group (X[,2] is 0 or 1)
         const double A1 = two ? A * v.at(V_C0, coef_index(d, 1, g)) : A;

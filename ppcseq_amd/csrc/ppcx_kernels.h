@@ -100,7 +100,7 @@ struct PpcArgs {
 };
 
 hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, hipStream_t st);
-int loglik_resident_workgroups_per_cu(int CM, int S, int C);   // 0: the kernel cannot be launched with this much LDS
+int loglik_resident_workgroups_per_cu(int CM, const Dims& d);   // 0: the kernel cannot be launched with this much LDS
 size_t loglik_lds_bytes(int S, int C);
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_step_kernel(const StepArgs& a, int nblocks, int nchains, hipStream_t st);

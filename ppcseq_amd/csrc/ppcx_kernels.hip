@@ -31,6 +31,9 @@ namespace ppcx {
 #ifndef PPCX_LOGLIK_OCC
 #define PPCX_LOGLIK_OCC 4
 #endif
+#ifndef PPCX_LOGLIK_OCC_FAST
+#define PPCX_LOGLIK_OCC_FAST 4                   // wavefronts per SIMD of the instantiation without the per-cell-eta path
+#endif
 __device__ __forceinline__ double wave_xor_add_rt(double v, int lane_xor_mask) {      // run-time mask: ds_bpermute
   const int src = (int)((threadIdx.x ^ (unsigned)lane_xor_mask) & 63u) << 2;
   const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
@@ -42,7 +45,7 @@ __device__ __forceinline__ double wave_xor_add_rt(double v, int lane_xor_mask) {
 // chosen on the host so that all ranges cost the same, and walks it 64 / L genes at a time. All wavefronts start
 // together and finish together: no partly filled last round of workgroups, one LDS fill per resident workgroup.
 // Wavefronts are independent after the LDS fill (no barrier, no atomic), and a gene's sums depend on L only.
-template <int CM, int LG>
+template <int CM, int LG, bool GEN>
 __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c, const VecRef& v, double* sums, int p0, int p1,
                                               const double* stab, const double* sE, const double* sExpo, const double* sX,
                                               int lane, bool any_generic) {
@@ -56,7 +59,7 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
     const int pn = p + GPW + gl;
     if (p + GPW < p1) g_next = a.order[pn < p1 ? pn : p1 - 1];
     GeneSumsV<CM> o;
-    lane_gene_sums<CM, L>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, o);
+    lane_gene_sums<CM, L, GEN>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, o);
     // sum X_sc rho is needed of genes with slopes only (and of every gene when X[,1] != 1): a pass without such genes
     // neither reduces nor stores it (the close kernel does not use those entries of a plain gene)
     const bool with_tx = any_generic && (!d.x0_is_one || PPCX_WAVE_ANY(g < d.K));
@@ -80,8 +83,8 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
   }
 }
 
-template <int CM>
-__global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(LoglikArgs a) {
+template <int CM, bool GEN>
+__global__ __launch_bounds__(256, GEN ? PPCX_LOGLIK_OCC : PPCX_LOGLIK_OCC_FAST) void ppcx_loglik_kernel(LoglikArgs a) {
   extern __shared__ double lds[];
   // workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids chain * 8 + (jb & 7) inside every run of
   // 8 range blocks x chains put the chains of one range block on ONE XCD, so its L2 fetches the rows once
@@ -114,13 +117,13 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC) void ppcx_loglik_kernel(Logli
   __syncthreads();
   if (p0 >= p1) return;
   switch (a.lgL) {
-    case 0: loglik_passes<CM, 0>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    case 1: loglik_passes<CM, 1>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    case 2: loglik_passes<CM, 2>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    case 3: loglik_passes<CM, 3>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    case 4: loglik_passes<CM, 4>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    case 5: loglik_passes<CM, 5>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    default: loglik_passes<CM, 6>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 0: loglik_passes<CM, 0, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 1: loglik_passes<CM, 1, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 2: loglik_passes<CM, 2, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 3: loglik_passes<CM, 3, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 4: loglik_passes<CM, 4, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 5: loglik_passes<CM, 5, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    default: loglik_passes<CM, 6, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
   }
 }
 
@@ -660,29 +663,34 @@ __global__ void ppcx_fill_kernel(double* p, long n, double val) {
 // launch helpers (host)
 // -----------------------------------------------------------------------------------------------------
 size_t loglik_lds_bytes(int S, int C) { return sizeof(double) * (2 * kLogTabSize + (size_t)S * (2 + C) + 2 * kLdsPad); }
-int loglik_resident_workgroups_per_cu(int CM, int S, int C) {
+// the instantiation a model runs: CM design columns (2, 4 or 8) and whether any gene can need the per-cell-eta path
+static const void* loglik_kernel_ptr(int CM, bool gen) {
+  if (CM <= 2) return gen ? (const void*)ppcx_loglik_kernel<2, true> : (const void*)ppcx_loglik_kernel<2, false>;
+  if (CM <= 4) return gen ? (const void*)ppcx_loglik_kernel<4, true> : (const void*)ppcx_loglik_kernel<4, false>;
+  return gen ? (const void*)ppcx_loglik_kernel<8, true> : (const void*)ppcx_loglik_kernel<8, false>;
+}
+static bool loglik_generic_possible(const Dims& d) { return !d.x0_is_one || (d.C >= 2 && d.K > 0 && !d.x1_binary); }
+int loglik_resident_workgroups_per_cu(int CM, const Dims& d) {
   int n = 0;
-  const size_t lds_bytes = loglik_lds_bytes(S, C);
-  hipError_t e = hipSuccess;
+  const size_t lds_bytes = loglik_lds_bytes(d.S, d.C);
+  const bool gen = loglik_generic_possible(d);
+  const void* f = loglik_kernel_ptr(CM, gen);
   if (lds_bytes > 64u * 1024u) {               // more than the default limit of dynamic LDS: ask for it once
-    if (CM <= 2) e = hipFuncSetAttribute((const void*)ppcx_loglik_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    else if (CM <= 4) e = hipFuncSetAttribute((const void*)ppcx_loglik_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    else e = hipFuncSetAttribute((const void*)ppcx_loglik_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
   }
-  if (CM <= 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<2>, 256, lds_bytes);
-  else if (CM <= 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<4>, 256, lds_bytes);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<8>, 256, lds_bytes);
+  hipError_t e;
+  if (CM <= 2) e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<2, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<2, false>, 256, lds_bytes);
+  else if (CM <= 4) e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<4, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<4, false>, 256, lds_bytes);
+  else e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<8, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<8, false>, 256, lds_bytes);
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
 }
 hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, hipStream_t st) {
   const size_t lds_bytes = loglik_lds_bytes(a.d.S, a.d.C);
   const dim3 grid((unsigned)((a.nbpc + 7) / 8 * 8) * (unsigned)a.nchains);
-  if (CM <= 2) hipLaunchKernelGGL((ppcx_loglik_kernel<2>), grid, dim3(256), lds_bytes, st, a);
-  else if (CM <= 4) hipLaunchKernelGGL((ppcx_loglik_kernel<4>), grid, dim3(256), lds_bytes, st, a);
-  else hipLaunchKernelGGL((ppcx_loglik_kernel<8>), grid, dim3(256), lds_bytes, st, a);
-  return hipGetLastError();
+  LoglikArgs args = a;
+  void* params[] = {&args};
+  return hipLaunchKernel(loglik_kernel_ptr(CM, loglik_generic_possible(a.d)), grid, dim3(256), params, lds_bytes, st);
 }
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st) {
   const dim3 grid(nblocks, nchains);
