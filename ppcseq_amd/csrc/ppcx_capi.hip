@@ -45,7 +45,7 @@ struct ppcx_model {
   std::vector<double> X_host, expo_host;
   int* d_counts = nullptr;
   double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_SX = nullptr, *d_ncell = nullptr, *d_Lg1 = nullptr;
-  unsigned* d_low = nullptr; size_t low_cap = 0;   // low-count cell list (ppcx_gene.h gene_cells) and its capacity
+  unsigned* d_low = nullptr; size_t low_cap = 0;   // low-count cell list (ppcx_gene.h low_cells) and its capacity
   int *d_low_start = nullptr, *d_nhi = nullptr;
   unsigned short* d_low_m = nullptr;           // [G][8] entry k < 7: number of list cells with count > k
   double* d_logtab = nullptr;
@@ -205,7 +205,7 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
   HIPCHK(hipMemcpy(m->d_nhi, nhi.data(), sizeof(int) * (size_t)G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_low_m, low_m.data(), sizeof(unsigned short) * low_m.size(), hipMemcpyHostToDevice));
   // gene_order: a wavefront holds several genes, runs the plain and the slope cell paths one after the other when it
-  // holds genes of both kinds, and stays in the low-count loop (ppcx_gene.h gene_cells) for as long as its gene with the
+  // holds genes of both kinds, and stays in the low-count loop (ppcx_gene.h low_cells) for as long as its gene with the
   // longest list needs. So neighbours in the launch should be alike: genes with slopes first, then by the length of
   // their low-count list, longest first -- the expensive wavefronts start first, the cheap ones fill the tail.
   {

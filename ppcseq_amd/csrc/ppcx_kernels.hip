@@ -1,22 +1,23 @@
 // ppcx_kernels.hip -- gfx950 kernels of the NB hierarchical NUTS / posterior-predictive engine.
 //
-//   ppcx_loglik_kernel<L,CM> "kernel A1": streams the int32 count matrix once per gradient evaluation and reduces
-//                           it to a handful of sums per gene. Replaces lp_reduce + map_rect + X*alpha of
+//   ppcx_loglik_kernel<CM,GEN>  streams the int32 count matrix once per gradient evaluation and reduces it to a handful
+//                           of sums per gene. Replaces lp_reduce + map_rect + X*alpha of
 //                           inst/stan/negBinomial_MPI.stan:58-120,:205,:226-240.
-//   ppcx_close_kernel<CM>   "kernel A2": per gene: priors (.stan:219-223), gradient, second half kick of the
-//                           leapfrog, NUTS tree bookkeeping of the gene's coordinates, block partial sums.
-//   ppcx_update_kernel      "kernel B": reduction of A's block partials, hyper-parameters, NUTS/adaptation
-//                           state machine (ppcx_nuts.h) and the per-coordinate updates of the next command.
+//   ppcx_close_kernel<CM>   per gene: priors (.stan:219-223), gradient, second half kick of the leapfrog, NUTS tree
+//                           bookkeeping of the gene's coordinates, block partial sums.
+//   ppcx_step_kernel        reduction of the close kernel's block partials, hyper-parameters, NUTS / adaptation state
+//                           machine (ppcx_nuts.h) and, in the same launch, the per-coordinate work of the next command.
+//   ppcx_update_kernel      that per-coordinate work as a launch of its own (initialisation, ADVI).
 //   ppcx_ppc_kernel         generated quantities (.stan:259-266) + credible-interval summary
 //                           (R/utilities.R:685-703 / :733-784): NB draws straight into LDS, order
 //                           statistics by bisection on the value, type-7 quantiles, mean, sd.
 //   ppcx_gather_kernel      column gather of the retained draws.
 //
-// Work decomposition of kernel A1 (DESIGN.md "lp/grad kernel"): a gene is owned by L lanes of one
-// wavefront (L in {1,2,4,...,64}, chosen per problem so that ceil(S/L)*L wastes few lanes and the
-// launch fills 1024 SIMDs evenly); lanes stride over that gene's samples, read the per-sample
-// constants from LDS, and combine with an L-lane xor-shuffle butterfly. Per-block partial sums go to a
-// slab that kernel B reduces in a fixed order, so results are bitwise reproducible for a fixed grid.
+// Work decomposition of the log-likelihood kernel: a gene is owned by L lanes of one wavefront
+// (L in {1,2,4,...,64}); a wavefront walks a range of the host's gene order, 64 / L genes per pass; lanes stride over the
+// gene's samples four cells per trip, read the per-sample constants from LDS, and combine with an L-lane butterfly.
+// Per-block partial sums of the close kernel go to a slab that the step kernel reduces in a fixed order, so results are
+// bitwise reproducible for a fixed number of lanes per gene.
 #include <hip/hip_runtime.h>
 #include "ppcx_gene.h"
 #include "ppcx_kernels.h"

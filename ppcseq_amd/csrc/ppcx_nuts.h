@@ -1,4 +1,4 @@
-// ppcx_nuts.h -- device-resident NUTS: the command protocol between the two kernels of a leapfrog
+// ppcx_nuts.h -- device-resident NUTS: the command protocol between the kernels of a leapfrog
 // and the per-chain scalar state machine.
 //
 // Reference behaviour replaced: rstan::sampling(...) at R/utilities.R:1497-1512 (chains, iter, warmup=150,
@@ -7,15 +7,16 @@
 // (multinomial NUTS with the generalised U-turn criterion and its two cross-subtree checks, diagonal
 // Euclidean metric, dual-averaging step size, windowed variance adaptation).
 //
-// MI355X-first structure: one leapfrog round = four launches on one stream.
+// MI355X-first structure: one leapfrog round = three launches on one stream.
 //   * log-likelihood kernel : the gradient evaluation of one leapfrog for every chain -- the count matrix streamed once,
-//     a handful of sums per gene (ppcx_gene.h gene_cells);
+//     a handful of sums per gene (ppcx_gene.h lane_gene_sums);
 //   * close kernel          : per gene: priors, gradient, second half kick, tree bookkeeping of the gene's coordinates
 //     (U-turn dot products, subtree slots), per-workgroup partial sums into a slab;
-//   * step kernel           : one workgroup per chain reduces the slab in a fixed order and runs the scalar NUTS /
-//     adaptation state machine (`chain_step` / `chain_advance`), emitting the next command;
-//   * update kernel         : applies the command to every gene-owned coordinate (proposal / sample copies, draw
-//     storage, Welford / metric updates, momentum refresh, first half kick + drift, the constants of the new position).
+//   * step kernel           : reduces the slab in a fixed order and runs the scalar NUTS / adaptation state machine
+//     (`chain_step` / `chain_advance`), emitting the next command, and applies that command to every gene-owned coordinate
+//     (proposal / sample copies, draw storage, Welford / metric updates, momentum refresh, first half kick + drift, the
+//     constants of the new position): every workgroup of its grid repeats the step on the same inputs and then takes its
+//     share of the coordinates (a separate update kernel does the coordinate work at initialisation and for ADVI).
 //   State and commands are double-buffered between rounds. The host only pumps the launches and polls a done flag: no
 //   per-leapfrog host round trip. Stan's recursive build_tree is evaluated iteratively: a completed left subtree of
 //   level d parks its (rho, p_begin, p_end, proposal, log weight) in slot d until its right sibling completes.

@@ -76,7 +76,7 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_
     chain ids (the Philox stream of chain c does not depend on the rank that runs it), the draws of the checked genes are
     all-gathered (a few MB) and rank 0 computes the credible intervals and flags from the POOLED draws; the result is
     broadcast, so every rank returns the same InferenceResult as one fit of all the chains would give.
-    `launch` = (lanes_per_gene, groups_per_wave) pins the kernel geometry (bit-identical results across rank counts need
+    `launch` = (lanes_per_gene, workgroups) pins the log-likelihood launch (0 = automatic) (bit-identical results across rank counts need
     the same geometry: the automatic choice depends on the chains per launch)."""
     import math
     from . import _lib

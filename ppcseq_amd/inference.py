@@ -104,7 +104,7 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *,
                       `cores` worker processes, R/utilities.R:1500-1501) and the credible intervals come from the POOLED
                       draws, as rstan::summary does over merged chains (:685-703). One process per GPU under
                       torch.distributed: ppcseq_amd.distributed.do_inference.
-    launch            (lanes_per_gene, groups_per_wave) pins the kernel geometry; by default it follows the number of
+    launch            (lanes_per_gene, workgroups) pins the log-likelihood launch (0 = automatic); by default it follows the number of
                       chains per launch, and results agree to rounding, not bit for bit, between geometries
     Returns an InferenceResult.
     """
