@@ -340,3 +340,35 @@ def test_cfg1_stress_all_genes_as_controls(L, bundled):
     called = set(res.loc[res["tot_deleterious_outliers"] > 0, "symbol"])
     assert {"CYP1A1", "LYZ"} <= called and len(called) <= 4
     assert res.attrs["diagnostics_test"]["divergent"][:, 150:].mean() < 0.02
+
+
+def test_a_chain_does_not_depend_on_the_chains_it_shares_launches_with(L, monkeypatch):
+    """Chains are independent given their global id (Philox key) and the lanes per gene (summation order inside a gene).
+    The same chain must therefore come out bit-identical from a 3-chain fit, from a fit with far more chains than the
+    chip holds resident workgroups per chain for (130 chains: the launch plan has fewer than 8 workgroups per chain, and
+    chains finish at different times, so the plan is redone many times), and from a fit whose chains are split into groups
+    on separate streams (PPCX_STREAM_GROUPS)."""
+    d = ind.synth(300, 12, K=20, seed=17)
+    m = L.Model(d["counts"], d["X"], d["exposure"], 20)
+    try:
+        m.set_launch(8, 0)
+        kw = dict(iter=60, warmup=40, seed=5)
+        f3 = m.fit_nuts(chains=3, **kw)
+        d3, g3 = f3.draws().copy(), f3.diagnostics()["n_leapfrog"].copy()
+        f3.close()
+        f130 = m.fit_nuts(chains=130, **kw)
+        d130, g130 = f130.draws(), f130.diagnostics()["n_leapfrog"]
+        assert np.array_equal(g130[:3], g3) and np.array_equal(d130[:3], d3)
+        assert len({tuple(r) for r in g130.tolist()}) > 100          # the chains are genuinely different trajectories
+        f130.close()
+        monkeypatch.setenv("PPCX_STREAM_GROUPS", "3")
+        f7 = m.fit_nuts(chains=7, **kw)
+        assert np.array_equal(f7.diagnostics()["n_leapfrog"][:3], g3) and np.array_equal(f7.draws()[:3], d3)
+        f7.close()
+        # a chain placed by its global id: chain 2 of the 3-chain fit alone in a fit with chain_id_offset = 2
+        monkeypatch.delenv("PPCX_STREAM_GROUPS")
+        f1 = m.fit_nuts(chains=1, chain_id_offset=2, **kw)
+        assert np.array_equal(f1.draws()[0], d3[2])
+        f1.close()
+    finally:
+        m.close()
