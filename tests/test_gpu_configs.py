@@ -132,6 +132,30 @@ def test_cfg2_nuts_decisions_follow_oracle(L, oracle):
     assert r.treedepth.max() >= 4 and r.n_leapfrog.sum() > 300
 
 
+def test_cfg3_nuts_decisions_follow_oracle(L, oracle):
+    """The headline configuration (20 000 x 200): the first warm-up iterations of two chains against the oracle's NUTS at the
+    same seed -- identical tree sizes and depths, step sizes to 1e-8 (the oracle costs 0.15 s per gradient here, so the
+    comparison stops after a few hundred of them; cfg2 above goes further)."""
+    G, S, seed = CONFIGS["cfg3"]
+    d = ind.synth(G, S, seed=seed)
+    K = d["K"]
+    mo = oracle.model(d["counts"], d["X"], d["exposure"], K, n_threads=min(16, os.cpu_count() or 1))
+    kw = dict(chains=2, iter=10, warmup=10, seed=20253, max_treedepth=5)
+    r = oracle.nuts_model(mo, oracle.cfg(**kw))
+    m = L.Model(d["counts"], d["X"], d["exposure"], K)
+    try:
+        f = m.fit_nuts(**kw)
+        dg = f.diagnostics()
+        f.close()
+    finally:
+        m.close()
+    assert np.array_equal(dg["n_leapfrog"], r.n_leapfrog)
+    assert np.array_equal(dg["treedepth"], r.treedepth)
+    assert np.array_equal(dg["divergent"], r.divergent)
+    assert np.max(np.abs(dg["stepsize"] - r.stepsize) / r.stepsize) < 1e-8
+    assert r.n_leapfrog.sum() > 80 and r.treedepth.max() >= 4
+
+
 def test_cfg4_gene_shards_and_ppc_kernel(L, oracle):
     """cfg4 (50 000 x 500): the gene-sharded run (in-process shards: the exchange step is the same sum) takes the same
     decisions as the unsharded run, and the posterior-predictive kernel reproduces the oracle's integers on the draws."""
