@@ -57,6 +57,9 @@ PPCX_API int ppcx_model_create(int device, int G, int S, int C, int K, const int
 PPCX_API int ppcx_model_set_exclusions(ppcx_model* m, int n_excl, const int32_t* excl);   /* pass 2 of R/methods.R:320-342 */
 PPCX_API int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int workgroups); /* 0 = automatic; lanes: power of two <= 64 */
 PPCX_API int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int* nblocks);
+/* diagnostic: the log-likelihood launch planned for `nchains` chains -- lanes per gene, workgroups per chain and the
+   gene-order positions bounds[0 .. 4 * workgroups_per_chain] delimiting the wavefronts' ranges (NULL to skip) */
+PPCX_API int ppcx_model_get_plan(ppcx_model* m, int nchains, int* lanes_per_gene, int* workgroups_per_chain, int* bounds, int cap);
 PPCX_API int ppcx_model_dim(const ppcx_model* m);          /* D = 2G + K*max(C-1,1) + 6 */
 PPCX_API void ppcx_model_destroy(ppcx_model* m);
 

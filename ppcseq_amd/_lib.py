@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("PPCX_LIB", os.path.join(_HERE, "libppcx.so"))   # PPC
 
 EXPORTS = [
     "ppcx_version", "ppcx_device_count", "ppcx_last_error", "ppcx_model_create", "ppcx_model_set_exclusions",
-    "ppcx_model_set_launch", "ppcx_model_get_launch", "ppcx_model_dim", "ppcx_model_destroy", "ppcx_log_prob_grad",
+    "ppcx_model_set_launch", "ppcx_model_get_launch", "ppcx_model_get_plan", "ppcx_model_dim", "ppcx_model_destroy", "ppcx_log_prob_grad",
     "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_from_draws", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
     "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_bench_gene_kernel",
     "ppcx_model_create_shard", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
@@ -59,6 +59,7 @@ def load() -> C.CDLL:
     lib.ppcx_model_set_exclusions.argtypes = [C.c_void_p, C.c_int, ip]
     lib.ppcx_model_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.ppcx_model_get_launch.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.ppcx_model_get_plan.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int32), C.c_int]
     lib.ppcx_model_dim.argtypes = [C.c_void_p]
     lib.ppcx_model_destroy.argtypes = [C.c_void_p]
     lib.ppcx_model_destroy.restype = None
@@ -150,6 +151,15 @@ class Model:
         """Pin the log-likelihood kernel's lanes per gene (a power of two <= 64) and/or its number of persistent
         workgroups; 0 = automatic. Results depend on lanes_per_gene only (summation order inside a gene)."""
         _check(load().ppcx_model_set_launch(self._h, int(lanes_per_gene), int(workgroups)))
+
+    def get_plan(self, nchains):
+        """(lanes per gene, workgroups per chain, bounds) of the log-likelihood launch planned for `nchains` chains:
+        wavefront j of a chain walks the gene-order positions bounds[j] .. bounds[j + 1] - 1 (diagnostic)."""
+        lanes, nb = C.c_int(), C.c_int()
+        _check(load().ppcx_model_get_plan(self._h, int(nchains), C.byref(lanes), C.byref(nb), None, 0))
+        b = np.zeros(4 * nb.value + 1, np.int32)
+        _check(load().ppcx_model_get_plan(self._h, int(nchains), C.byref(lanes), C.byref(nb), _p(b, C.c_int32), int(b.size)))
+        return lanes.value, nb.value, b
 
     def get_launch(self):
         a, b = C.c_int(), C.c_int()

@@ -323,6 +323,25 @@ extern "C" int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, i
   if (nblocks) *nblocks = m->nblocks_chosen;
   return PPCX_OK;
 }
+// the plan of a log-likelihood launch of `nchains` chains: workgroups per chain, and the gene-order positions
+// bounds[0 .. 4 * workgroups_per_chain] that delimit the wavefronts' ranges (bounds may be NULL; `cap` entries at most).
+// A diagnostic: tests check its invariants, nothing in the product path reads it back.
+extern "C" int ppcx_model_get_plan(ppcx_model* m, int nchains, int* lanes_per_gene, int* workgroups_per_chain, int* bounds, int cap) {
+  if (!m || nchains < 1) return fail(PPCX_ERR_ARG, "bad arguments");
+  HIPCHK(hipSetDevice(m->device));
+  choose_launch(m, nchains);
+  ppcx_model::Plan pl;
+  const int rc = plan_launch(m, nchains, 1, &pl);
+  if (rc != PPCX_OK) return rc;
+  if (lanes_per_gene) *lanes_per_gene = m->L;
+  if (workgroups_per_chain) *workgroups_per_chain = pl.nbpc;
+  if (bounds) {
+    const int n = 4 * pl.nbpc + 1;
+    if (cap < n) return fail(PPCX_ERR_ARG, "bounds buffer too small");
+    HIPCHK(hipMemcpy(bounds, pl.d_bounds, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  return PPCX_OK;
+}
 extern "C" int ppcx_model_dim(const ppcx_model* m) { return m ? m->d.D : PPCX_ERR_ARG; }
 extern "C" void ppcx_model_destroy(ppcx_model* m) {
   if (!m) return;

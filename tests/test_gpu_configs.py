@@ -396,3 +396,23 @@ def test_a_chain_does_not_depend_on_the_chains_it_shares_launches_with(L, monkey
         f1.close()
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("G,S,K", [(20000, 200, 1000), (5000, 50, 250), (300, 12, 20), (7, 3, 2)])
+def test_launch_plan_invariants(L, G, S, K):
+    """The host's plan of a log-likelihood launch: the wavefronts' ranges tile the gene order and none holds more passes
+    (of 64 / L genes, counted from its own start) than its share rounded up -- for every number of chains still running."""
+    d = ind.synth(G, S, K=K, seed=3)
+    m = L.Model(d["counts"], d["X"], d["exposure"], K)
+    try:
+        for nch in (1, 2, 3, 5, 8, 16, 130):
+            lanes, nb, b = m.get_plan(nch)
+            gpw = 64 // lanes
+            npass = -(-G // gpw)
+            wpc = 4 * nb
+            assert b[0] == 0 and b[-1] == G and np.all(np.diff(b) >= 0)
+            pmax = -(-npass // wpc)
+            assert np.max(-(-np.diff(b) // gpw)) <= pmax, (nch, lanes, nb)
+            assert nb * nch <= max(4 * 256, nch)               # resident workgroups of the chip (4 per CU), or one per chain
+    finally:
+        m.close()
