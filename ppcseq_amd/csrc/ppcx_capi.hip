@@ -388,7 +388,6 @@ static int work_alloc(Work& w, ppcx_model* m, int nchains) {
   // of the launch: it fixes the summation order of the kinetic energy, and a chain's results must not depend on its company.
   w.nb_update = (D + 255) / 256;
   if (w.nb_update > 80) w.nb_update = 80;
-  if (const char* e = getenv("PPCX_NB_UPDATE")) { const int v = atoi(e); if (v >= 1 && v < w.nb_update) w.nb_update = v; }   // development aid
   if (w.nb_update < 1) w.nb_update = 1;
   HIPCHK(hipMalloc(&w.vecs, sizeof(double) * (size_t)nchains * V_COUNT * w.Dpad));
   w.nb_close = (m->d.G + 255) / 256;
