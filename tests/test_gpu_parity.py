@@ -213,10 +213,16 @@ def test_nuts_posterior_matches_oracle_distribution(L, oracle):
         f.close()
     finally:
         m.close()
-    a = r.draws[..., cols].reshape(-1, 6)
-    se = np.sqrt(a.var(0) / 100 + b.var(0) / 100)
+    from ppcseq_amd.ess import ess_bulk
+    a3, b3 = r.draws[..., cols], b.reshape(4, -1, 6)                   # [chains, draws, 6]
+    a, b = a3.reshape(-1, 6), b3.reshape(-1, 6)
+    # two independent runs of the same sampler: tolerances from their own Monte-Carlo error (the slow hyper-parameters have
+    # an effective sample size of a few dozen here; var(log sd_hat) ~ 1 / (2 ESS))
+    ea = np.array([max(ess_bulk(a3[:, :, j]), 8.0) for j in range(6)])
+    eb = np.array([max(ess_bulk(b3[:, :, j]), 8.0) for j in range(6)])
+    se = np.sqrt(a.var(0) / ea + b.var(0) / eb)
     assert np.all(np.abs(a.mean(0) - b.mean(0)) < 5 * se)
-    assert np.all(np.abs(np.log(a.std(0) / b.std(0))) < 0.35)
+    assert np.all(np.abs(np.log(a.std(0) / b.std(0))) < 0.05 + 4.5 * np.sqrt(0.5 / ea + 0.5 / eb))
     assert dg["divergent"][:, 150:].mean() <= 0.02      # small hierarchical model: rare divergences are expected
     assert dg["stepsize"][:, -1].min() > 0
 
