@@ -179,10 +179,14 @@ PPCO_EXPORT double ppco_log_prob_grad(const ppco_model* m, const double* u, doub
   }
 
   /* likelihood: sum over all cells (.stan:97-103) ... */
+  /* per-gene sums are added afterwards in gene order: an OpenMP reduction combines the threads' partial sums in the
+     order they arrive, and the last bits of lp then differ from run to run (NUTS trajectories separate after ~50
+     iterations; the distributional tests saw two different "oracle" posteriors on two boxes) */
   double lik = 0.0;
+  double* lik_g = (double*)malloc(sizeof(double) * (size_t)(G > 0 ? G : 1));
   int nt = m->n_threads > 0 ? m->n_threads : 1;
   (void)nt;
-#pragma omp parallel for reduction(+:lik) num_threads(nt) schedule(static)
+#pragma omp parallel for num_threads(nt) schedule(static)
   for (int g = 0; g < G; ++g) {
     const double phi = exp(-sigma_raw[g]);              /* sigma = 1/exp(sigma_raw) (.stan:203) */
     double acc = 0.0, d_int = 0.0, d_phi_sum = 0.0;
@@ -201,7 +205,7 @@ PPCO_EXPORT double ppco_log_prob_grad(const ppco_model* m, const double* u, doub
         for (int c = 0; c < C; ++c) d_alpha[c] += m->X[(size_t)c * S + s] * de;
       }
     }
-    lik += acc;
+    lik_g[g] = acc;
     if (grad) {
       d_int = d_alpha[0];
       grad[o.intercept + g] += d_int;
@@ -212,6 +216,8 @@ PPCO_EXPORT double ppco_log_prob_grad(const ppco_model* m, const double* u, doub
       }
     }
   }
+  for (int g = 0; g < G; ++g) lik += lik_g[g];
+  free(lik_g);
   /* ... minus the same over the excluded cells (.stan:105-115) */
   for (int e = 0; e < m->n_excl; ++e) {
     int cell = m->excl[e], g = cell / S, s = cell % S;
