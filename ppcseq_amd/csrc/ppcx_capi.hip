@@ -75,8 +75,9 @@ extern "C" const char* ppcx_last_error(void) { return g_err.c_str(); }
 // Launch geometry of the log-likelihood kernel. The launch is resident: n_res = (workgroups the chip holds at once)
 // divided among the chains of the launch, four wavefronts each; wavefront j of a chain walks the gene positions
 // bounds[j] .. bounds[j + 1] of the gene order, 64 / L genes per pass.
-//   pass cost (in row-sweep iterations of a lane): 3 for loading and closing the genes (129 vector instructions against
-//   43.7 per iteration: SQ_INSTS_VALU at S = 40, 104, 200), ceil(S / L) for the row sweep
+//   pass cost (in row-sweep iterations of a lane): 5.8 for loading and closing the genes -- 129 vector instructions against
+//   43.7 per iteration (SQ_INSTS_VALU at S = 40, 104, 200) are 3 iterations' worth of issue, but with the dependent loads at
+//   the start of a pass they weigh like 5 to 6 in time (L = 8 against 16 at 4 chains, 4 against 8 at 3 chains: measured), ceil(S / L) for the row sweep
 //   (a little more on the two-group path, 2.5 x on the generic path with an exp per cell), 0.75 per iteration of the
 //   low-count loop, which lasts as long as the longest list of the pass needs -- from the kernel's instruction counts
 //   (profiles/, SQ_INSTS_VALU: ~50 per row-sweep cell, ~100 per list cell, ~250 per pass).
@@ -88,7 +89,7 @@ static double pass_cost(const ppcx_model* m, int L, int p, int n) {
   int lowmax = 0; bool slope = false;
   for (int i = p; i < p + n; ++i) { if (m->pos_low[i] > lowmax) lowmax = m->pos_low[i]; slope = slope || m->pos_slope[i]; }
   const double sweep = (double)((S + L - 1) / L) * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? 1.15 : 1.0));
-  return 3.0 + sweep + 0.75 * (double)((lowmax + L - 1) / L);
+  return 5.8 + sweep + 0.75 * (double)((lowmax + L - 1) / L);
 }
 static int resident_workgroups(const ppcx_model* m, int share) {
   int n = m->wgs_override > 0 ? m->wgs_override : m->n_cu * m->wgs_per_cu;
@@ -111,7 +112,7 @@ static void choose_launch(ppcx_model* m, int nchains) {
   for (int L = 1; L <= 64; L <<= 1) {
     const int gpw = 64 / L;
     const int wpc = 4 * workgroups_per_chain(m, L, nchains, resident_workgroups(m, 1));
-    const double t = ceil(ceil((double)G / gpw) / wpc) * (3.0 + (double)((S + L - 1) / L));   // passes of the busiest wavefront x pass cost
+    const double t = ceil(ceil((double)G / gpw) / wpc) * (5.8 + (double)((S + L - 1) / L));   // passes of the busiest wavefront x pass cost
     if (t < best) { best = t; bestL = L; }
   }
   const int L = m->L_override > 0 ? m->L_override : bestL;
