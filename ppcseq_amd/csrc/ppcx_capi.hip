@@ -349,6 +349,7 @@ extern "C" void ppcx_model_destroy(ppcx_model* m) {
   if (!m) return;
   if (m->live_fits > 0) { m->destroy_requested = true; return; }   // freed by the last ppcx_fit_free
   (void)hipSetDevice(m->device);
+  drop_plans(m);
   (void)hipFree(m->d_counts); (void)hipFree(m->d_E); (void)hipFree(m->d_expo); (void)hipFree(m->d_X);
   (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_SX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_low); (void)hipFree(m->d_low_start); (void)hipFree(m->d_nhi); (void)hipFree(m->d_low_m); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_order);
   if (m->stream) (void)hipStreamDestroy(m->stream);
