@@ -221,7 +221,7 @@ def main():
                 b_grad = b_grad / world              # each rank streams its share of the genes
             achieved = b_grad * chains_per_launch / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "ppcx_loglik_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(chains_per_launch),
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(chains_per_launch), "fp64_issue": issue_profile(),
                     "algorithmic_bytes_per_launch": b_grad * chains_per_launch, "avg_launch_ms": round(ms, 5),
                     "timed_launches": int(kA_n),
                     "note": "achieved = algorithmic bytes (SURVEY 8d: count matrix + coordinates, per chain gradient) x chains per "
@@ -277,6 +277,23 @@ def pmc_traffic(chains_per_launch):
         if int(p.get("chains_per_launch", 0)) != int(round(chains_per_launch)):
             return None
         return round((p["fetch_size_kib_per_launch"] + p["write_size_kib_per_launch"]) * 1024.0, 1)
+    except Exception:
+        return None
+
+
+def issue_profile():
+    """What actually bounds the log-likelihood kernel -- fp64 vector issue -- from the latest committed counter profile
+    (profiles/rNN_loglik_issue.json: SQ counters, clock and arithmetic-ceiling microbenchmarks of this kernel at the
+    headline workload). Reported inside `roofline` beside the HBM figures; null when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_loglik_issue.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fh:
+            p = json.load(fh)
+        return {k: p[k] for k in ("vector_insts_per_cell_iteration", "vector_pipes_busy_frac_at_sustained_clock",
+                                  "sustained_clock_ghz_under_fp64_fma", "frac_of_cell_arithmetic_ceiling") if k in p} | {"profile": os.path.basename(files[-1])}
     except Exception:
         return None
 
