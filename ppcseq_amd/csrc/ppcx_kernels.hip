@@ -189,6 +189,21 @@ __global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
       for (int cc = 0; cc < CM; ++cc) if (cc < d.C) acc.Tx[cc] = sums[(3 + cc) * G + g];
     }
   }
+  // the parked subtrees of the first levels this leaf closes are requested now: one round trip for all of them, behind the
+  // gene's arithmetic, instead of one per level after it (a chain closing three levels kept the launch 4 us longer)
+  constexpr int kPreLev = 3;
+  double pre[kPreLev][NCM][3];
+  const int n_pre = c.type == CMD_LEAF ? (c.n_merge < kPreLev ? c.n_merge : kPreLev) : 0;
+#pragma unroll
+  for (int lev = 0; lev < kPreLev; ++lev) {
+#pragma unroll
+    for (int j = 0; j < NCM; ++j) {
+      pre[lev][j][0] = pre[lev][j][1] = pre[lev][j][2] = 0.0;
+      if (lev < n_pre && j < x.ncoord) {
+        pre[lev][j][0] = v.at(V_LRHO + lev, x.idx[j]); pre[lev][j][1] = v.at(V_LPBEG + lev, x.idx[j]); pre[lev][j][2] = v.at(V_LPEND + lev, x.idx[j]);
+      }
+    }
+  }
   double pn[NCM], minv[NCM], part[10];
   gene_finish<CM>(d, c, v, x, acc, a.Sy, a.SyE, a.SyX, a.SX, a.ncell, a.Lg1, part, pn, minv);
   block_accumulate<10>(part, wacc, wave, lane);
@@ -196,7 +211,16 @@ __global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
     NodeVals nv[NCM];
 #pragma unroll
     for (int j = 0; j < NCM; ++j) nv[j] = NodeVals{pn[j], pn[j]};
-    for (int lev = 0; lev < c.n_merge; ++lev) {
+#pragma unroll
+    for (int lev = 0; lev < kPreLev; ++lev) {
+      if (lev < n_pre) {
+        double dots[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots_vals(pre[lev][j][0], pre[lev][j][1], pre[lev][j][2], pn[j], minv[j], &nv[j], dots);
+        block_accumulate<6>(dots, wacc + PT_DOTS + 6 * lev, wave, lane);
+      }
+    }
+    for (int lev = kPreLev; lev < c.n_merge; ++lev) {
       double dots[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots(v, x.idx[j], lev, pn[j], minv[j], &nv[j], dots);

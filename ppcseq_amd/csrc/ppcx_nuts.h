@@ -159,8 +159,12 @@ struct NodeVals { double nrho, npbeg; };
 
 // contribution of coordinate i to the six U-turn dot products of the merge at level d (slot d holds the
 // completed left sibling). Mirrors Stan's three compute_criterion calls inside build_tree.
+// Lr, Lb, Le: the parked left subtree of level d (rho, p_begin, p_end) of this coordinate
+PPCX_HD void coord_merge_dots_vals(double Lr, double Lb, double Le, double p_end, double minv, NodeVals* nv, double* dots);
 PPCX_HD void coord_merge_dots(const VecRef& v, int i, int d, double p_end, double minv, NodeVals* nv, double* dots) {
-  const double Lr = v.at(V_LRHO + d, i), Lb = v.at(V_LPBEG + d, i), Le = v.at(V_LPEND + d, i);
+  coord_merge_dots_vals(v.at(V_LRHO + d, i), v.at(V_LPBEG + d, i), v.at(V_LPEND + d, i), p_end, minv, nv, dots);
+}
+PPCX_HD void coord_merge_dots_vals(double Lr, double Lb, double Le, double p_end, double minv, NodeVals* nv, double* dots) {
   const double pes = minv * p_end;
   const double rs = Lr + nv->nrho;              // rho_subtree = rho_init + rho_final
   dots[0] += (minv * Lb) * rs;                  // p_sharp_beg . rho_subtree
