@@ -416,3 +416,32 @@ def test_launch_plan_invariants(L, G, S, K):
             assert nb * nch <= max(4 * 256, nch)               # resident workgroups of the chip (4 per CU), or one per chain
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("G,S,C,K", [(24, 2500, 2, 6), (16, 4300, 2, 0), (9, 1, 1, 0), (5, 3, 2, 5)])
+def test_extreme_sample_counts(L, oracle, G, S, C, K):
+    """Many samples: the per-sample constants need more than the default 64 KB of dynamic LDS (88 KB at S = 2500, 146 KB at
+    S = 4300: one resident workgroup per CU, the launch plan follows); and degenerate ones (a single sample; fewer samples
+    than lanes per gene). Density and gradient against the oracle."""
+    d = ind.synth(G, S, K=K, seed=8, C=C)
+    mo = oracle.model(d["counts"], d["X"], d["exposure"], K)
+    m = L.Model(d["counts"], d["X"], d["exposure"], K)
+    try:
+        rng = np.random.default_rng(1)
+        u = rng.uniform(-0.5, 0.5, (3, m.D))
+        u[:, 3:3 + G] += 4.0
+        for lanes in (0, 8, 64):
+            m.set_launch(lanes, 0)
+            lp, g = m.log_prob_grad(u)
+            for i in range(3):
+                lpo, go = oracle.log_prob_grad(mo, u[i])
+                assert abs(lp[i] - lpo) <= 1e-11 * max(1.0, abs(lpo)), (lanes, i)
+                assert np.max(np.abs(g[i] - go) / (1 + np.abs(go))) <= 1e-10, (lanes, i)
+    finally:
+        m.close()
+
+
+def test_too_many_samples_for_lds_is_refused(L):
+    d = ind.synth(4, 5300, K=0, seed=2)
+    with pytest.raises(L.PpcxError, match="LDS"):
+        L.Model(d["counts"], d["X"], d["exposure"], 0)
