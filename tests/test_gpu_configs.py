@@ -445,3 +445,31 @@ def test_too_many_samples_for_lds_is_refused(L):
     d = ind.synth(4, 5300, K=0, seed=2)
     with pytest.raises(L.PpcxError, match="LDS"):
         L.Model(d["counts"], d["X"], d["exposure"], 0)
+
+
+def test_fully_excluded_gene_low_count_exclusions_and_all_genes_checked(L, oracle):
+    """Exclusions that empty a whole gene, that hit cells of the low-count list (their tallies must follow), with every gene
+    checked (K = G: all genes carry a slope) -- density and gradient against the oracle, then back to no exclusions."""
+    rng = np.random.default_rng(11)
+    G, S = 30, 14
+    d = ind.synth(G, S, K=G, seed=12)
+    counts = d["counts"].copy()
+    counts[3] = rng.integers(0, 8, S)                     # a gene made of list cells only
+    counts[4, :5] = [0, 7, 8, 1, 0]
+    excl = np.concatenate([np.arange(7 * S, 8 * S),        # gene 7: every cell excluded
+                           3 * S + np.array([0, 5, 9]),    # list cells of gene 3
+                           4 * S + np.array([1, 2])]).astype(np.int32)
+    u = rng.uniform(-0.7, 0.7, (2, oracle.dim(G, 2, G)))
+    u[:, 3:3 + G] += 3.5
+    m = L.Model(counts, d["X"], d["exposure"], G)
+    try:
+        for ex in (excl, None, excl[::-1].copy()):
+            m.set_exclusions(ex)
+            mo = oracle.model(counts, d["X"], d["exposure"], G, excl=ex)
+            lp, g = m.log_prob_grad(u)
+            for i in range(2):
+                lpo, go = oracle.log_prob_grad(mo, u[i])
+                assert abs(lp[i] - lpo) <= 1e-11 * max(1.0, abs(lpo))
+                assert np.max(np.abs(g[i] - go) / (1 + np.abs(go))) <= 1e-10
+    finally:
+        m.close()
