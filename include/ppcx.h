@@ -41,8 +41,15 @@ extern "C" {
 typedef struct ppcx_model ppcx_model;
 typedef struct ppcx_fit ppcx_fit;
 
+/* ABI version: bumped whenever the layout or meaning of an argument changes. 100 = round 1; 200 = round 2 (dims[15] /
+ * reals[6] / counts_rng + errbuf + errlen of ppcx_do_inference_C, ppcx_model_set_launch's second argument = workgroups);
+ * 300 = this one: ppcx_do_inference_C takes the version its caller was written for as dims[0], so that a shim built for
+ * another layout gets PPCX_ERR_ARG instead of reading past its arrays.                                                */
+#define PPCX_VERSION 300
 PPCX_API int ppcx_version(void);
 PPCX_API int ppcx_device_count(void);
+/* free and total memory of a device in bytes (what R/methods.R:178-195 asks the host about before keeping all draws) */
+PPCX_API int ppcx_device_memory(int device, unsigned long long* free_bytes, unsigned long long* total_bytes);
 PPCX_API const char* ppcx_last_error(void);
 
 /* --- model = Stan data block (inst/stan/negBinomial_MPI.stan:142-173), logical form -------------
@@ -115,7 +122,8 @@ PPCX_API void ppcx_fit_free(ppcx_fit* f);
 /* R .C() convention (all pointers, void return; character vectors arrive as char**): one do_inference() pass end to end --
  * what R/utilities.R:1482-1531 obtains from vb_iterative()/sampling(), summary(fit, "counts_rng"), extract() and
  * summary(fit, "alpha_sub_1").
- *   dims[15] = {device, G, S, C, K, n_excl, chains, iter, warmup, n_gen, resample,
+ *   dims[16] = {PPCX_VERSION the caller was written for (anything else: status PPCX_ERR_ARG, nothing else is read),
+ *               device, G, S, C, K, n_excl, chains, iter, warmup, n_gen, resample,
  *               approximate_posterior_inference (0 = NUTS, R/utilities.R:1497-1512; 1 = ADVI through the bounded
  *               vb_iterative retry, :1487-1494), save_generated_quantities (counts_rng is filled, :796),
  *               vb_output_samples, vb_iter (0 = 50000)}
@@ -158,6 +166,11 @@ PPCX_API int ppcx_comm_unique_id(char* out128);               /* rank 0 creates 
 PPCX_API int ppcx_comm_create(int device, int nranks, int rank, const char* id128, ppcx_comm** out);
 PPCX_API void ppcx_comm_destroy(ppcx_comm* c);
 PPCX_API int ppcx_fit_nuts_comm(ppcx_model* shard, const ppcx_nuts_config* cfg, ppcx_comm* comm, ppcx_fit** out);
+
+/* What the ranks of a gene-sharded run conclude at a poll from the max-reduced vector
+ * [rounds, -rounds, chains done, -chains done, -(error status)] and their own status: PPCX_OK, the peer's / own error
+ * class, or PPCX_ERR_STALL when the ranks disagree. Pure host logic, exported so that it can be tested without two GPUs. */
+PPCX_API int ppcx_guard_decision(const double* reduced5, int local_status);
 
 /* Development aid, not part of the reference boundary: mean duration (ms) of `reps` back-to-back launches of
  * the gene kernel on the command the chains hold after `warm_pairs` launch pairs (n_merge < 0: as is).       */

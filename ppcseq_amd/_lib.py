@@ -21,7 +21,9 @@ EXPORTS = [
     "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_bench_gene_kernel",
     "ppcx_model_create_shard", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
     "ppcx_fit_nuts_comm", "ppcx_advi_config_default", "ppcx_fit_advi", "ppcx_fit_advi_info", "ppcx_fit_advi_iterative",
+    "ppcx_guard_decision", "ppcx_device_memory",
 ]
+ABI_VERSION = 300           # include/ppcx.h PPCX_VERSION this binding was written for
 
 
 class PpcxError(RuntimeError):
@@ -53,7 +55,13 @@ def load() -> C.CDLL:
         raise PpcxError(f"{LIB_PATH} not found: run `python -m ppcseq_amd.build` (hipcc, gfx950) first; "
                         "there is no CPU fallback")
     lib = C.CDLL(LIB_PATH)
+    lib.ppcx_version.restype = C.c_int
+    if lib.ppcx_version() != ABI_VERSION:
+        raise PpcxError(f"{LIB_PATH} has ABI version {lib.ppcx_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                        "(`python -m ppcseq_amd.build --force`)")
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    lib.ppcx_guard_decision.argtypes = [dp, C.c_int]
+    lib.ppcx_device_memory.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.ppcx_last_error.restype = C.c_char_p
     lib.ppcx_model_create.argtypes = [C.c_int] * 5 + [ip, dp, dp, C.c_double, C.c_int, ip, C.POINTER(C.c_void_p)]
     lib.ppcx_model_set_exclusions.argtypes = [C.c_void_p, C.c_int, ip]
@@ -105,6 +113,13 @@ def _p(a, t):
 
 def device_count() -> int:
     return int(load().ppcx_device_count())
+
+
+def device_memory(device=0):
+    """(free, total) bytes of a HIP device."""
+    f, t = C.c_ulonglong(), C.c_ulonglong()
+    _check(load().ppcx_device_memory(int(device), C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
 
 
 class Model:
@@ -336,6 +351,14 @@ class Fit:
         if getattr(self, "_h", None):
             load().ppcx_fit_free(self._h)
             self._h = None
+
+    # a device-resident handle: copies (pandas deep-copies DataFrame.attrs, where identify_outliers(pass_fit=True) puts the
+    # fits, R/methods.R:353-357) share it
+    def __copy__(self):
+        return self
+
+    def __deepcopy__(self, memo):
+        return self
 
     def __del__(self):
         try:

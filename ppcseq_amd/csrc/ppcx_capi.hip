@@ -34,6 +34,7 @@ struct ppcx_model {
   int CM, L = 64;
   int L_override = 0, wgs_override = 0;        // ppcx_model_set_launch
   int n_cu = 256, wgs_per_cu = 4;              // resident workgroups of the log-likelihood kernel = n_cu * wgs_per_cu
+  int ls_wgs_per_cu = 0;                       // the same for the merged launch of a pipelined round (0: cannot run)
   int nblocks_chosen = 0;                      // workgroups of the last planned launch (what ppcx_model_get_launch reports)
   // gene order of the log-likelihood launch (upload_counts): per position, the length of the gene's low-count list
   // and whether it has slopes -- what a pass of a wavefront costs (plan_launch)
@@ -68,9 +69,20 @@ struct ppcx_fit {
   double advi_elbo = 0, advi_eta = 0; int advi_converged = 0;
 };
 
-extern "C" int ppcx_version(void) { return 100; }
+extern "C" int ppcx_version(void) { return PPCX_VERSION; }
 extern "C" int ppcx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" const char* ppcx_last_error(void) { return g_err.c_str(); }
+extern "C" int ppcx_device_memory(int device, unsigned long long* free_bytes, unsigned long long* total_bytes) {
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(PPCX_ERR_ARG, "no such HIP device");
+  HIPCHK(hipSetDevice(device));
+  size_t f = 0, t = 0;
+  HIPCHK(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (unsigned long long)f;
+  if (total_bytes) *total_bytes = (unsigned long long)t;
+  return PPCX_OK;
+}
 
 // Launch geometry of the log-likelihood kernel. The launch is resident: n_res = (workgroups the chip holds at once)
 // divided among the chains of the launch, four wavefronts each; wavefront j of a chain walks the gene positions
@@ -91,16 +103,18 @@ static double pass_cost(const ppcx_model* m, int L, int p, int n) {
   const double sweep = (double)((S + L - 1) / L) * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? 1.15 : 1.0));
   return 5.8 + sweep + 0.75 * (double)((lowmax + L - 1) / L);
 }
-static int resident_workgroups(const ppcx_model* m, int share) {
-  int n = m->wgs_override > 0 ? m->wgs_override : m->n_cu * m->wgs_per_cu;
-  n /= share < 1 ? 1 : share;
+// reserve: workgroups of the same launch that are not log-likelihood workgroups (the state machines of a pipelined
+// round's merged launch; they are dispatched first and resident for a part of the launch)
+static int resident_workgroups(const ppcx_model* m, int reserve) {
+  int n = m->wgs_override > 0 ? m->wgs_override : m->n_cu * (reserve > 0 ? m->ls_wgs_per_cu : m->wgs_per_cu);
+  n -= reserve;
   return n < 1 ? 1 : n;
 }
 // workgroups per chain: all of the resident ones, a multiple of 8 (the kernel deals runs of 8 to the XCDs), not more
 // than there are passes to hand out
-static int workgroups_per_chain(const ppcx_model* m, int L, int nch, int n_res) {
+static int workgroups_per_chain(const ppcx_model* m, int L, int nch, int n_res, bool whole_runs = true) {
   int nbpc = n_res / (nch < 1 ? 1 : nch);
-  if (nbpc >= 8) nbpc = nbpc / 8 * 8;
+  if (nbpc >= 8 && whole_runs) nbpc = nbpc / 8 * 8;
   if (nbpc < 1) nbpc = 1;
   const int gpw = 64 / L, npass = (m->d.G + gpw - 1) / gpw;
   if (nbpc > (npass + 3) / 4) nbpc = (npass + 3) / 4;
@@ -111,7 +125,7 @@ static void choose_launch(ppcx_model* m, int nchains) {
   int bestL = 64; double best = 1e300;
   for (int L = 1; L <= 64; L <<= 1) {
     const int gpw = 64 / L;
-    const int wpc = 4 * workgroups_per_chain(m, L, nchains, resident_workgroups(m, 1));
+    const int wpc = 4 * workgroups_per_chain(m, L, nchains, resident_workgroups(m, 0));
     const double t = ceil(ceil((double)G / gpw) / wpc) * (5.8 + (double)((S + L - 1) / L));   // passes of the busiest wavefront x pass cost
     if (t < best) { best = t; bestL = L; }
   }
@@ -122,22 +136,24 @@ static void choose_launch(ppcx_model* m, int nchains) {
     m->plans.clear();
     m->L = L;
   }
-  m->nblocks_chosen = workgroups_per_chain(m, m->L, nchains, resident_workgroups(m, 1)) * nchains;
+  m->nblocks_chosen = workgroups_per_chain(m, m->L, nchains, resident_workgroups(m, 0)) * nchains;
 }
 static void drop_plans(ppcx_model* m) {
   std::lock_guard<std::mutex> lk(m->plan_mutex);
   for (auto& kv : m->plans) (void)hipFree(kv.second.d_bounds);
   m->plans.clear();
 }
-// the ranges for a launch of `nch` chains that may use 1 / share of the chip (share > 1: stream groups)
-static int plan_launch(ppcx_model* m, int nch, int share, ppcx_model::Plan* out) {
+// the ranges for a launch of `nch` chains beside `reserve` other workgroups
+static int plan_launch(ppcx_model* m, int nch, int reserve, ppcx_model::Plan* out) {
   std::lock_guard<std::mutex> lk(m->plan_mutex);
-  const int n_res = resident_workgroups(m, share);
+  const int n_res = resident_workgroups(m, reserve);
   const auto key = std::make_pair(nch, n_res);
   auto it = m->plans.find(key);
   if (it != m->plans.end()) { *out = it->second; return PPCX_OK; }
   const int G = m->d.G, L = m->L, gpw = 64 / L;
-  const int nbpc = workgroups_per_chain(m, L, nch, n_res), wpc = 4 * nbpc, npass = (G + gpw - 1) / gpw;
+  // beside state machines (reserve > 0) the last run of the launch may be partial: their slots and the range blocks
+  // together fill the chip
+  const int nbpc = workgroups_per_chain(m, L, nch, n_res, reserve == 0), wpc = 4 * nbpc, npass = (G + gpw - 1) / gpw;
   std::vector<double> cost(npass);
   double total = 0;
   for (int k = 0; k < npass; ++k) {
@@ -272,6 +288,7 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   m->d.x1_binary = x1b;
   m->wgs_per_cu = loglik_resident_workgroups_per_cu(m->CM, m->d);      // of the instantiation this model runs
   if (m->wgs_per_cu < 1) { delete m; return fail(PPCX_ERR_LIMIT, "the log-likelihood kernel cannot be resident with S * (2 + C) doubles of per-sample constants in LDS"); }
+  m->ls_wgs_per_cu = ls_resident_workgroups_per_cu(m->CM, m->d);
   std::vector<double> E(S);
   for (int s = 0; s < S; ++s) E[s] = exp(exposure[s]);
 #define MCHK(expr) do { int rc_ = (expr); if (rc_ != PPCX_OK) { ppcx_model_destroy(m); return rc_; } } while (0)
@@ -333,7 +350,7 @@ extern "C" int ppcx_model_get_plan(ppcx_model* m, int nchains, int* lanes_per_ge
   HIPCHK(hipSetDevice(m->device));
   choose_launch(m, nchains);
   ppcx_model::Plan pl;
-  const int rc = plan_launch(m, nchains, 1, &pl);
+  const int rc = plan_launch(m, nchains, 0, &pl);
   if (rc != PPCX_OK) return rc;
   if (lanes_per_gene) *lanes_per_gene = m->L;
   if (workgroups_per_chain) *workgroups_per_chain = pl.nbpc;
@@ -371,7 +388,7 @@ struct Work {
   int* done_host = nullptr;
   long Dpad = 0; int nb_update = 1, nb_close = 1; long launches = 0;
   hipStream_t stream = nullptr; bool own_stream = false;
-  int share = 1;                 // pumps that run on the model at the same time (stream groups): each plans for 1/share of the chip
+  bool pipelined = false;        // two launches per round (ppcx_ls_kernel + ppcx_gene_kernel) instead of three
   int *active = nullptr, *active_host = nullptr; int n_active = 0;   // chains still running (pump), 0 = all
   ~Work() {
     (void)hipFree(vecs); (void)hipFree(partials); (void)hipFree(done); (void)hipFree(sums); (void)hipFree(red);
@@ -437,9 +454,9 @@ struct RunIO {                  // output buffers of a run (device pointers, may
 // T0 slab, double-buffered like the states: a step launched at generation g (= w.launches) reads buffer g & 1, the
 // update that belongs to the command it decides writes buffer (g + 1) & 1.
 // with_update: the per-coordinate work of the new command in the same launch (ppcx_kernels.hip, ppcx_step_kernel).
-static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int phases, bool with_update = false) {
+static void step_args(ppcx_model* m, Work& w, const RunIO& io, int phases, bool with_update, StepArgs* o) {
   const int in = (int)(w.launches & 1), out = in ^ 1;
-  StepArgs sa;
+  StepArgs& sa = *o;
   sa.d = m->d; sa.phases = phases;
   sa.states_in = w.states[in]; sa.states_out = w.states[out];
   sa.cmds_in = w.cmds[in]; sa.cmds_out = w.cmds[out];
@@ -450,6 +467,10 @@ static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int
   sa.out_divergent = io.div; sa.out_accept = io.accept; sa.done = w.done;
   sa.upd_vecs = nullptr; sa.upd_Dpad = 0; sa.upd_t0_out = nullptr; sa.upd_logtab = nullptr;
   if (with_update && (phases & STEP_ADVANCE)) { sa.upd_vecs = w.vecs; sa.upd_Dpad = w.Dpad; sa.upd_t0_out = w.t0[out]; sa.upd_logtab = m->d_logtab; }
+}
+static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int phases, bool with_update = false) {
+  StepArgs sa;
+  step_args(m, w, io, phases, with_update, &sa);
   hipError_t e = launch_step_kernel(sa, w.nb_update, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("step kernel: ") + hipGetErrorString(e));
   if (phases & STEP_ADVANCE) w.launches++;
@@ -464,19 +485,59 @@ static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("update kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
 }
-static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
+// runs of a pipelined round's merged launch whose position 7 holds state machines: one per chain of the fit, `nact`
+// (chains still running = columns of the launch) per run
+static int step_runs(int nchains, int nact) { return (nchains + nact - 1) / nact; }
+static int loglik_args(ppcx_model* m, Work& w, int nchains, int reserve, LoglikArgs* out) {
   const int nact = w.n_active > 0 ? w.n_active : nchains;
   ppcx_model::Plan pl;
-  int rc = plan_launch(m, nact, w.share, &pl);
+  int rc = plan_launch(m, nact, reserve, &pl);
   if (rc != PPCX_OK) return rc;
-  LoglikArgs la;
+  LoglikArgs& la = *out;
   la.d = m->d; la.cd.counts = m->d_counts; la.cd.low = m->d_low; la.cd.low_start = m->d_low_start; la.cd.n_hi = m->d_nhi; la.cd.low_m = m->d_low_m; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
   la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order;
   la.lgL = 0; while ((1 << la.lgL) < m->L) ++la.lgL;
   la.nchains = nact; la.active = w.n_active > 0 ? w.active : nullptr; la.nbpc = pl.nbpc; la.bounds = pl.d_bounds;
+  return PPCX_OK;
+}
+static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
+  LoglikArgs la;
+  int rc = loglik_args(m, w, nchains, 0, &la);
+  if (rc != PPCX_OK) return rc;
   hipError_t e = launch_loglik_kernel(m->CM, la, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("loglik kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
+}
+static void close_args(ppcx_model* m, Work& w, CloseArgs* o);
+// pipelined round, first launch: the state machines that digest the previous gene kernel's sums beside the log-likelihood
+// workgroups of this round (the command buffer the log-likelihood part reads is the one the state machines read, not
+// the one they write)
+static int launch_ls(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
+  const int nact = w.n_active > 0 ? w.n_active : nchains;
+  const int n_srun = step_runs(nchains, nact);
+  LoglikArgs la;
+  int rc = loglik_args(m, w, nchains, n_srun * nact, &la);       // the state machines' slots are not log-likelihood workgroups
+  if (rc != PPCX_OK) return rc;
+  StepArgs sa;
+  step_args(m, w, io, STEP_REDUCE | STEP_ADVANCE, false, &sa);
+  hipError_t e = launch_ls_kernel(m->CM, la, sa, n_srun, nchains, 1, w.stream);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("merged log-likelihood / step kernel: ") + hipGetErrorString(e));
+  w.launches++;
+  return PPCX_OK;
+}
+// pipelined round, second launch: the command the state machines just wrote, gene by gene
+static int launch_gene_round(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
+  GeneArgs ga;
+  close_args(m, w, &ga.c);
+  ga.draws = io.draws; ga.draws_chain_stride = io.draws_stride; ga.logtab = m->d_logtab; ga.spec = 1;
+  hipError_t e = launch_gene_kernel(m->CM, ga, w.nb_close, nchains, w.stream);
+  if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("gene kernel: ") + hipGetErrorString(e));
+  return PPCX_OK;
+}
+static void close_args(ppcx_model* m, Work& w, CloseArgs* o) {
+  CloseArgs& ca = *o;
+  ca.d = m->d; ca.Sy = m->d_Sy; ca.SyE = m->d_SyE; ca.SyX = m->d_SyX; ca.SX = m->d_SX; ca.ncell = m->d_ncell; ca.Lg1 = m->d_Lg1;
+  ca.sums = w.sums; ca.vecs = w.vecs; ca.Dpad = w.Dpad; ca.cmds = w.cmds[w.launches & 1]; ca.partials = w.partials;
 }
 static int launch_close(ppcx_model* m, Work& w, int nchains) {
   CloseArgs ca;
@@ -526,26 +587,45 @@ struct ppcx_comm { ncclComm_t comm = nullptr; int nranks = 1, rank = 0, device =
 // poll the ranks compare (rounds issued, chains done, local error) with ONE max-reduction of [x, -x] pairs: if the
 // counts differ anywhere, or any rank failed, every rank leaves the pump with the same status instead of waiting for
 // a collective its peers will never issue.
+static int guard_decision(const double* g, int local_rc);
 static int comm_guard(ppcx_comm* c, hipStream_t st, long long pairs, int n_done, int local_rc, int* all_rc) {
-  double v[5] = {(double)pairs, -(double)pairs, (double)n_done, -(double)n_done, local_rc != PPCX_OK ? (double)(-local_rc) : 0.0};
-  HIPCHK(hipMemcpyAsync(c->d_guard, v, sizeof v, hipMemcpyHostToDevice, st));
+  // the vector travels through pinned host memory (the device reads it in place): a failing upload cannot keep this rank
+  // out of the collective its peers are about to enter
+  double* v = c->h_guard;
+  v[0] = (double)pairs; v[1] = -(double)pairs; v[2] = (double)n_done; v[3] = -(double)n_done; v[4] = local_rc != PPCX_OK ? (double)(-local_rc) : 0.0;
+  const std::string local_msg = g_err;
+  hipError_t he = hipMemcpyAsync(c->d_guard, v, sizeof(double) * 5, hipMemcpyHostToDevice, st);
   const int e = g_rccl.AllReduce(c->d_guard, c->d_guard, 5, /*ncclDouble*/ 8, /*ncclMax*/ 2, c->comm, st);
   if (e != 0) return fail(PPCX_ERR_HIP, std::string("ncclAllReduce (guard): ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"));
-  HIPCHK(hipMemcpyAsync(c->h_guard, c->d_guard, sizeof v, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  const double* g = c->h_guard;
-  *all_rc = PPCX_OK;
-  if (g[4] != 0.0) *all_rc = local_rc != PPCX_OK ? local_rc : fail(-(int)g[4], "another rank of the gene-sharded run reported an error");
-  else if (g[0] != -g[1] || g[2] != -g[3]) *all_rc = fail(PPCX_ERR_STALL, "the ranks of the gene-sharded run disagree on the rounds issued or the chains finished");
+  if (he == hipSuccess) he = hipMemcpyAsync(c->h_guard + 8, c->d_guard, sizeof(double) * 5, hipMemcpyDeviceToHost, st);
+  if (he == hipSuccess) he = hipStreamSynchronize(st);
+  if (he != hipSuccess) return fail(PPCX_ERR_HIP, std::string("guard exchange: ") + hipGetErrorString(he));
+  const int d = guard_decision(c->h_guard + 8, local_rc);
+  *all_rc = d;
+  if (d != PPCX_OK) {
+    if (local_rc != PPCX_OK) g_err = local_msg;
+    else if (d == PPCX_ERR_STALL) g_err = "the ranks of the gene-sharded run disagree on the rounds issued or the chains finished";
+    else g_err = "another rank of the gene-sharded run reported an error";
+  }
   return PPCX_OK;
 }
 
 // One shard of a run: its model (all genes, or a contiguous gene range) and its device scratch.
 struct Shard { ppcx_model* m; Work* w; RunIO io; };
 
-// Launch (loglik, close, reduce [, exchange], update) rounds until every chain reports done. With several
-// shards in one process they share shard 0's stream and their partial sums are added by ppcx_sum_shards_kernel;
-// with a communicator the sums are all-reduced over the ranks (RCCL, xGMI) between reduce and update.
+// What the ranks of a gene-sharded run conclude from the max-reduced guard vector [rounds, -rounds, done, -done, error]
+// (a pure function: tests/test_abi.py drives it through ppcx_guard_decision without a GPU).
+static int guard_decision(const double* g, int local_rc) {
+  if (g[4] != 0.0) return local_rc != PPCX_OK ? local_rc : -(int)g[4];
+  if (g[0] != -g[1] || g[2] != -g[3]) return PPCX_ERR_STALL;
+  return PPCX_OK;
+}
+extern "C" int ppcx_guard_decision(const double* reduced5, int local_rc) { return reduced5 ? guard_decision(reduced5, local_rc) : PPCX_ERR_ARG; }
+
+// Launch rounds until every chain reports done. A round is (loglik, close, step + update) -- three launches -- or, pipelined
+// (Work::pipelined), (merged log-likelihood / step launch, gene kernel) -- two. With several shards in one process they share
+// shard 0's stream and their partial sums are added by ppcx_sum_shards_kernel; with a communicator the sums are all-reduced
+// over the ranks (RCCL, xGMI) between reduce and advance.
 static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long max_pairs, bool time_kernels,
                 PumpStats* stats) {
   const int ns = (int)sh.size();
@@ -553,11 +633,15 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
   int rc = PPCX_OK;
   // Several ranks (one gene shard per process): a rank that fails must not leave its peers waiting in a collective. It
   // stops launching kernels but keeps issuing the per-round all-reduces until the next poll, where comm_guard lets every
-  // rank see the failure (or a disagreement on the rounds issued) and leave together.
+  // rank see the failure (or a disagreement on the rounds issued) and leave together. Every local failure inside the
+  // loop -- a launch, an event, a copy -- becomes local_rc; only a failing collective returns at once (its peers are
+  // then in an undefined state anyway).
   const bool guarded = comm && comm->comm && comm->nranks > 1;
+  const bool piped = ns == 1 && !(comm && comm->comm) && sh[0].w->pipelined;
   int local_rc = PPCX_OK;
 #define PUMP_TRY(expr) do { if (local_rc == PPCX_OK) { const int r_ = (expr); if (r_ != PPCX_OK) { if (!guarded) return r_; local_rc = r_; } } } while (0)
-  for (int k = 0; k < ns; ++k) {                                   // PH_START: first command, then its coordinate work
+#define PUMP_HIP(expr) do { if (local_rc == PPCX_OK) { const hipError_t e_ = (expr); if (e_ != hipSuccess) { const int r_ = fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); if (!guarded) return r_; local_rc = r_; } } } while (0)
+  if (!piped) for (int k = 0; k < ns; ++k) {                      // PH_START: first command, then its coordinate work
     PUMP_TRY(launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_REDUCE | STEP_ADVANCE));
     PUMP_TRY(launch_update(sh[k].m, *sh[k].w, nchains, sh[k].io));
   }
@@ -566,7 +650,7 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
   } evs;
-  if (time_kernels) for (hipEvent_t& x : evs.e) HIPCHK(hipEventCreate(&x));
+  if (time_kernels) for (hipEvent_t& x : evs.e) if (hipEventCreate(&x) != hipSuccess) { x = nullptr; time_kernels = false; }
   hipEvent_t &ev0 = evs.e[0], &ev1 = evs.e[1], &ev2 = evs.e[2], &ev3 = evs.e[3];
   long long pairs = 0; int n_done = 0;
   Work& w0 = *sh[0].w;
@@ -574,20 +658,26 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
     bool sampled = false;
     for (int i = 0; i < batch; ++i, ++pairs) {
       const bool smp = time_kernels && !sampled && (pairs / batch) % sample_every == 0 && i == batch / 2 && local_rc == PPCX_OK;
-      if (smp) HIPCHK(hipEventRecord(ev0, st));
+      if (smp) PUMP_HIP(hipEventRecord(ev0, st));
+      if (piped) {
+        PUMP_TRY(launch_ls(sh[0].m, w0, nchains, sh[0].io));
+        if (smp) { PUMP_HIP(hipEventRecord(ev1, st)); sampled = true; }
+        PUMP_TRY(launch_gene_round(sh[0].m, w0, nchains, sh[0].io));
+        if (smp) { PUMP_HIP(hipEventRecord(ev2, st)); PUMP_HIP(hipEventRecord(ev3, st)); }
+        continue;
+      }
       for (int k = 0; k < ns; ++k) PUMP_TRY(launch_loglik(sh[k].m, *sh[k].w, nchains));
-      if (smp) { HIPCHK(hipEventRecord(ev1, st)); sampled = true; }
+      if (smp) { PUMP_HIP(hipEventRecord(ev1, st)); sampled = true; }
       const bool exchange = ns > 1 || (comm && comm->comm);
       for (int k = 0; k < ns; ++k) {
         PUMP_TRY(launch_close(sh[k].m, *sh[k].w, nchains));
-        if (smp && k == ns - 1) HIPCHK(hipEventRecord(ev2, st));
+        if (smp && k == ns - 1) PUMP_HIP(hipEventRecord(ev2, st));
         PUMP_TRY(launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, exchange ? STEP_REDUCE : (STEP_REDUCE | STEP_ADVANCE), !exchange));
       }
       if (ns > 1) {
         ShardSumArgs sa; sa.n_shards = ns; sa.n = nchains * PT_COUNT;
         for (int k = 0; k < ns; ++k) sa.bufs[k] = sh[k].w->red;
-        hipError_t e = launch_sum_shards_kernel(sa, st);
-        if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("shard sum kernel: ") + hipGetErrorString(e));
+        PUMP_HIP(launch_sum_shards_kernel(sa, st));
       }
       if (comm && comm->nranks >= 1 && comm->comm) {                 // issued by every rank every round, failed or not
         const int e = g_rccl.AllReduce(w0.red, w0.red, (size_t)nchains * PT_COUNT, /*ncclDouble*/ 8, /*ncclSum*/ 0, comm->comm, st);
@@ -596,45 +686,53 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       for (int k = 0; k < ns; ++k) {
         if (exchange) PUMP_TRY(launch_step(sh[k].m, *sh[k].w, nchains, sh[k].io, STEP_ADVANCE, true));   // step + coordinate update in one launch
       }
-      if (smp) HIPCHK(hipEventRecord(ev3, st));
+      if (smp) PUMP_HIP(hipEventRecord(ev3, st));
     }
-    HIPCHK(hipMemcpyAsync(w0.done_host, w0.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (const char* e = getenv("PPCX_TEST_FAIL_AT_ROUND")) {       // fault injection for the guard's tests (tests/test_gpu_multi.py)
+      const long long at = atoll(e);
+      const char* rk = getenv("PPCX_TEST_FAIL_RANK");
+      if (at > 0 && pairs >= at && local_rc == PPCX_OK && (!rk || !comm || atoi(rk) == comm->rank))
+        local_rc = fail(PPCX_ERR_HIP, "injected failure (PPCX_TEST_FAIL_AT_ROUND)");
+    }
+    PUMP_HIP(hipMemcpyAsync(w0.done_host, w0.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
+    PUMP_HIP(hipStreamSynchronize(st));
     if (sampled && n_done == 0 && local_rc == PPCX_OK) {   // only launches in which every chain was still active
-      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-      stats->kA_ms_sum += ms; stats->kA_samples++; stats->chain_launches += nchains;
-      HIPCHK(hipEventElapsedTime(&ms, ev1, ev2)); stats->kC_ms_sum += ms;
-      HIPCHK(hipEventElapsedTime(&ms, ev2, ev3)); stats->kU_ms_sum += ms;
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
+        stats->kA_ms_sum += ms; stats->kA_samples++; stats->chain_launches += nchains;
+        if (hipEventElapsedTime(&ms, ev1, ev2) == hipSuccess) stats->kC_ms_sum += ms;
+        if (hipEventElapsedTime(&ms, ev2, ev3) == hipSuccess) stats->kU_ms_sum += ms;
+      }
     }
     n_done = 0;
     rc = local_rc;
-    for (int c = 0; c < nchains; ++c) {
+    if (local_rc == PPCX_OK) for (int c = 0; c < nchains; ++c) {
       if (w0.done_host[c]) ++n_done;
       if (w0.done_host[c] == 2) rc = fail(PPCX_ERR_INIT, "no finite initial point after 100 attempts");
       if (w0.done_host[c] == 3) rc = fail(PPCX_ERR_STEPSIZE, "step-size heuristic diverged");
     }
-    if (pairs > max_pairs && n_done < nchains) rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished");
+    if (pairs > max_pairs && n_done < nchains && rc == PPCX_OK) rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished");
     if (guarded) {
       int all_rc = PPCX_OK;
       const int grc = comm_guard(comm, st, pairs, n_done, rc, &all_rc);
       if (grc != PPCX_OK) return grc;
       if (all_rc != PPCX_OK) { rc = all_rc; break; }
-    } else if (local_rc != PPCX_OK) break;
+    } else if (rc != PPCX_OK) break;
     if (n_done == nchains) break;
-    if (rc == PPCX_ERR_STALL) break;
     // fewer chains in the launch: the others get their wavefronts (the stream is idle here, the list can be rewritten)
     if (n_done > 0) {
       int na = 0;
       for (int c = 0; c < nchains; ++c) if (!w0.done_host[c]) w0.active_host[na++] = c;
       for (int k = 0; k < ns; ++k) {
         Work& wk = *sh[k].w;
-        HIPCHK(hipMemcpyAsync(wk.active, w0.active_host, sizeof(int) * na, hipMemcpyHostToDevice, st));
+        PUMP_HIP(hipMemcpyAsync(wk.active, w0.active_host, sizeof(int) * na, hipMemcpyHostToDevice, st));
         wk.n_active = na;
       }
-      HIPCHK(hipStreamSynchronize(st));
+      PUMP_HIP(hipStreamSynchronize(st));
     }
   }
 #undef PUMP_TRY
+#undef PUMP_HIP
   stats->pairs = pairs;
   return rc;
 }
@@ -784,18 +882,25 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   FHIP(hipMemsetAsync(f->d_nleap, 0, sizeof(int) * (size_t)nch * iter, m->stream));
   FHIP(hipMemsetAsync(f->d_div, 0, sizeof(int) * (size_t)nch * iter, m->stream));
   FHIP(hipStreamSynchronize(m->stream));
-  // Chains can be split into groups that run on their own streams from their own host threads
-  // (PPCX_STREAM_GROUPS=n): while one group sits in its latency-bound close / step kernels another group's
-  // log-likelihood kernel has the CUs. Measured on cfg3, 8 chains: 4.1 s per fit with one stream, 3.8 s with two groups,
-  // 3.6 s with three (each launch planned for the whole chip), 5.2 s with four (more streams than hardware queues).
-  // Default 1: a single in-order stream keeps the per-kernel timings of the bench clean.
+  // Round structure. Pipelined (default where it applies): two launches per leapfrog, the state machine beside the
+  // log-likelihood workgroups (ppcx_kernels.hip, "Pipelined rounds"). It needs a model whose cells read the anticipated
+  // constants only (no per-cell linear predictor). The choice must not depend on the number of chains: the two round
+  // structures sum the kinetic energy of fresh momenta in different orders, and a chain's draws may not depend on its
+  // company. (With more chains than the chip holds workgroups the state machines simply run ahead of the log-likelihood
+  // workgroups instead of beside them.) PPCX_PIPELINE=0 selects the three-launch round.
+  bool piped = m->ls_wgs_per_cu >= 1 && m->d.x0_is_one && (m->d.C < 2 || m->d.K == 0 || m->d.x1_binary);
+  if (const char* e = getenv("PPCX_PIPELINE")) if (atoi(e) == 0) piped = false;
+  // Chains can also be split into groups that run on their own streams from their own host threads
+  // (PPCX_STREAM_GROUPS=n): while one group sits in its latency-bound kernels another group's log-likelihood
+  // workgroups have the CUs.
   int ngrp = 1;
   if (const char* e = getenv("PPCX_STREAM_GROUPS")) { int v = atoi(e); if (v >= 1) ngrp = v < nch ? v : nch; }
   struct Group { int c0 = 0, n = 0; Work w; RunIO io; PumpStats ps; int rc = PPCX_OK; std::string err; long long leap = 0; };
   std::vector<Group> grp(ngrp);
-  const long long max_pairs = (long long)iter * ((1LL << cfg->max_treedepth) + 8) + 100000;
+  const long long max_pairs = ((long long)iter * ((1LL << cfg->max_treedepth) + 8) + 100000) * (piped ? 2 : 1);
   for (int g = 0; g < ngrp; ++g) {
     Group& G = grp[g];
+    G.w.pipelined = piped;
     G.c0 = (int)((long long)nch * g / ngrp); G.n = (int)((long long)nch * (g + 1) / ngrp) - G.c0;
     if (g > 0) { FHIP(hipStreamCreateWithFlags(&G.w.stream, hipStreamNonBlocking)); G.w.own_stream = true; }
     int rc = work_alloc(G.w, m, G.n);
@@ -1153,7 +1258,7 @@ extern "C" int ppcx_comm_create(int device, int nranks, int rank, const char* id
   c->nranks = nranks; c->rank = rank; c->device = device;
   const int e = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
   if (e != 0) { delete c; return fail(PPCX_ERR_HIP, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error")); }
-  if (hipMalloc(&c->d_guard, sizeof(double) * 8) != hipSuccess || hipHostMalloc(&c->h_guard, sizeof(double) * 8) != hipSuccess) {
+  if (hipMalloc(&c->d_guard, sizeof(double) * 8) != hipSuccess || hipHostMalloc(&c->h_guard, sizeof(double) * 16) != hipSuccess) {
     ppcx_comm_destroy(c); return fail(PPCX_ERR_HIP, "allocating the communicator's guard buffers failed");
   }
   *out = c;
@@ -1325,6 +1430,11 @@ extern "C" void ppcx_do_inference_C(const int* dims, const int* counts, const do
     }
   };
   if (!dims || !reals || !ci) { finish(fail(PPCX_ERR_ARG, "dims, reals and ci must not be NULL")); return; }
+  if (dims[0] != PPCX_VERSION) {               // a shim written for another argument layout: nothing else is read
+    finish(fail(PPCX_ERR_ARG, "ppcx_do_inference_C: dims[0] must be the ABI version the caller was written for (" + std::to_string(PPCX_VERSION) + "), got " + std::to_string(dims[0])));
+    return;
+  }
+  dims += 1;                                   // the fields below are numbered as in include/ppcx.h, after the version
   const int device = dims[0], G = dims[1], S = dims[2], C = dims[3], K = dims[4], n_excl = dims[5];
   const int vb = dims[11], save_rng = dims[12];
   if (save_rng && !counts_rng) { finish(fail(PPCX_ERR_ARG, "save_generated_quantities without a counts_rng buffer")); return; }

@@ -17,6 +17,7 @@ struct GeneCtx {
   int gg, ncoord;
   bool active, has_slopes, fast, two;           // two: fast path with the group-dependent constant A / A1
   int idx[NCM];
+  double q[NCM];                  // the coordinates' positions (intercept, sigma_raw, slopes) at the end being evaluated
   GeneParams<CM> gp;
 };
 
@@ -36,29 +37,39 @@ PPCX_HD void coord_consts(const Dims& d, const VecRef& v, int i, double q, const
 }
 
 // load the gene's (already drifted) coordinates -- coefficients, sigma_raw, phi -- for the close kernel
+// which coordinates gene g owns and which cell path it takes (no memory access)
 template <int CM>
-PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, GeneCtx<CM>& x) {
+PPCX_HD void gene_index(const Dims& d, int g, GeneCtx<CM>& x) {
   constexpr int NCM = CM + 1;
   x.active = g < d.G;
   x.gg = x.active ? g : 0;
   const int C = d.C;
   const int nslope = x.gg < d.K ? (C - 1 > 1 ? C - 1 : 1) : 0;   // alpha_sub_1 exists even for C == 1 (.stan:189)
   x.ncoord = x.active ? 2 + nslope : 0;
-  double q[NCM];
 #pragma unroll
-  for (int j = 0; j < NCM; ++j) {
+  for (int j = 0; j < NCM; ++j)
     x.idx[j] = j == 0 ? d.off_intercept + x.gg : (j == 1 ? d.off_sigma_raw + x.gg : coef_index(d, j - 1, x.gg));
-    q[j] = j < x.ncoord ? v.at(V_Q0 + 3 * c.dir, x.idx[j]) : 0.0;
-  }
   x.has_slopes = x.active && x.gg < d.K && C >= 2;
   x.two = x.has_slopes && d.x0_is_one && d.x1_binary;
   x.fast = d.x0_is_one && (!x.has_slopes || x.two);
-  x.gp.coef[0] = q[0];
+}
+// the gene's parameters from its coordinates' positions x.q[] (phi: the constant written with the position)
+template <int CM>
+PPCX_HD void gene_params(const Dims& d, const VecRef& v, GeneCtx<CM>& x) {
+  x.gp.coef[0] = x.q[0];
 #pragma unroll
-  for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < C) ? q[cc + 1] : 0.0;
-  x.gp.sigma_raw = q[1];
+  for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < d.C) ? x.q[cc + 1] : 0.0;
+  x.gp.sigma_raw = x.q[1];
   x.gp.phi = x.active ? v.at(V_C0, x.idx[1]) : 1.0;        // sigma = 1 ./ exp(sigma_raw)   (.stan:203)
   x.gp.invphi = 0.0; x.gp.dlt = 0.0; x.gp.dps = 0.0; x.gp.A = 0.0; x.gp.A1 = 0.0;
+}
+template <int CM>
+PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, GeneCtx<CM>& x) {
+  constexpr int NCM = CM + 1;
+  gene_index<CM>(d, g, x);
+#pragma unroll
+  for (int j = 0; j < NCM; ++j) x.q[j] = j < x.ncoord ? v.at(V_Q0 + 3 * c.dir, x.idx[j]) : 0.0;
+  gene_params<CM>(d, v, x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -212,31 +223,38 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   cell_acc_close<CM>(gp, acc, tab, nhi, low_lik, low_dph, &o);
 }
 
-// close the gene with its reduced sums: gradient, second half kick, stores, partial sums part[0..9]
+// close the gene with its reduced sums: gradient, second half kick, stores, partial sums part[0..9].
+// The gene's data constants and its coordinates' momenta / metric arrive in registers (gene_finish loads them; the gene
+// kernel of a pipelined round has requested them at its start, together with everything else it reads).
+struct GeneData { double Sy, SyE, ncell, Lg1, SyX[kMaxC], SX[kMaxC]; };
 template <int CM>
-PPCX_HD void gene_finish(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, GeneSumsV<CM>& acc,
-                         const double* Sy, const double* SyE, const double* SyXg, const double* SXg, const double* ncell,
-                         const double* Lg1, double* part, double* pn, double* minv) {
-  constexpr int NCM = CM + 1;
-  if (x.fast) acc.Tx[0] = acc.Sr;               // X[,1] == 1
-  double SyX[CM], SX[CM];
+PPCX_HD void gene_data_load(const Dims& d, int gg, const double* Sy, const double* SyE, const double* SyXg, const double* SXg,
+                            const double* ncell, const double* Lg1, GeneData& o) {
+  o.Sy = Sy[gg]; o.SyE = SyE[gg]; o.ncell = ncell[gg]; o.Lg1 = Lg1[gg];
 #pragma unroll
   for (int cc = 0; cc < CM; ++cc) {
-    SyX[cc] = (cc < d.C) ? SyXg[(long)cc * d.G + x.gg] : 0.0;
-    SX[cc] = (cc < d.C) ? SXg[(long)cc * d.G + x.gg] : 0.0;
+    o.SyX[cc] = (cc < d.C) ? SyXg[(long)cc * d.G + gg] : 0.0;
+    o.SX[cc] = (cc < d.C) ? SXg[(long)cc * d.G + gg] : 0.0;
   }
+}
+template <int CM>
+PPCX_HD void gene_finish_vals(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, GeneSumsV<CM>& acc,
+                              const GeneData& gd, const double* p_in, const double* minv, double* part, double* pn,
+                              double* gn = nullptr) {
+  constexpr int NCM = CM + 1;
+  if (x.fast) acc.Tx[0] = acc.Sr;               // X[,1] == 1
   GeneOut<CM> go;
-  gene_close<CM>(d, c.hy, x.gg, x.has_slopes, x.gp, acc, Sy[x.gg], SyE[x.gg], SyX, SX, ncell[x.gg], Lg1[x.gg], &go);
+  gene_close<CM>(d, c.hy, x.gg, x.has_slopes, x.gp, acc, gd.Sy, gd.SyE, gd.SyX, gd.SX, gd.ncell, gd.Lg1, &go);
 #pragma unroll
   for (int k = 0; k < 10; ++k) part[k] = 0.0;
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < NCM; ++j) {
     const double gnew = j == 0 ? go.g_coef[0] : (j == 1 ? go.g_sigma_raw : go.g_coef[j >= 2 ? j - 1 : 0]);
-    pn[j] = 0.0; minv[j] = 1.0;
+    pn[j] = 0.0;
+    if (gn) gn[j] = gnew;
     if (j < x.ncoord) {
-      minv[j] = v.at(V_MINV, x.idx[j]);
-      pn[j] = v.at(V_P0 + 3 * c.dir, x.idx[j]) + 0.5 * c.eps * gnew;      // second half kick
+      pn[j] = p_in[j] + 0.5 * c.eps * gnew;      // second half kick
       v.at(V_P0 + 3 * c.dir, x.idx[j]) = pn[j];
       v.at(V_G0 + 3 * c.dir, x.idx[j]) = gnew;
       part[PT_T1] += pn[j] * pn[j] * minv[j];
@@ -250,6 +268,21 @@ PPCX_HD void gene_finish(const Dims& d, const Cmd& c, const VecRef& v, const Gen
     part[PT_NONFINITE] = bad ? 1.0 : 0.0;
   }
 }
+template <int CM>
+PPCX_HD void gene_finish(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, GeneSumsV<CM>& acc,
+                         const double* Sy, const double* SyE, const double* SyXg, const double* SXg, const double* ncell,
+                         const double* Lg1, double* part, double* pn, double* minv, double* gn = nullptr) {
+  constexpr int NCM = CM + 1;
+  GeneData gd;
+  gene_data_load<CM>(d, x.gg, Sy, SyE, SyXg, SXg, ncell, Lg1, gd);
+  double p_in[NCM];
+#pragma unroll
+  for (int j = 0; j < NCM; ++j) {
+    minv[j] = 1.0; p_in[j] = 0.0;
+    if (j < x.ncoord) { minv[j] = v.at(V_MINV, x.idx[j]); p_in[j] = v.at(V_P0 + 3 * c.dir, x.idx[j]); }
+  }
+  gene_finish_vals<CM>(d, c, v, x, acc, gd, p_in, minv, part, pn, gn);
+}
 
 // update kernel, one gene-owned coordinate: pre-operations of the new command, then the first half kick and the drift of
 // the next leapfrog (written in place into the end being advanced) and the constants of the new position. A command
@@ -260,12 +293,67 @@ PPCX_HD void coord_update(const Dims& d, const Cmd& nc, const VecRef& v, int i, 
   if (nc.type == CMD_FLUSH) return;
   double qn = cv.q;
   if (nc.eps != 0.0) {
-    const double ph = cv.p + 0.5 * nc.eps * cv.g;
-    qn = cv.q + nc.eps * cv.minv * ph;
+    double ph;
+    kick_drift(cv.q, cv.p, cv.g, nc.eps, cv.minv, &ph, &qn);
     v.at(V_P0 + 3 * nc.dir, i) = ph;
     v.at(V_Q0 + 3 * nc.dir, i) = qn;
   }
   coord_consts(d, v, i, qn, tab);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined rounds (two launches per leapfrog: ppcx_ls_kernel, ppcx_gene_kernel). The gene kernel does everything that
+// belongs to ONE gene, one thread per gene: the per-coordinate work of the command (gene_coord_update: what coord_update
+// does per coordinate), the close of the evaluated leaf (gene_finish + tree bookkeeping), and -- ahead of the state
+// machine's decision -- the constants of the position the next leaf of the same subtree would evaluate (gene_spec_consts),
+// so that the next log-likelihood launch can run beside the state machine instead of after it.
+// ---------------------------------------------------------------------------------------------------------------
+// the command's work on the gene's coordinates; leaves the new positions in x.q[]. consts: also the constants of the new
+// positions (commands whose position the log-likelihood kernel has not evaluated ahead of time).
+// cache: the coordinates' end states requested ahead (coord_prefetch_for) or null; p_out / minv_out: momentum after the
+// first half kick and the metric, for a close that follows in the same thread (null: not wanted).
+template <int CM, bool CACHED = false>
+PPCX_HD void gene_coord_update(const Dims& d, const Cmd& c, const VecRef& v, GeneCtx<CM>& x, double* draws, double* T0,
+                               const double* tab, bool consts, const CoordCache* cache = nullptr, double* p_out = nullptr,
+                               double* minv_out = nullptr) {
+  constexpr int NCM = CM + 1;
+#pragma unroll
+  for (int j = 0; j < NCM; ++j) {
+    x.q[j] = 0.0;
+    if (p_out) { p_out[j] = 0.0; minv_out[j] = 1.0; }
+    if (j < x.ncoord) {
+      const int i = x.idx[j];
+      CoordVals cv;
+      if (CACHED) { const CoordCache cj = cache[j]; cv = coord_pre(c, v, i, i, global_flat(d, i), true, draws, d.D, c.k0, c.k1, T0, &cj); }
+      else cv = coord_pre(c, v, i, i, global_flat(d, i), true, draws, d.D, c.k0, c.k1, T0);
+      double qn = cv.q, ph = cv.p;
+      if (c.type != CMD_FLUSH) {
+        if (c.eps != 0.0) {
+          kick_drift(cv.q, cv.p, cv.g, c.eps, cv.minv, &ph, &qn);
+          v.at(V_P0 + 3 * c.dir, i) = ph;
+          v.at(V_Q0 + 3 * c.dir, i) = qn;
+        }
+        if (consts) coord_consts(d, v, i, qn, tab);
+      }
+      x.q[j] = qn;
+      if (p_out) { p_out[j] = ph; minv_out[j] = cv.minv; }
+    }
+  }
+}
+// constants of the position the NEXT leaf would evaluate if the subtree continues in the same direction with the same
+// step: q + eps minv (pn + eps/2 gn), from the values the close has in registers
+template <int CM>
+PPCX_HD void gene_spec_consts(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, const double* pn,
+                              const double* gn, const double* minv, const double* tab) {
+  constexpr int NCM = CM + 1;
+#pragma unroll
+  for (int j = 0; j < NCM; ++j) {
+    if (j < x.ncoord) {
+      double ph, qn;
+      kick_drift(x.q[j], pn[j], gn[j], c.eps, minv[j], &ph, &qn);
+      coord_consts(d, v, x.idx[j], qn, tab);
+    }
+  }
 }
 
 // Kernel B, serial part (one thread per chain): finish the hyper coordinates of the executed command,
@@ -365,5 +453,23 @@ PPCX_HD void chain_step(const Lanes& ln, const Dims& d, ChainScalars& st, TreeAr
   }
 }
 #undef PPCX_SLOT
+
+// The state machine's part of a pipelined round. `ex` is the chain's current command. If the log-likelihood launch that
+// just ran had not evaluated it yet (its position was not the one anticipated), nothing is decided: the command is carried
+// to the next round, now evaluated. Otherwise the chain steps, and the new command is marked as already evaluated when it
+// is the continuation the gene kernel anticipated (spec: the model's cell paths read the anticipated constants only).
+// Returns whether the chain stepped.
+template <class Lanes>
+PPCX_HD bool chain_step_pipelined(const Lanes& ln, const Dims& d, ChainScalars& st, TreeArrays& ta, const Cmd& ex,
+                                  const double* red, const VecRef& hv, const ChainIO& io, Reduced& rd, Cmd& nc, bool spec) {
+  if (st.phase != PH_START && cmd_evaluates(ex) && !ex.evaluated) {
+    nc = ex; nc.evaluated = 1; nc.updated = 1;
+    return false;
+  }
+  chain_step(ln, d, st, ta, ex, red, st.phase != PH_START, hv, io, rd, nc);
+  nc.updated = 0;
+  nc.evaluated = (spec && spec_continues(ex, nc)) ? 1 : 0;
+  return true;
+}
 
 }  // namespace ppcx

@@ -39,6 +39,15 @@ struct CloseArgs {
   double* partials;             // [chains][nblocks_close][PT_COUNT]
 };
 
+// the gene kernel of a pipelined round (ppcx_gene_kernel): close kernel + the per-coordinate work of the command + the
+// constants of the anticipated next position
+struct GeneArgs {
+  CloseArgs c;
+  double* draws; long draws_chain_stride;   // PRE_STORE_DRAW
+  const double* logtab;         // log table (global memory), staged in LDS for coord_consts
+  int spec;                     // anticipate the next leaf's position (models whose cell paths read the constants only)
+};
+
 enum StepPhase : int { STEP_REDUCE = 1, STEP_ADVANCE = 2 };
 struct StepArgs {
   Dims d;
@@ -103,6 +112,11 @@ hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, hipStream_t st);
 int loglik_resident_workgroups_per_cu(int CM, const Dims& d);   // 0: the kernel cannot be launched with this much LDS
 size_t loglik_lds_bytes(int S, int C);
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st);
+// pipelined rounds: the merged launch (the state machines take position 7 of the first n_srun runs of 8 x chains
+// workgroups, log-likelihood range blocks everything else) and the gene kernel
+hipError_t launch_ls_kernel(int CM, const LoglikArgs& a, const StepArgs& sa, int n_srun, int n_chains_total, int spec, hipStream_t st);
+int ls_resident_workgroups_per_cu(int CM, const Dims& d);
+hipError_t launch_gene_kernel(int CM, const GeneArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_step_kernel(const StepArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st);
 hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st);

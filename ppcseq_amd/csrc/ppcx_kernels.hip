@@ -84,18 +84,21 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
   }
 }
 
-template <int CM, bool GEN>
-__global__ __launch_bounds__(256, GEN ? PPCX_LOGLIK_OCC : PPCX_LOGLIK_OCC_FAST) void ppcx_loglik_kernel(LoglikArgs a) {
-  extern __shared__ double lds[];
-  // workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids chain * 8 + (jb & 7) inside every run of
-  // 8 range blocks x chains put the chains of one range block on ONE XCD, so its L2 fetches the rows once
-  const int nch = a.nchains;
-  const int lin = blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
-  const int jb = run * 8 + (r & 7);
+// the body of a log-likelihood workgroup: range block jb of the chain in column `col` of the launch.
+// PIPE: part of a pipelined round's merged launch (ppcx_ls_kernel) -- the command in a.cmds is then the chain's command
+// BEFORE the state machine that runs beside this workgroup has looked at it.
+template <int CM, bool GEN, bool PIPE>
+__device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col, double* lds) {
   if (jb >= a.nbpc) return;
-  const int chain = a.active ? a.active[r >> 3] : r >> 3;
+  const int chain = a.active ? a.active[col] : col;
   const Cmd& c = a.cmds[chain];
   if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
+  if (PIPE) {
+    // evaluated and not a leaf: the gene kernel has closed it and anticipated nothing -- there is no position to evaluate
+    // until the state machine has decided (a leaf that has been closed left the constants of the anticipated next leaf;
+    // a command that has not been evaluated left its own)
+    if (c.evaluated && c.type != CMD_LEAF) return;
+  }
   constexpr int NS = GeneSums<CM>::N;
   const Dims& d = a.d;
   const int S = d.S, C = d.C;
@@ -126,6 +129,16 @@ __global__ __launch_bounds__(256, GEN ? PPCX_LOGLIK_OCC : PPCX_LOGLIK_OCC_FAST) 
     case 5: loglik_passes<CM, 5, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
     default: loglik_passes<CM, 6, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
   }
+}
+
+template <int CM, bool GEN>
+__global__ __launch_bounds__(256, GEN ? PPCX_LOGLIK_OCC : PPCX_LOGLIK_OCC_FAST) void ppcx_loglik_kernel(LoglikArgs a) {
+  extern __shared__ double lds[];
+  // workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids chain * 8 + (jb & 7) inside every run of
+  // 8 range blocks x chains put the chains of one range block on ONE XCD, so its L2 fetches the rows once
+  const int nch = a.nchains;
+  const int lin = blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
+  loglik_role<CM, GEN, false>(a, run * 8 + (r & 7), r >> 3, lds);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -415,6 +428,266 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
 }
 
 
+
+// -----------------------------------------------------------------------------------------------------
+// Pipelined rounds: two launches per leapfrog instead of three, and the state machine off the critical path.
+//   ppcx_ls_kernel   : ONE launch holds the log-likelihood workgroups of round r AND, in its first workgroups (one per
+//                      chain), the state machine that digests round r - 1: it reduces the gene kernel's slab, advances
+//                      the chain and writes the next command while the count matrix is being streamed. This works
+//                      because the log-likelihood part reads only per-gene constants, and the gene kernel has already
+//                      written those for the position the next leaf will most likely evaluate (same subtree direction,
+//                      same step). When the state machine decides otherwise (a new transition, the tree turning round,
+//                      the step-size search) the evaluation is void: the gene kernel then only applies the command and
+//                      leaves its true constants, the next launch evaluates them, and the chain has lost one round.
+//   ppcx_gene_kernel : everything that belongs to one gene, one thread per gene: the per-coordinate work of the command
+//                      (what the step kernel's coordinate part does in the three-launch round), the close of the leaf,
+//                      the constants of the anticipated next position.
+// The three-launch round stays for gene shards (their sums cross processes between reduce and advance), ADVI,
+// single evaluations and models with a per-cell linear predictor (whose cells read the positions themselves).
+// -----------------------------------------------------------------------------------------------------
+struct StepShared {
+  double sm[3][8][32];
+  double red[PT_COUNT];
+  double hv[V_COUNT * 8];
+  Cmd ex, nc;
+  ChainState st;
+  Reduced rd;
+};
+__device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain, StepShared& s, bool spec) {
+  constexpr int NST = (int)(sizeof(ChainState) / sizeof(int)), NCMD = (int)(sizeof(Cmd) / sizeof(int)), NHV = V_COUNT * 8;
+  static_assert(NST <= 4 * 256 && NCMD <= 256 && NHV <= 3 * 256 && PT_COUNT <= 96, "step role staging sizes");
+  const int tid = threadIdx.x;
+  const ChainState* st_in = a.states_in + chain;
+  const bool done = st_in->sc.phase == PH_DONE;
+  int r_st[4], r_cmd = 0; double r_hv[3];
+  {
+    const int* s2 = reinterpret_cast<const int*>(st_in);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r_st[k] = tid + 256 * k < NST ? s2[tid + 256 * k] : 0;
+    if (tid < NCMD) r_cmd = reinterpret_cast<const int*>(a.cmds_in + chain)[tid];
+    const double* hvg = a.hyper_in + (long)chain * NHV;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r_hv[k] = tid + 256 * k < NHV ? hvg[tid + 256 * k] : 0.0;
+  }
+  {
+    // the gene kernel's slab, every column (the kinetic energy of fresh momenta arrives in column PT_T0 here); a carried
+    // round reads a stale slab and ignores the sums
+    const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
+    const int c = tid & 31, ch = tid >> 5;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    const bool in2 = c + 64 < PT_COUNT;
+#pragma unroll 4
+    for (int b = ch; b < a.nblocks_close; b += 8) {
+      const double* row = slab + (long)b * PT_COUNT;
+      const double v0 = row[c], v1 = row[c + 32], v2 = in2 ? row[c + 64] : 0.0;
+      s0 += v0; s1 += v1; s2 += v2;
+    }
+    const Cmd& exg = a.cmds_in[chain];
+    const int np = (done || exg.type == CMD_DONE || exg.type == CMD_FLUSH) ? 0 : parts_used(exg);   // uniform
+    s.sm[0][ch][c] = c < np ? s0 : 0.0; s.sm[1][ch][c] = c + 32 < np ? s1 : 0.0; s.sm[2][ch][c] = c + 64 < np ? s2 : 0.0;
+    __syncthreads();
+    if (tid < PT_COUNT) {
+      double t = 0.0;
+      if (tid < np) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s.sm[tid >> 5][k][tid & 31];
+      }
+      s.red[tid] = t;
+    }
+  }
+  if (done) {                                  // finished chain: carry its final state across the double buffer
+    if (tid == 0) { a.states_out[chain] = *st_in; a.cmds_out[chain] = a.cmds_in[chain]; }
+    const double* hi = a.hyper_in + (long)chain * NHV;
+    double* ho = a.hyper_out + (long)chain * NHV;
+    for (int i = tid; i < NHV; i += 256) ho[i] = hi[i];
+    return;
+  }
+  {
+    int* d2 = reinterpret_cast<int*>(&s.st);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (tid + 256 * k < NST) d2[tid + 256 * k] = r_st[k];
+    if (tid < NCMD) reinterpret_cast<int*>(&s.ex)[tid] = r_cmd;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (tid + 256 * k < NHV) s.hv[tid + 256 * k] = r_hv[k];
+  }
+  __syncthreads();
+  if (tid < 8) {
+    ChainScalars st = s.st.sc;
+    ChainIO io;
+    io.draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
+    io.out.lp = a.out_lp ? a.out_lp + (long)chain * a.n_keep : nullptr;
+    io.out.stepsize = a.out_stepsize ? a.out_stepsize + (long)chain * a.iter : nullptr;
+    io.out.treedepth = a.out_treedepth ? a.out_treedepth + (long)chain * a.iter : nullptr;
+    io.out.n_leapfrog = a.out_n_leapfrog ? a.out_n_leapfrog + (long)chain * a.iter : nullptr;
+    io.out.divergent = a.out_divergent ? a.out_divergent + (long)chain * a.iter : nullptr;
+    io.out.accept = a.out_accept ? a.out_accept + (long)chain * a.iter : nullptr;
+    Cmd nc;
+    (void)chain_step_pipelined(WaveLanes{tid}, a.d, st, s.st.ta, s.ex, s.red, VecRef{s.hv, 8}, io, s.rd, nc, spec);
+    if (tid == 0) {
+      s.st.sc = st;
+      s.nc = nc;
+      if (st.phase == PH_DONE) a.done[chain] = 1 + st.error;
+    }
+  }
+  __syncthreads();
+  double* hvo = a.hyper_out + (long)chain * NHV;
+  for (int i = tid; i < NHV; i += 256) hvo[i] = s.hv[i];
+  const int* s2 = reinterpret_cast<const int*>(&s.st); int* d2 = reinterpret_cast<int*>(a.states_out + chain);
+  for (int i = tid; i < NST; i += 256) d2[i] = s2[i];
+  const int* c2 = reinterpret_cast<const int*>(&s.nc); int* e2 = reinterpret_cast<int*>(a.cmds_out + chain);
+  if (tid < NCMD) e2[tid] = c2[tid];
+}
+
+// Grid: runs of 8 x (chains of the launch) workgroups, as in ppcx_loglik_kernel: position r & 7 of a run is a range block,
+// r >> 3 the chain's column, and the workgroups with equal r & 7 land on one XCD. In the first n_srun runs position 7 is not
+// a range block but a state machine (of chain run * columns + column, if there is such a chain): state machines take the
+// slot of a log-likelihood workgroup each, all on one XCD, and every workgroup of the launch is resident from its start.
+template <int CM>
+__global__ __launch_bounds__(256, PPCX_LOGLIK_OCC_FAST) void ppcx_ls_kernel(LoglikArgs a, StepArgs sa, int n_srun, int n_chains_total, int spec) {
+  extern __shared__ double lds[];
+  const int nch = a.nchains;
+  const int lin = blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
+  const int pos = r & 7, col = r >> 3;
+  if (run < n_srun && pos == 7) {
+    const int sc = run * nch + col;
+    if (sc >= n_chains_total) return;
+    __builtin_amdgcn_s_setprio(3);             // latency-bound and short: ahead of the log-likelihood wavefronts of its SIMDs
+    step_role_pipelined(sa, sc, *reinterpret_cast<StepShared*>(lds), spec != 0);
+    return;
+  }
+  const int jb = run < n_srun ? run * 7 + pos : n_srun * 7 + (run - n_srun) * 8 + pos;
+  loglik_role<CM, false, true>(a, jb, col, lds);
+}
+
+template <int CM>
+__global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gene_kernel(GeneArgs ga) {
+  constexpr int NCM = CM + 1;
+  constexpr int NS = GeneSums<CM>::N;
+  __shared__ double wacc[4 * PT_COUNT];
+  __shared__ double s_tab[2 * kLogTabSize];
+  const CloseArgs& a = ga.c;
+  const int chain = blockIdx.y;
+  const Cmd& c = a.cmds[chain];
+  if (c.type == CMD_DONE) return;
+  const bool do_update = !c.updated, do_close = c.evaluated && c.type != CMD_FLUSH;      // uniform over the launch's chain
+  if (!do_update && !do_close) return;
+  const Dims& d = a.d;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
+  const double* sums = a.sums + (long)chain * NS * d.G;
+  const int g = blockIdx.x * 256 + tid;
+  const bool any_generic = !d.x0_is_one || (d.C >= 2 && d.K > 0);
+  GeneCtx<CM> x;
+  gene_index<CM>(d, g, x);
+  // ---- everything this thread reads is requested here, in one round trip, before anything is stored
+  const double tab0 = ga.logtab[tid], tab1 = ga.logtab[tid + 256];
+  static_assert(2 * kLogTabSize == 512, "two table entries per thread");
+  CoordCache cache[NCM];
+  double p_cur[NCM], minv[NCM];
+#pragma unroll
+  for (int j = 0; j < NCM; ++j) {
+    p_cur[j] = 0.0; minv[j] = 1.0; x.q[j] = 0.0;
+    if (j < x.ncoord) {
+      if (do_update) cache[j] = coord_prefetch_for(c, v, x.idx[j]);
+      else { x.q[j] = v.at(V_Q0 + 3 * c.dir, x.idx[j]); p_cur[j] = v.at(V_P0 + 3 * c.dir, x.idx[j]); minv[j] = v.at(V_MINV, x.idx[j]); }
+    }
+  }
+  GeneSumsV<CM> acc;
+  acc.lik = acc.dph = acc.Sr = 0.0;
+#pragma unroll
+  for (int cc = 0; cc < CM; ++cc) acc.Tx[cc] = 0.0;
+  GeneData gd;
+  double phi = 1.0;
+  constexpr int kPreLev = 3;
+  double pre[kPreLev][NCM][3];
+  const int n_pre = (do_close && c.type == CMD_LEAF) ? (c.n_merge < kPreLev ? c.n_merge : kPreLev) : 0;
+  if (do_close) {
+    if (x.active) {
+      const long G = d.G;
+      acc.lik = sums[0 * G + g]; acc.dph = sums[1 * G + g]; acc.Sr = sums[2 * G + g];
+      if (any_generic) {
+#pragma unroll
+        for (int cc = 0; cc < CM; ++cc) if (cc < d.C) acc.Tx[cc] = sums[(3 + cc) * G + g];
+      }
+      // phi of the position being closed: written with the constants the log-likelihood kernel evaluated (for a leaf
+      // anticipated by the previous gene kernel the update below does not touch them)
+      phi = v.at(V_C0, x.idx[1]);
+    }
+    gene_data_load<CM>(d, x.gg, a.Sy, a.SyE, a.SyX, a.SX, a.ncell, a.Lg1, gd);
+#pragma unroll
+    for (int lev = 0; lev < kPreLev; ++lev) {
+#pragma unroll
+      for (int j = 0; j < NCM; ++j) {
+        pre[lev][j][0] = pre[lev][j][1] = pre[lev][j][2] = 0.0;
+        if (lev < n_pre && j < x.ncoord) {
+          pre[lev][j][0] = v.at(V_LRHO + lev, x.idx[j]); pre[lev][j][1] = v.at(V_LPBEG + lev, x.idx[j]); pre[lev][j][2] = v.at(V_LPEND + lev, x.idx[j]);
+        }
+      }
+    }
+  }
+  s_tab[tid] = tab0; s_tab[tid + 256] = tab1;
+  __syncthreads();
+  // ---- the command's work on the gene's coordinates
+  double T0 = 0.0;
+  double* draws = ga.draws ? ga.draws + (long)chain * ga.draws_chain_stride : nullptr;
+  if (do_update) gene_coord_update<CM, true>(d, c, v, x, draws, &T0, s_tab, !do_close, cache, p_cur, minv);
+  double* slab = a.partials + ((long)chain * gridDim.x + blockIdx.x) * PT_COUNT;
+  if (!do_close) {                             // the command's position has not been evaluated yet: nothing to close
+    double t0v[1] = {T0};
+    block_accumulate<1>(t0v, wacc, wave, lane);
+    __syncthreads();
+    if (tid == 0) slab[PT_T0] = ((wacc[0] + wacc[PT_COUNT]) + wacc[2 * PT_COUNT]) + wacc[3 * PT_COUNT];
+    return;
+  }
+  // ---- close the evaluated position
+  x.gp.coef[0] = x.q[0];
+#pragma unroll
+  for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < d.C) ? x.q[cc + 1] : 0.0;
+  x.gp.sigma_raw = x.q[1];
+  x.gp.phi = phi; x.gp.invphi = 0.0; x.gp.dlt = 0.0; x.gp.dps = 0.0; x.gp.A = 0.0; x.gp.A1 = 0.0;
+  double pn[NCM], gn[NCM], part[10];
+  gene_finish_vals<CM>(d, c, v, x, acc, gd, p_cur, minv, part, pn, gn);
+  part[PT_T0] = T0;
+  block_accumulate<10>(part, wacc, wave, lane);
+  if (c.type == CMD_LEAF) {
+    NodeVals nv[NCM];
+#pragma unroll
+    for (int j = 0; j < NCM; ++j) nv[j] = NodeVals{pn[j], pn[j]};
+#pragma unroll
+    for (int lev = 0; lev < kPreLev; ++lev) {
+      if (lev < n_pre) {
+        double dots[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots_vals(pre[lev][j][0], pre[lev][j][1], pre[lev][j][2], pn[j], minv[j], &nv[j], dots);
+        block_accumulate<6>(dots, wacc + PT_DOTS + 6 * lev, wave, lane);
+      }
+    }
+    for (int lev = kPreLev; lev < c.n_merge; ++lev) {
+      double dots[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots(v, x.idx[j], lev, pn[j], minv[j], &nv[j], dots);
+      block_accumulate<6>(dots, wacc + PT_DOTS + 6 * lev, wave, lane);
+    }
+    if (!c.subtree_complete) {
+#pragma unroll
+      for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_store_slot(v, x.idx[j], c.n_merge, pn[j], nv[j]);
+    } else {
+      double top[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_top_dots(v, x.idx[j], c.dir, pn[j], minv[j], nv[j], top);
+      block_accumulate<6>(top, wacc + PT_TOP, wave, lane);
+    }
+    // ahead of the state machine: the constants of the position the next leaf of this subtree direction evaluates
+    if (ga.spec) gene_spec_consts<CM>(d, c, v, x, pn, gn, minv, s_tab);
+  }
+  __syncthreads();
+  const int np = parts_used(c);
+  for (int k = tid; k < np; k += 256) {
+    if (k == PT_T0 && !do_update) continue;    // left by the round that applied the command
+    const bool used = k < 10 || (k >= PT_DOTS && k < PT_DOTS + 6 * c.n_merge) || (k >= PT_TOP && c.subtree_complete);
+    slab[k] = used ? ((wacc[k] + wacc[PT_COUNT + k]) + wacc[2 * PT_COUNT + k]) + wacc[3 * PT_COUNT + k] : 0.0;
+  }
+}
 
 // in-process gene shards: every shard ends with the sum over shards (fixed order => identical bits everywhere)
 __global__ void ppcx_sum_shards_kernel(ShardSumArgs a) {
@@ -722,6 +995,42 @@ hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int ncha
   if (CM <= 2) hipLaunchKernelGGL((ppcx_close_kernel<2>), grid, dim3(256), 0, st, a);
   else if (CM <= 4) hipLaunchKernelGGL((ppcx_close_kernel<4>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((ppcx_close_kernel<8>), grid, dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+static const void* ls_kernel_ptr(int CM) {
+  if (CM <= 2) return (const void*)ppcx_ls_kernel<2>;
+  if (CM <= 4) return (const void*)ppcx_ls_kernel<4>;
+  return (const void*)ppcx_ls_kernel<8>;
+}
+static size_t ls_lds_bytes(int S, int C) { const size_t a = loglik_lds_bytes(S, C); return a > sizeof(StepShared) ? a : sizeof(StepShared); }
+int ls_resident_workgroups_per_cu(int CM, const Dims& d) {
+  int n = 0;
+  const size_t lds_bytes = ls_lds_bytes(d.S, d.C);
+  if (lds_bytes > 64u * 1024u) {
+    if (hipFuncSetAttribute(ls_kernel_ptr(CM), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  }
+  hipError_t e;
+  if (CM <= 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<2>, 256, lds_bytes);
+  else if (CM <= 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<4>, 256, lds_bytes);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<8>, 256, lds_bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+hipError_t launch_ls_kernel(int CM, const LoglikArgs& a, const StepArgs& sa, int n_srun, int n_chains_total, int spec, hipStream_t st) {
+  const size_t lds_bytes = ls_lds_bytes(a.d.S, a.d.C);
+  // runs: the first n_srun hold 7 range blocks (and a state machine) per chain, the others 8
+  int runs = n_srun;
+  if (a.nbpc > 7 * n_srun) runs += (a.nbpc - 7 * n_srun + 7) / 8;
+  const dim3 grid((unsigned)runs * 8u * (unsigned)a.nchains);
+  LoglikArgs args = a; StepArgs sargs = sa;
+  void* params[] = {&args, &sargs, &n_srun, &n_chains_total, &spec};
+  return hipLaunchKernel(ls_kernel_ptr(CM), grid, dim3(256), params, lds_bytes, st);
+}
+hipError_t launch_gene_kernel(int CM, const GeneArgs& a, int nblocks, int nchains, hipStream_t st) {
+  const dim3 grid(nblocks, nchains);
+  if (CM <= 2) hipLaunchKernelGGL((ppcx_gene_kernel<2>), grid, dim3(256), 0, st, a);
+  else if (CM <= 4) hipLaunchKernelGGL((ppcx_gene_kernel<4>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((ppcx_gene_kernel<8>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_step_kernel(const StepArgs& a, int nblocks, int nchains, hipStream_t st) {

@@ -63,6 +63,10 @@ struct Cmd {
   int leaf_n, n_merge, subtree_complete;   // tree position of this leaf inside the current subtree
   double hyp_q[6];               // hyper-parameter values (unconstrained) to evaluate the genes at
   uint32_t k0, k1;               // Philox key of this chain
+  // pipelined rounds (ppcx_ls_kernel / ppcx_gene_kernel): has the log-likelihood kernel evaluated this command's position
+  // (the per-gene sums belong to it), and has the per-coordinate work of the command (pre-operations, first half kick,
+  // drift) been applied. The classic three-launch round ignores both.
+  int evaluated, updated;
   Hyper hy;                      // make_hyper(hyp_q): computed once by kernel B so kernel A holds it in SGPRs
 };
 
@@ -71,15 +75,45 @@ struct VecRef {
   PPCX_HD double& at(int v, int i) const { return base[(long)v * stride + i]; }
 };
 struct CoordVals { double q, p, g, minv; };
+// first half kick and drift of one coordinate: ph = p + eps/2 g, qn = q + eps minv ph. One definition with explicit
+// fused operations, because the gene kernel evaluates it twice for the same leaf -- once ahead of the state machine's
+// decision, from registers, to hand the log-likelihood kernel the constants of the next position, and once for real --
+// and both must give the same bits.
+PPCX_HD void kick_drift(double q, double p, double g, double eps, double minv, double* ph, double* qn) {
+  const double h = fma(0.5 * eps, g, p);
+  *ph = h;
+  *qn = fma(eps * minv, h, q);
+}
 // both ends and the metric of one coordinate, fetched ahead of the state machine so that the memory latency
 // overlaps it (kernel B); coord_pre loads from memory when no cache is given
-struct CoordCache { double q[2], p[2], g[2], minv; };
+struct CoordCache {
+  double q[2], p[2], g[2], minv;
+  // constant indices only, so that the cache stays in registers (an end picked by a run-time index would put it on the stack)
+  PPCX_HD double qe(int e) const { return e ? q[1] : q[0]; }
+  PPCX_HD double pe(int e) const { return e ? p[1] : p[0]; }
+  PPCX_HD double ge(int e) const { return e ? g[1] : g[0]; }
+};
 PPCX_HD CoordCache coord_prefetch(const VecRef& v, int i) {
   CoordCache c;
   c.q[0] = v.at(V_Q0, i); c.p[0] = v.at(V_P0, i); c.g[0] = v.at(V_G0, i);
   c.q[1] = v.at(V_Q1, i); c.p[1] = v.at(V_P1, i); c.g[1] = v.at(V_G1, i);
   c.minv = v.at(V_MINV, i);
   return c;
+}
+
+// the same, restricted to what command c reads of coordinate i: the end it advances, and the other end only when a
+// proposal / sample copy takes it from there (a leaf after the tree turned round)
+PPCX_HD CoordCache coord_prefetch_for(const Cmd& c, const VecRef& v, int i) {
+  CoordCache cc;
+  const int e = c.dir, o = 1 - c.dir;
+  const double qe = v.at(V_Q0 + 3 * e, i), pe = v.at(V_P0 + 3 * e, i), ge = v.at(V_G0 + 3 * e, i);
+  double qo = 0.0, go = 0.0;
+  if (c.pre_dir == o && (c.pre_flags & (PRE_PROP | PRE_SAMPLE))) { qo = v.at(V_Q0 + 3 * o, i); go = v.at(V_G0 + 3 * o, i); }
+  cc.q[0] = e ? qo : qe; cc.q[1] = e ? qe : qo;
+  cc.p[0] = e ? 0.0 : pe; cc.p[1] = e ? pe : 0.0;
+  cc.g[0] = e ? go : ge; cc.g[1] = e ? ge : go;
+  cc.minv = v.at(V_MINV, i);
+  return cc;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -95,14 +129,14 @@ PPCX_HD CoordVals coord_pre(const Cmd& c, const VecRef& v, int i, int flat, int 
   const int f = c.pre_flags;
   if (f & PRE_PROP) {
     double q_, g_;
-    if (c.prop_src < 0) { q_ = cc ? cc->q[c.pre_dir] : v.at(V_Q0 + 3 * c.pre_dir, i); g_ = cc ? cc->g[c.pre_dir] : v.at(V_G0 + 3 * c.pre_dir, i); }
+    if (c.prop_src < 0) { q_ = cc ? cc->qe(c.pre_dir) : v.at(V_Q0 + 3 * c.pre_dir, i); g_ = cc ? cc->ge(c.pre_dir) : v.at(V_G0 + 3 * c.pre_dir, i); }
     else { q_ = v.at(V_LPQ + c.prop_src, i); g_ = v.at(V_LPG + c.prop_src, i); }
     if (writer) { v.at(V_LPQ + c.prop_slot, i) = q_; v.at(V_LPG + c.prop_slot, i) = g_; }
   }
   double sq = 0.0, sg = 0.0;
   bool have_s = false;
   if (f & PRE_SAMPLE) {
-    if (c.sample_src < 0) { sq = cc ? cc->q[c.pre_dir] : v.at(V_Q0 + 3 * c.pre_dir, i); sg = cc ? cc->g[c.pre_dir] : v.at(V_G0 + 3 * c.pre_dir, i); }
+    if (c.sample_src < 0) { sq = cc ? cc->qe(c.pre_dir) : v.at(V_Q0 + 3 * c.pre_dir, i); sg = cc ? cc->ge(c.pre_dir) : v.at(V_G0 + 3 * c.pre_dir, i); }
     else { sq = v.at(V_LPQ + c.sample_src, i); sg = v.at(V_LPG + c.sample_src, i); }
     have_s = true;
     if (writer) { v.at(V_SQ, i) = sq; v.at(V_SG, i) = sg; }
@@ -147,7 +181,7 @@ PPCX_HD CoordVals coord_pre(const Cmd& c, const VecRef& v, int i, int flat, int 
     r.p = coord_normal((uint32_t)rid, c.rng_c1, 3u, c.rng_c3, k0, k1) / sqrt(minv);
     if (writer) { v.at(V_Q1, i) = sq; v.at(V_G1, i) = sg; v.at(V_P1, i) = r.p; *T0 += r.p * r.p * minv; }
   } else {
-    if (cc) { r.q = cc->q[c.dir]; r.p = cc->p[c.dir]; r.g = cc->g[c.dir]; }
+    if (cc) { r.q = cc->qe(c.dir); r.p = cc->pe(c.dir); r.g = cc->ge(c.dir); }
     else { r.q = v.at(V_Q0 + 3 * c.dir, i); r.p = v.at(V_P0 + 3 * c.dir, i); r.g = v.at(V_G0 + 3 * c.dir, i); }
   }
   if ((f & PRE_SAVE_NEAR) && writer) v.at(V_PNEAR, i) = r.p;
@@ -292,8 +326,17 @@ PPCX_HD void cmd_clear(Cmd& c) {
   c.sample_src = -1; c.draw_index = 0; c.welford_n = 0; c.metric_n = 0; c.rng_c1 = 0; c.rng_c3 = 0;
   c.init_radius = 0; c.leaf_n = 0; c.n_merge = 0; c.subtree_complete = 0;
   for (int k = 0; k < 6; ++k) c.hyp_q[k] = 0.0;
-  c.k0 = 0; c.k1 = 0;
+  c.k0 = 0; c.k1 = 0; c.evaluated = 0; c.updated = 0;
 }
+// Pipelined rounds: after closing leaf `ex` the gene kernel assumes that the next command is the next leaf of the same
+// subtree direction with the same step, and writes the constants of that position for the log-likelihood launch that
+// runs beside the state machine. True unless the transition ends, a new transition starts or the tree turns round.
+PPCX_HD bool spec_continues(const Cmd& ex, const Cmd& nc) {
+  return ex.type == CMD_LEAF && nc.type == CMD_LEAF && nc.dir == ex.dir && nc.eps == ex.eps &&
+         (nc.pre_flags & (PRE_NEW_TRANSITION | PRE_INIT | PRE_EPS_TRY | PRE_METRIC)) == 0;
+}
+// does a command wait for a gradient evaluation (as opposed to CMD_FLUSH / CMD_DONE, which only move data)
+PPCX_HD bool cmd_evaluates(const Cmd& c) { return c.type == CMD_EVAL || c.type == CMD_EPS_TRY || c.type == CMD_LEAF; }
 
 // ----- helpers that fill in the next command ---------------------------------------------------------
 PPCX_HD void issue_eps_try(ChainScalars& st, Cmd& nc) {

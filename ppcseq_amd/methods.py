@@ -94,23 +94,45 @@ def get_scaled_counts_bulk(mat, samples):
     return dict(zip(samples, mult)), dict(zip(samples, nf))
 
 
+def required_device_memory(G, C, K, S, how_many_posterior_draws, cores, approximate_posterior_inference):
+    """Bytes the device holds for the full posterior analysis of one pass: the kept draws [chains][n_keep][D] stay
+    resident for the posterior-predictive kernel, beside the sampler's per-chain vectors. The device analogue of the
+    reference's RAM model (R/methods.R:184-188: `1.044e6 + draws * 3.777e-2` for MCMC, `1.554e6 + draws * 7.327e-2`
+    for VB, units unstated)."""
+    import math
+    from .inference import find_optimal_number_of_chains
+    D = 2 * G + K * max(C - 1, 1) + 6
+    Dpad = (D + 31) // 32 * 32
+    if approximate_posterior_inference:
+        return 8 * (int(how_many_posterior_draws) * D + 32 * 67 * Dpad) + 4 * G * S
+    chains = max(3, min(int(cores), find_optimal_number_of_chains(how_many_posterior_draws)))
+    n_keep = int(math.ceil(how_many_posterior_draws / chains))
+    return 8 * (chains * n_keep * D + chains * 67 * Dpad) + 4 * G * S
+
+
 def identify_outliers(data, formula="~ 1", sample="sample", transcript="transcript", abundance="count",
                       significance="PValue", do_check="do_check", scaling_factor=None,
                       percent_false_positive_genes=1, how_many_negative_controls=500,
-                      approximate_posterior_inference=False, approximate_posterior_analysis=False,
-                      draws_after_tail=10, save_generated_quantities=False, cores=4, pass_fit=False,
-                      do_check_only_on_detrimental=None, just_discovery=False, seed=None,
-                      adj_prob_theshold_2=None, device=0):
-    """Mirror of ppcseq::identify_outliers (R/methods.R:74-367).
+                      approximate_posterior_inference=True, approximate_posterior_analysis=True,
+                      draws_after_tail=10, save_generated_quantities=False, additional_parameters_to_save=(),
+                      cores=None, pass_fit=False, do_check_only_on_detrimental=None, tol_rel_obj=0.01,
+                      just_discovery=False, seed=None, adj_prob_theshold_2=None, device=0):
+    """Mirror of ppcseq::identify_outliers (R/methods.R:74-367): same arguments, same defaults.
 
-    data is a tidy pandas DataFrame (one row per transcript x sample). Differences from the reference,
-    all on purpose: the defaults of `approximate_posterior_inference` / `_analysis` are False because
-    this engine's native path is NUTS with the full posterior analysis (the reference defaults to ADVI,
-    R/methods.R:85-86); column arguments are strings. Returns a DataFrame with one row per checked
-    transcript: <transcript>, sample_wise_data (nested DataFrame), ppc_samples_failed,
-    tot_deleterious_outliers (when do_check_only_on_detrimental).
+    data is a tidy pandas DataFrame (one row per transcript x sample); column arguments are strings. As in the
+    reference the defaults are `approximate_posterior_inference = True` (ADVI, R/methods.R:85) and
+    `approximate_posterior_analysis = True` (:86); `tol_rel_obj` is accepted and, as in the reference, not used (the
+    inference pass hard-codes 0.005, R/utilities.R:1492); `additional_parameters_to_save` is a development argument of
+    the reference with nothing to add here (the fit keeps every parameter); `cores` defaults to the host's core count
+    (`detect_cores()`), which only bounds the number of chains. Pass `approximate_posterior_inference = False` for NUTS,
+    this engine's headline path. Returns a DataFrame with one row per checked transcript: <transcript>,
+    sample_wise_data (nested DataFrame), ppc_samples_failed, tot_deleterious_outliers (when do_check_only_on_detrimental).
     """
+    import os
     import pandas as pd
+    if cores is None:
+        cores = os.cpu_count() or 1                                        # detect_cores(), R/methods.R:91
+    del tol_rel_obj, additional_parameters_to_save                         # accepted for signature parity; see above
     covs = parse_formula(formula)
     if do_check_only_on_detrimental is None:
         do_check_only_on_detrimental = len(covs) > 0                      # R/methods.R:93
@@ -178,6 +200,14 @@ def identify_outliers(data, formula="~ 1", sample="sample", transcript="transcri
     exposure_rate = -np.log(multiplier)
 
     from . import _lib
+    # ---- enough memory for the full posterior? (R/methods.R:178-195 asks the host's RAM; the draws live on the device here)
+    if not approximate_posterior_analysis:
+        need = required_device_memory(G, X.shape[1], K, S, draws_2, cores, approximate_posterior_inference)
+        free, _total = _lib.device_memory(device)
+        if need > 0.9 * free:
+            warnings.warn("You don't have enough memory to model the posterior distribution with MCMC draws. "
+                          "Therefore the parameter approximate_posterior_analysis was set to TRUE")
+            approximate_posterior_analysis = True
     model = _lib.Model(counts, X, exposure_rate, K, device=device)
     try:
         # ---- pass 1: discovery (R/methods.R:268-286); always the full posterior analysis

@@ -26,7 +26,8 @@ t_frame = time.perf_counter() - t0
 t0 = time.perf_counter()
 res = identify_outliers(df, formula="~ Label", sample="sample", transcript="symbol", abundance="value", significance="PValue",
                         do_check="is_significant", percent_false_positive_genes=5, how_many_negative_controls=G - K,
-                        seed=20255, cores=int(os.environ.get("CORES", 8)))
+                        seed=20255, cores=int(os.environ.get("CORES", 8)),
+                        approximate_posterior_inference=False, approximate_posterior_analysis=False)
 t_all = time.perf_counter() - t0
 flag = {r["symbol"]: r["tot_deleterious_outliers"] for _, r in res.iterrows()}
 inj_genes = sorted({g for g, _ in d["injected"]})

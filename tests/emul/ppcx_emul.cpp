@@ -152,6 +152,101 @@ int emul_fit_nuts(int G, int S, int C, int K, const int32_t* counts, const doubl
   return rc;
 }
 
+// ---- pipelined rounds (ppcx_ls_kernel + ppcx_gene_kernel on the device): the same protocol with plain loops.
+// ls_first_s: run the state machine before the log-likelihood part of the merged launch (on the device they run side by
+// side: neither may depend on the other, so both orders must give the same chain).
+template <int CM>
+static void pipelined_loglik(const EmulModel& m, const Cmd& x, const VecRef& v, std::vector<GeneSumsV<CM>>& sums) {
+  if (x.type == CMD_DONE || x.type == CMD_FLUSH) return;
+  if (x.evaluated && x.type != CMD_LEAF) return;               // closed, and nothing was anticipated after it
+  CellData cd; cd.counts = m.counts.data(); cd.low = m.low.data(); cd.low_start = m.low_start.data(); cd.n_hi = m.nhi.data(); cd.low_m = m.low_m.data();
+  for (int g = 0; g < m.d.G; ++g)
+    lane_gene_sums<CM, 1>(m.d, x, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), sums[g]);
+}
+template <int CM>
+static void pipelined_gene(const EmulModel& m, const Cmd& y, const VecRef& v, double* draws, bool spec,
+                           std::vector<GeneSumsV<CM>>& sums, double* red) {
+  constexpr int NCM = CM + 1;
+  const Dims& d = m.d;
+  if (y.type == CMD_DONE) return;
+  const bool do_update = !y.updated, do_close = y.evaluated && y.type != CMD_FLUSH;
+  if (do_close) for (int k = 0; k < PT_COUNT; ++k) if (k != PT_T0) red[k] = 0.0;
+  double T0 = 0.0;
+  for (int g = 0; g < d.G; ++g) {
+    GeneCtx<CM> x;
+    gene_index<CM>(d, g, x);
+    if (do_update) gene_coord_update<CM>(d, y, v, x, draws, &T0, log_table(), !do_close);
+    if (!do_close) continue;
+    if (do_update) gene_params<CM>(d, v, x); else gene_load<CM>(d, y, v, g, x);
+    double pn[NCM], minv[NCM], gn[NCM], part[10];
+    GeneSumsV<CM> o = sums[g];
+    gene_finish<CM>(d, y, v, x, o, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.SX.data(), m.ncell.data(), m.Lg1.data(), part, pn, minv, gn);
+    for (int k = 0; k < 10; ++k) if (k != PT_T0) red[k] += part[k];
+    if (y.type == CMD_LEAF) {
+      NodeVals nv[NCM];
+      for (int j = 0; j < NCM; ++j) nv[j] = NodeVals{pn[j], pn[j]};
+      for (int lev = 0; lev < y.n_merge; ++lev)
+        for (int j = 0; j < x.ncoord; ++j) coord_merge_dots(v, x.idx[j], lev, pn[j], minv[j], &nv[j], red + PT_DOTS + 6 * lev);
+      if (!y.subtree_complete) { for (int j = 0; j < x.ncoord; ++j) coord_store_slot(v, x.idx[j], y.n_merge, pn[j], nv[j]); }
+      else for (int j = 0; j < x.ncoord; ++j) coord_top_dots(v, x.idx[j], y.dir, pn[j], minv[j], nv[j], red + PT_TOP);
+      if (spec) gene_spec_consts<CM>(d, y, v, x, pn, gn, minv, log_table());
+    }
+  }
+  if (do_update) red[PT_T0] = T0;
+}
+template <int CM>
+static int pipelined_chain(const EmulModel& m, const NutsConfig& nc, int ch, const ChainIO& io, bool spec, bool ls_first_s,
+                           long* rounds, long* carried) {
+  const int D = m.d.D;
+  std::vector<double> vecs((size_t)V_COUNT * D, 0.0), hv((size_t)V_COUNT * 8, 0.0), red(PT_COUNT, 0.0);
+  for (int i = 0; i < D; ++i) vecs[(size_t)V_MINV * D + i] = 1.0;
+  for (int k = 0; k < 8; ++k) hv[V_MINV * 8 + k] = 1.0;
+  std::vector<GeneSumsV<CM>> sums(m.d.G);
+  ChainState st; state_init(st, nc, ch, 0);
+  Cmd x, y; cmd_clear(x);
+  VecRef v{vecs.data(), D}, h{hv.data(), 8};
+  Reduced rd;
+  for (long guard = 0; guard < 100000000L; ++guard) {
+    if (!ls_first_s) pipelined_loglik<CM>(m, x, v, sums);
+    const Cmd x_seen = x;                                         // what the log-likelihood part of the launch reads
+    const bool stepped = chain_step_pipelined(SerialLanes{}, m.d, st.sc, st.ta, x, red.data(), h, io, rd, y, spec);
+    if (ls_first_s) pipelined_loglik<CM>(m, x_seen, v, sums);
+    ++*rounds; if (!stepped) ++*carried;
+    x = y;
+    if (x.type == CMD_DONE) return st.sc.error ? -3 : 0;
+    pipelined_gene<CM>(m, x, v, io.draws, spec, sums, red.data());
+  }
+  return -5;
+}
+// rounds[chains], carried[chains]: launches per chain and how many of them only carried a command (mis-anticipations)
+extern "C" __attribute__((visibility("default")))
+int emul_fit_nuts_pipelined(int G, int S, int C, int K, const int32_t* counts, const double* X, const double* expo, double lmm,
+                            int n_excl, const int32_t* excl, const EmulCfg* cfg, int spec, int ls_first_s, double* draws, double* lp,
+                            double* stepsize, int* treedepth, int* n_leapfrog, int* divergent, double* accept, long* rounds,
+                            long* carried) {
+  EmulModel m = make_model(G, S, C, K, counts, X, expo, lmm, n_excl, excl);
+  const int D = m.d.D, nk = cfg->iter - cfg->warmup;
+  NutsConfig nc; nc.chains = cfg->chains; nc.iter = cfg->iter; nc.warmup = cfg->warmup; nc.seed = cfg->seed;
+  nc.adapt_delta = cfg->adapt_delta; nc.max_treedepth = cfg->max_treedepth; nc.init_radius = cfg->init_radius;
+  nc.stepsize0 = cfg->stepsize0; nc.init_buffer = cfg->init_buffer; nc.term_buffer = cfg->term_buffer;
+  nc.window = cfg->window; nc.chain_id_offset = cfg->chain_id_offset;
+  int rc = 0;
+  for (int ch = 0; ch < cfg->chains; ++ch) {
+    ChainIO io;
+    io.draws = draws + (size_t)ch * nk * D;
+    io.out.lp = lp + (size_t)ch * nk; io.out.stepsize = stepsize + (size_t)ch * cfg->iter;
+    io.out.treedepth = treedepth + (size_t)ch * cfg->iter; io.out.n_leapfrog = n_leapfrog + (size_t)ch * cfg->iter;
+    io.out.divergent = divergent + (size_t)ch * cfg->iter; io.out.accept = accept + (size_t)ch * cfg->iter;
+    rounds[ch] = 0; carried[ch] = 0;
+    int r;
+    if (m.CM == 2) r = pipelined_chain<2>(m, nc, ch, io, spec != 0, ls_first_s != 0, rounds + ch, carried + ch);
+    else if (m.CM == 4) r = pipelined_chain<4>(m, nc, ch, io, spec != 0, ls_first_s != 0, rounds + ch, carried + ch);
+    else r = pipelined_chain<8>(m, nc, ch, io, spec != 0, ls_first_s != 0, rounds + ch, carried + ch);
+    if (r != 0) rc = r;
+  }
+  return rc;
+}
+
 extern "C" __attribute__((visibility("default")))
 int emul_nb2_log_rng(double eta, double phi, unsigned long long seed, unsigned cell, unsigned draw) {
   return nb2_log_rng(eta, phi, seed32(seed), cell, draw);

@@ -179,3 +179,41 @@ def test_approximated_analysis_oracle_properties(oracle):
     ref = np.stack([[[oracle.nb2_log_rng(d["exposure"][s] + dr[0, 3 + g] + d["X"][s, 1] * dr[0, 13 + g], np.exp(-dr[0, 16 + g]), 3, g * 6 + s, j)
                       for s in range(6)] for g in range(3)] for j in range(7)])
     assert np.array_equal(one, ref)
+
+
+@pytest.mark.parametrize("G,S,C,K,seed", [(30, 8, 2, 4, 3), (20, 6, 1, 3, 4), (24, 7, 3, 4, 5)])
+def test_pipelined_rounds_reproduce_the_classic_rounds(emul, G, S, C, K, seed):
+    """The two-launch round (log-likelihood beside the state machine, positions anticipated by the gene kernel, a carried
+    round when the anticipation was wrong) is a re-ordering of the same arithmetic: the same chains come out, whichever
+    of the two concurrent parts of the merged launch runs first, with and without anticipation. The only difference is
+    the order in which the kinetic energy of fresh momenta is summed (per gene instead of per coordinate index), so the
+    early iterations agree to rounding."""
+    from tests.emul_util import emul_fit_pipelined
+    d = ind.synth(G, S, K=K, seed=seed, C=C)
+    if C == 3:
+        d["X"][:, 2] = np.linspace(-1, 1, S)              # a continuous covariate: genes with the per-cell-eta path
+    e = emul_fit(emul, d["counts"], d["X"], d["exposure"], K, 2, 60, 40, 11)
+    n = 14
+    total_leaps = e["n_leapfrog"].sum(1)
+    # genes with the per-cell-eta path read the positions themselves, not the anticipated constants: such a model runs
+    # without anticipation (on the device it keeps the three-launch round)
+    generic = C == 3
+    for spec in ((False,) if generic else (True, False)):
+        for first_s in (False, True):
+            p = emul_fit_pipelined(emul, d["counts"], d["X"], d["exposure"], K, 2, 60, 40, 11, spec=spec, ls_first_s=first_s)
+            assert np.array_equal(p["n_leapfrog"][:, :n], e["n_leapfrog"][:, :n])
+            assert np.array_equal(p["treedepth"][:, :n], e["treedepth"][:, :n])
+            assert np.max(np.abs(p["stepsize"][:, :n] - e["stepsize"][:, :n])) < 1e-9
+            assert np.max(np.abs(p["accept"][:, :n] - e["accept"][:, :n])) < 1e-7
+            if first_s:
+                ps = p
+            leaps = p["n_leapfrog"].sum(1)
+            if spec:
+                # a carried round per mis-anticipation: new transitions, direction changes, the step-size search
+                assert np.all(p["carried"] < 0.35 * leaps + 200), (p["carried"], leaps)
+            else:
+                assert np.all(p["carried"] >= leaps)          # nothing anticipated: every evaluation takes two rounds
+    # the two orders of the merged launch give the same bits
+    p2 = emul_fit_pipelined(emul, d["counts"], d["X"], d["exposure"], K, 2, 60, 40, 11, spec=not generic, ls_first_s=False)
+    assert np.array_equal(p2["draws"], ps["draws"]) and np.array_equal(p2["n_leapfrog"], ps["n_leapfrog"])
+    assert total_leaps.min() > 100

@@ -331,7 +331,8 @@ def test_cfg5_two_pass_full_size_against_generator_truth(L):
     genes, df = _tidy(d["counts"], d["X"], K, np.random.default_rng(1))
     res = identify_outliers(df, formula="~ Label", sample="sample", transcript="symbol", abundance="value",
                             significance="PValue", do_check="is_significant", percent_false_positive_genes=5,
-                            how_many_negative_controls=G - K, seed=20255, cores=8)
+                            how_many_negative_controls=G - K, seed=20255, cores=8,
+                            approximate_posterior_inference=False, approximate_posterior_analysis=False)
     assert len(res) == K and res.attrs["total_draws"] == S * K * 20000
     hit = 0
     for g, s in d["injected"]:
@@ -360,7 +361,8 @@ def test_cfg1_stress_all_genes_as_controls(L, bundled):
     assert df["is_significant"].sum() == 15 * S
     res = identify_outliers(df, formula="~ Label", sample="sample", transcript="symbol", abundance="value",
                             significance="PValue", do_check="is_significant", percent_false_positive_genes=5,
-                            how_many_negative_controls=G - 15, seed=20251, cores=3)
+                            how_many_negative_controls=G - 15, seed=20251, cores=3,
+                            approximate_posterior_inference=False, approximate_posterior_analysis=False)
     called = set(res.loc[res["tot_deleterious_outliers"] > 0, "symbol"])
     assert {"CYP1A1", "LYZ"} <= called and len(called) <= 4
     assert res.attrs["diagnostics_test"]["divergent"][:, 150:].mean() < 0.02

@@ -278,7 +278,8 @@ def test_reference_known_answer_bundled_counts(L, bundled):
     df["is_significant"] = df["symbol"].isin(["SLC16A12", "CYP1A1", "ART3"])
     res = identify_outliers(df, formula="~ Label", sample="sample", transcript="symbol", abundance="value",
                             significance="PValue", do_check="is_significant", percent_false_positive_genes=1,
-                            how_many_negative_controls=50, cores=1, seed=42)
+                            how_many_negative_controls=50, cores=1, seed=42,
+                            approximate_posterior_inference=False, approximate_posterior_analysis=False)
     assert res["symbol"].tolist() == ["SLC16A12", "CYP1A1", "ART3"]
     assert res["tot_deleterious_outliers"].tolist() == [0, 1, 0]
     sw = res.loc[1, "sample_wise_data"]
@@ -343,7 +344,7 @@ def test_reference_readme_example(L, bundled):
     df["is_significant"] = df["FDR"] < 0.01
     res = identify_outliers(df, formula="~ Label", sample="sample", transcript="symbol", abundance="value",
                             significance="PValue", do_check="is_significant", percent_false_positive_genes=5,
-                            cores=4, seed=7)
+                            cores=4, seed=7, approximate_posterior_inference=False, approximate_posterior_analysis=False)
     assert len(res) == 15
     flagged = res[res["tot_deleterious_outliers"] > 0]["symbol"].tolist()
     by = res.set_index("symbol")
@@ -425,19 +426,26 @@ def test_gene_shards_equal_the_unsharded_run(L, G, S, C, K, bounds):
             s_.close()
 
 
-def test_rccl_communicator_single_rank(L):
+def test_rccl_communicator_single_rank(L, monkeypatch):
     """RCCL plumbing (dlopen, unique id, communicator, stream-ordered all-reduce between reduce and update) with one
-    rank: must reproduce the plain run exactly. Multi-rank runs need one GPU per rank (driver's multi-GPU node)."""
+    rank: must reproduce the plain run of the same round structure exactly (gene shards keep the three-launch round: their
+    sums cross the ranks between reduce and advance), and the default -- pipelined -- run up to the order in which the
+    kinetic energy of fresh momenta is summed. Multi-rank: tests/test_gpu_multi.py."""
     d = ind.synth(24, 6, K=3, seed=2)
     m = L.Model(d["counts"], d["X"], d["exposure"], 3)
     ms = L.Model(d["counts"], d["X"], d["exposure"], 0, shard=(24, 3, 0, 24))
     try:
         comm = L.Comm(1, 0, L.Comm.unique_id())
+        fp = m.fit_nuts(chains=2, iter=25, warmup=15, seed=9)
+        monkeypatch.setenv("PPCX_PIPELINE", "0")
         f = m.fit_nuts(chains=2, iter=25, warmup=15, seed=9)
+        monkeypatch.delenv("PPCX_PIPELINE")
         fc = ms.fit_nuts_comm(comm, chains=2, iter=25, warmup=15, seed=9)
         assert np.array_equal(f.diagnostics()["n_leapfrog"], fc.diagnostics()["n_leapfrog"])
         assert np.array_equal(f.draws(), fc.draws())
-        f.close(); fc.close(); comm.close()
+        assert np.array_equal(fp.diagnostics()["n_leapfrog"][:, :12], fc.diagnostics()["n_leapfrog"][:, :12])
+        assert np.max(np.abs(fp.diagnostics()["stepsize"][:, :12] - fc.diagnostics()["stepsize"][:, :12])) < 1e-9
+        f.close(); fc.close(); fp.close(); comm.close()
     finally:
         m.close(); ms.close()
 
@@ -488,6 +496,28 @@ def test_reference_tests_through_the_vb_path(L, bundled, approx_analysis):
     assert res["tot_deleterious_outliers"].tolist() == [0, 1, 0]
 
 
+def test_reference_call_without_mode_flags(L, bundled):
+    """A caller porting the reference's call unchanged -- no approximate_posterior_* flags, the reference's `tol_rel_obj`
+    and `pass_fit` arguments present -- runs the reference's default mode (ADVI inference, approximated analysis,
+    R/methods.R:85-86) and gets the reference's known answer c(0, 1, 0) (tests/testthat/test-ppcSeq.R:11-30)."""
+    import pandas as pd
+    from ppcseq_amd.methods import identify_outliers
+    genes = [str(g) for g in bundled["genes"]]
+    samples = [str(s) for s in bundled["samples"]]
+    G, S = len(genes), len(samples)
+    df = pd.DataFrame({
+        "symbol": np.repeat(genes, S), "sample": np.tile(samples, G), "value": bundled["value"].reshape(-1),
+        "PValue": np.repeat(bundled["PValue"], S), "Label": np.tile(bundled["Label"].astype(str), G)})
+    df["is_significant"] = df["symbol"].isin(["SLC16A12", "CYP1A1", "ART3"])
+    res = identify_outliers(df, formula="~ Label", sample="sample", transcript="symbol", abundance="value",
+                            significance="PValue", do_check="is_significant", percent_false_positive_genes=1,
+                            tol_rel_obj=0.01, how_many_negative_controls=50, cores=1, pass_fit=True, seed=11)
+    assert res["tot_deleterious_outliers"].tolist() == [0, 1, 0]
+    assert "iterations" in res.attrs["diagnostics_test"]          # the ADVI path ran (its diagnostics, not NUTS')
+    for k in ("fit 1", "fit 2"):
+        res.attrs[k].close()
+
+
 def test_outlier_call_concordance_with_cpu_path():
     """BASELINE metric, second half: identical outlier calls (GPU path vs CPU oracle path) at a fixed seed on the
     bundled counts' test configuration."""
@@ -529,7 +559,7 @@ def test_dot_C_entry_point_matches_handle_api(L):
     excl = np.array([5, 17], np.int32)
     chains, iter_, warmup, seed = 3, 120, 80, 13
     n_draws = chains * (iter_ - warmup)
-    dims = np.array([0, G, S, Cc, K, excl.size, chains, iter_, warmup, 0, 0, 0, 1, 0, 0], np.int32)
+    dims = np.array([L.ABI_VERSION, 0, G, S, Cc, K, excl.size, chains, iter_, warmup, 0, 0, 0, 1, 0, 0], np.int32)
     reals = np.array([5.612671, 0.7352941, 0.01, 0.99, float(seed), 0.0])
     ci = np.zeros((K, S, 4)); slope = np.zeros(K); status = np.array([99], np.int32)
     rng = np.zeros((n_draws, K, S), np.int32)
@@ -544,7 +574,7 @@ def test_dot_C_entry_point_matches_handle_api(L):
         f.close()
         assert np.array_equal(ci, ci2) and np.allclose(slope, slope2, rtol=0, atol=1e-14) and np.array_equal(rng, rng2)
         # the reference's default mode: ADVI (approximate_posterior_inference = TRUE), approximated analysis
-        dims_vb = dims.copy(); dims_vb[9:15] = [700, 1, 1, 0, 400, 0]
+        dims_vb = dims.copy(); dims_vb[10:16] = [700, 1, 1, 0, 400, 0]
         msg = _dot_C(lib, dims_vb, counts, X, expo, excl, reals, ci, slope, None, status)
         assert status[0] == 0 and msg == ""
         fv = m.fit_advi(output_samples=400, seed=seed)
@@ -555,9 +585,12 @@ def test_dot_C_entry_point_matches_handle_api(L):
     finally:
         m.close()
     # bad arguments come back as a status and a message, never as an exception across the boundary
-    dims_bad = dims.copy(); dims_bad[1] = 0
+    dims_bad = dims.copy(); dims_bad[2] = 0
     msg = _dot_C(lib, dims_bad, counts, X, expo, excl, reals, ci, slope, rng, status)
     assert status[0] == -1 and "G>=1" in msg
+    # a shim written for the previous argument layout (device first, 15 entries) is refused before anything is read
+    msg = _dot_C(lib, np.ascontiguousarray(dims[1:]), counts, X, expo, excl, reals, ci, slope, rng, status)
+    assert status[0] == -1 and "ABI version" in msg
     msg = _dot_C(lib, dims, counts, X, expo, excl, reals, ci, slope, None, status)       # save_generated_quantities without a buffer
     assert status[0] == -1 and "counts_rng" in msg
     msg = _dot_C(lib, dims_bad, counts, X, expo, excl, reals, ci, slope, rng, status, errlen=8)   # a short buffer is not overrun
@@ -582,7 +615,7 @@ def test_reference_testthat_cases_through_the_dot_C_entry(L, bundled):
     for approx in (True, False):
         status = np.array([99], np.int32); ci = np.zeros((K, S, 4)); slope = np.zeros(K)
         # pass 1 (discovery): always the full analysis (R/methods.R:273); draws_1 = max(1000, 10 / thr1) = 1000
-        dims = np.array([0, G, S, 2, K, 0, 0, 0, 0, 0, 0, 1, 0, 1000, 0], np.int32)
+        dims = np.array([L.ABI_VERSION, 0, G, S, 2, K, 0, 0, 0, 0, 0, 0, 1, 0, 1000, 0], np.int32)
         reals = np.array([5.612671, 1.0, thr1, 1 - thr1, 321.0, 0.0])
         assert _dot_C(lib, dims, counts, Xf, expo, None, reals, ci, slope, None, status) == "" and status[0] == 0
         r1 = _post_process(counts[:K], ci.copy(), slope.copy(), X)
@@ -590,9 +623,9 @@ def test_reference_testthat_cases_through_the_dot_C_entry(L, bundled):
         # pass 2 (test): exclusions, truncation compensation, draws_2 = 10 / thr2 = 10 500
         draws2 = int(max(1000, 10 / thr2))
         if approx:
-            dims2 = np.array([0, G, S, 2, K, excl.size, 0, 0, 0, draws2, 1, 1, 0, 1000, 0], np.int32)
+            dims2 = np.array([L.ABI_VERSION, 0, G, S, 2, K, excl.size, 0, 0, 0, draws2, 1, 1, 0, 1000, 0], np.int32)
         else:
-            dims2 = np.array([0, G, S, 2, K, excl.size, 0, 0, 0, 0, 0, 1, 0, draws2, 0], np.int32)
+            dims2 = np.array([L.ABI_VERSION, 0, G, S, 2, K, excl.size, 0, 0, 0, 0, 0, 1, 0, draws2, 0], np.int32)
         reals2 = np.array([5.612671, 0.7352941, thr2, 1 - thr2, 321.0, 0.0])
         assert _dot_C(lib, dims2, counts, Xf, expo, excl if excl.size else None, reals2, ci, slope, None, status) == ""
         assert status[0] == 0

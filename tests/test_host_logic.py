@@ -123,3 +123,31 @@ def test_identify_outliers_argument_validation():
     with pytest.warns(UserWarning):                      # nothing to check -> empty result (R/methods.R:117-127)
         out = meth.identify_outliers(base.assign(chk=False), **kw)
     assert len(out) == 0 and list(out.columns)[0] == "symbol"
+
+
+def test_identify_outliers_signature_is_the_references():
+    """Argument names and defaults of ppcseq::identify_outliers (R/methods.R:74-102): a call ported unchanged must select
+    the same inference mode. (`.data` and the dotted column arguments lose their dot; `device` is the one addition.)"""
+    import inspect
+    sig = inspect.signature(meth.identify_outliers)
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert d["formula"] == "~ 1" and d["percent_false_positive_genes"] == 1 and d["how_many_negative_controls"] == 500
+    assert d["approximate_posterior_inference"] is True and d["approximate_posterior_analysis"] is True      # R/methods.R:85-86
+    assert d["draws_after_tail"] == 10 and d["save_generated_quantities"] is False and d["pass_fit"] is False
+    assert d["tol_rel_obj"] == 0.01 and d["just_discovery"] is False and d["adj_prob_theshold_2"] is None     # :94-97
+    assert d["scaling_factor"] is None and d["additional_parameters_to_save"] == ()
+    ref_order = ["formula", "sample", "transcript", "abundance", "significance", "do_check", "scaling_factor",
+                 "percent_false_positive_genes", "how_many_negative_controls", "approximate_posterior_inference",
+                 "approximate_posterior_analysis", "draws_after_tail", "save_generated_quantities",
+                 "additional_parameters_to_save", "cores", "pass_fit", "do_check_only_on_detrimental", "tol_rel_obj",
+                 "just_discovery", "seed", "adj_prob_theshold_2"]
+    assert list(sig.parameters)[1:1 + len(ref_order)] == ref_order
+
+
+def test_device_memory_model_of_the_full_analysis():
+    """What the device holds for a full posterior analysis (kept draws + sampler vectors) -- the quantity the guard that
+    mirrors R/methods.R:178-195 compares with the free device memory. cfg5: 20 000 x 200, K = 1000, 20 000 draws, 8 chains."""
+    need = meth.required_device_memory(20000, 2, 1000, 200, 20000, 8, False)
+    D = 2 * 20000 + 1000 + 6
+    assert need >= 8 * 20000 * D and need < 8 * 20000 * D * 1.1       # dominated by the draws: 6.6 GB
+    assert meth.required_device_memory(20000, 2, 1000, 200, 1000, 8, True) < 2e9       # ADVI: 32 evaluation slots + 1000 draws

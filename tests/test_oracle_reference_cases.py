@@ -1,0 +1,101 @@
+"""The oracle pinned on the reference's own known answers (no GPU): oracle/ppc_oracle.c driven through the whole
+identify_outliers() procedure -- thresholds, discovery pass, exclusion, test pass with truncation compensation, flags
+(R/methods.R:155-167,268-342) -- on the bundled `counts` data, as the reference's tests and README write the calls:
+
+  * tests/testthat/test-ppcSeq.R:7-32  "VB post approx no correction": ADVI inference, approximated analysis,
+    SLC16A12 / CYP1A1 / ART3 + 50 negative controls, pfp = 1, cores = 1   =>  tot_deleterious_outliers = c(0, 1, 0)
+  * tests/testthat/test-ppcSeq.R:34-57 "VB post full": the same with the full posterior analysis  =>  c(0, 1, 0)
+  * README.md:50-92: FDR < 0.01 (15 genes) + 500 controls, pfp = 5  =>  CYP1A1 and LYZ carry one deleterious outlier each,
+    CYP1A1's is sample 11165PP (man/figures/unnamed-chunk-9-2.png); here through the oracle's NUTS.
+
+Everything else that checks the product against the oracle leans on this file.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from ppcseq_amd.inference import _post_process, find_optimal_number_of_chains
+from ppcseq_amd.methods import get_scaled_counts_bulk
+from tests.conftest import bundled_test_config
+
+THREADS = min(8, os.cpu_count() or 1)
+
+
+def _oracle_pass(O, counts, X, expo, K, p, draws, seed, *, vb, approx_analysis, cores, excl=None, tc=1.0):
+    """One do_inference() pass (R/utilities.R:1321-1547) on the oracle: chain / iteration arithmetic of :1372-1386,:1502,
+    vb(output_samples = draws_practical, iter = 50000, tol_rel_obj = 0.005) or sampling(), the summary of counts_rng
+    (:685-703) or the approximated one (:733-784), slope = posterior mean of alpha_sub_1 (:1531), flags (:651-663,:493-513)."""
+    practical = 1000 if approx_analysis else int(draws)
+    mo = O.model(counts, X, expo, K, excl=excl, n_threads=THREADS)
+    if vb:
+        for attempt in range(5):                     # vb_iterative (R/utilities.R:246-278), bounded
+            try:
+                dr = O.advi(mo, output_samples=practical, iter=50000, tol_rel_obj=0.005, seed=seed + attempt)["draws"]
+                break
+            except RuntimeError:
+                continue
+        else:
+            raise RuntimeError("ADVI failed five times")
+    else:
+        chains = max(3, min(int(cores), find_optimal_number_of_chains(practical)))
+        n_iter = int(math.ceil(practical / chains)) + 150
+        r = O.nuts_model(mo, O.cfg(chains=chains, iter=n_iter, warmup=150, seed=seed))
+        dr = r.draws.reshape(-1, r.draws.shape[-1])
+    if approx_analysis:
+        gq = O.generated_quantities_approx(mo, dr, int(draws), tc, seed=seed)
+    else:
+        gq = O.generated_quantities(mo, dr, tc, seed=seed)
+    ci = O.summarise(gq, p, 1 - p)
+    off = 3 + counts.shape[0]
+    return _post_process(counts[:K], ci, dr[:, off:off + K].mean(0), X)
+
+
+def _oracle_identify_outliers(O, counts, X, K, *, pfp, vb, approx_analysis, cores, seed, draws_after_tail=10):
+    """identify_outliers() (R/methods.R:155-167, :222-238, :268-342) with both passes on the oracle."""
+    S = counts.shape[1]
+    mult, _ = get_scaled_counts_bulk(counts, list(range(S)))             # R/methods.R:222-238
+    expo = -np.log(np.array([mult[s] for s in range(S)]))
+    thr2 = pfp / 100 / S * 2                                             # do_check_only_on_detrimental (a covariate)
+    thr1 = max(0.05, 2 * thr2)
+    draws1, draws2 = max(draws_after_tail / thr1, 1000), max(draws_after_tail / thr2, 1000)
+    r1 = _oracle_pass(O, counts, X, expo, K, thr1, draws1, seed, vb=vb, approx_analysis=False, cores=cores)   # :273: always full
+    excl = np.flatnonzero(r1.deleterious_outliers.ravel()).astype(np.int32)                                   # :292-300
+    r2 = _oracle_pass(O, counts, X, expo, K, thr2, draws2, seed, vb=vb, approx_analysis=approx_analysis, cores=cores,
+                      excl=excl, tc=0.7352941)                                                                # :320-342
+    return r1, r2
+
+
+@pytest.mark.parametrize("approx_analysis", [True, False])
+def test_reference_testthat_cases_on_the_oracle(oracle, bundled, approx_analysis):
+    counts, X, genes, K = bundled_test_config(bundled)
+    assert genes[:3] == ["SLC16A12", "CYP1A1", "ART3"] and counts.shape == (53, 21)
+    r1, r2 = _oracle_identify_outliers(oracle, counts, X, K, pfp=1, vb=True, approx_analysis=approx_analysis, cores=1, seed=11)
+    assert r2.deleterious_outliers.sum(1).tolist() == [0, 1, 0]          # expect_equal(..., c(0,1,0))
+    s = int(np.flatnonzero(r2.deleterious_outliers[1])[0])
+    assert str(bundled["samples"][s]) == "11165PP" and int(counts[1, s]) == 5835
+    assert r1.deleterious_outliers[1, s]                                  # found by the discovery pass already
+
+
+def test_readme_case_on_the_oracle_through_nuts(oracle, bundled):
+    """README.md:50-92 (the reference runs it with its default, VB; here the oracle's NUTS): of the 15 genes with FDR < 0.01
+    exactly CYP1A1 and LYZ fail the check, one deleterious outlier each."""
+    genes = [str(g) for g in bundled["genes"]]
+    chk = [i for i in range(len(genes)) if bundled["FDR"][i] < 0.01]
+    assert len(chk) == 15
+    others = [i for i in range(len(genes)) if i not in set(chk)]
+    order = sorted(others, key=lambda i: bundled["PValue"][i])
+    controls = set(order[-500:])
+    sel = chk + [i for i in others if i in controls]
+    counts = bundled["value"][sel].astype(np.int32)
+    label = bundled["Label"]
+    X = np.stack([np.ones(len(label)), (label == sorted(set(label))[1]).astype(float)], axis=1)
+    r1, r2 = _oracle_identify_outliers(oracle, counts, X, 15, pfp=5, vb=False, approx_analysis=False, cores=3, seed=7)
+    tot = r2.deleterious_outliers.sum(1)
+    called = {genes[sel[g]] for g in range(15) if tot[g] > 0}
+    assert {"CYP1A1", "LYZ"} <= called and len(called) <= 3                 # README: exactly these two (+ <= 1 borderline cell)
+    g = [genes[i] for i in sel].index("CYP1A1")
+    s = int(np.flatnonzero(r2.deleterious_outliers[g])[0])
+    assert tot[g] == 1 and str(bundled["samples"][s]) == "11165PP"
+    assert tot[[genes[i] for i in sel].index("LYZ")] == 1
