@@ -6,7 +6,9 @@ A "step" is one complete fit -- Stan-default warm-up (150) + kept draws for ever
 on the synthetic 20,000 genes x 200 samples matrix of BASELINE config 3, inputs already resident in
 HBM. `value` = sum over steps of the pooled bulk-ESS (min over the six hyper-parameters and lp__) divided
 by the summed wall time (barrier + device synchronise on both sides, max over ranks). Chains are the
-sharded unit (weak scaling: chains/GPU fixed); there is no collective on the data path.
+sharded unit (weak scaling: chains/GPU fixed); there is no collective on the data path. The timed fits run the
+library's defaults (pipelined rounds, two chain groups on their own streams); the `roofline` sample comes from one
+more fit on a single in-order stream, where HIP events around a launch time that launch alone.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -43,8 +45,12 @@ def main():
                          "genes partitioned over GPUs with an RCCL all-reduce of the partial sums every leapfrog (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--stream-group-steps", type=int, default=1,
-                    help="extra fits with PPCX_STREAM_GROUPS=3, reported beside the headline (0 = skip)")
+    ap.add_argument("--stream-groups", type=int, default=0,
+                    help="chain groups on their own streams for the timed fits (0 = the library's default: 2 from six chains on)")
+    ap.add_argument("--single-stream-steps", type=int, default=1,
+                    help="fits on ONE in-order stream (PPCX_STREAM_GROUPS=1) after the timed ones: the source of the roofline's "
+                         "per-launch timings, reported beside the headline (0 = skip: no roofline object)")
+    ap.add_argument("--no-ppc", action="store_true", help="skip the posterior-predictive kernel's object")
     ap.add_argument("--as-named-steps", type=int, default=1,
                     help="fits of the configuration AS BASELINE cfg3 names it (1 chain per GPU), reported beside the headline "
                          "(0 = skip); outside the timed region of the headline")
@@ -108,6 +114,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.stream_groups > 0:
+        os.environ["PPCX_STREAM_GROUPS"] = str(args.stream_groups)
+
     def one_fit(step_seed):
         if comm is not None:                   # every rank runs the same chains on its genes
             return model.fit_nuts_comm(comm, chains=nch, iter=n_iter, warmup=args.nuts_warmup, seed=step_seed)
@@ -120,6 +129,7 @@ def main():
 
     tot_time, tot_ess, tot_grad = 0.0, 0.0, 0
     kA_ms, kA_n, kA_chains = 0.0, 0, 0.0
+    ppc_obj, rounds_last, single_kt = None, 0, None
     ess_detail, depth_mean, div_total = None, [], 0
     for k in range(args.steps):
         barrier()
@@ -150,11 +160,16 @@ def main():
         ess_detail = per
         tot_time += dt
         tot_grad += int(ge.sum())
-        kA_ms += tm.gene_kernel_ms_mean * tm.gene_kernel_samples
-        kA_n += tm.gene_kernel_samples
-        kA_chains += tm.gene_kernel_chain_launches_mean * tm.gene_kernel_samples
+        if args.mode == "shards":              # one stream there: the timed fits' own launch timings
+            kA_ms += tm.gene_kernel_ms_mean * tm.gene_kernel_samples
+            kA_n += tm.gene_kernel_samples
+            kA_chains += tm.gene_kernel_chain_launches_mean * tm.gene_kernel_samples
         depth_mean.append(float(dg["treedepth"].mean()))
         div_total += int(dg["divergent"][:, args.nuts_warmup:].sum())
+        rounds_last = kt["launch_triples"]
+        # the posterior-predictive kernel on this fit's draws (outside the timed region; rank 0, last step)
+        if rank == 0 and k == args.steps - 1 and not args.no_ppc and args.mode == "chains":
+            ppc_obj = ppc_object(fit, K, S, C)
         fit.close()
 
     launch_used = model.get_launch()           # (lanes per gene, workgroups) of the timed fits' log-likelihood launches
@@ -182,15 +197,15 @@ def main():
         as_named = {"chains_per_gpu": 1, "chains_total": world, "value": round(ess_an / t_an, 3), "unit": "ESS/s",
                     "ms_per_step": round(1e3 * t_an / args.as_named_steps, 2), "steps": args.as_named_steps}
 
-    # The same fit with the chains in three groups on their own streams (PPCX_STREAM_GROUPS=3): one group's log-likelihood
-    # launch overlaps the other groups' latency-bound close / step kernels. Reported beside the headline, not as `value`:
-    # the headline keeps one in-order stream, on which the per-kernel timings of `roofline` are clean.
-    grouped = None
-    if args.mode == "chains" and args.stream_group_steps > 0 and nch >= 3:
-        os.environ["PPCX_STREAM_GROUPS"] = "3"
+    # The same fit on ONE in-order stream: HIP events around a launch then time that launch alone, which is what the
+    # roofline object needs (with chain groups on several streams another group's kernels run inside the bracket).
+    single = None
+    if args.mode == "chains" and args.single_stream_steps > 0:
+        prev = os.environ.get("PPCX_STREAM_GROUPS")
+        os.environ["PPCX_STREAM_GROUPS"] = "1"
         try:
             t_g, ess_g = 0.0, 0.0
-            for k in range(args.stream_group_steps):
+            for k in range(args.single_stream_steps):
                 barrier()
                 t0 = time.perf_counter()
                 fg = one_fit(1 + k)
@@ -199,16 +214,24 @@ def main():
                 if dist_on:
                     dt = D.max_over_ranks(dt, device=dev)
                 hypg, lpg = fg.columns(hyper_cols), fg.diagnostics()["lp"]
+                tmg, single_kt = fg.timing(), fg.kernel_times()
                 fg.close()
+                kA_ms += tmg.gene_kernel_ms_mean * tmg.gene_kernel_samples
+                kA_n += tmg.gene_kernel_samples
+                kA_chains += tmg.gene_kernel_chain_launches_mean * tmg.gene_kernel_samples
                 if dist_on:
                     hypg = D.all_gather_chains(hypg, device=dev)
                     lpg = D.all_gather_chains(lpg, device=dev)
                 ess_g += float(np.nanmin([ess_bulk(hypg[:, :, j]) for j in range(6)] + [ess_bulk(lpg)]))
                 t_g += dt
-            grouped = {"stream_groups": 3, "chains_total": nch * world, "value": round(ess_g / t_g, 3), "unit": "ESS/s",
-                       "ms_per_step": round(1e3 * t_g / args.stream_group_steps, 2), "steps": args.stream_group_steps}
+            single = {"stream_groups": 1, "chains_total": nch * world, "value": round(ess_g / t_g, 3), "unit": "ESS/s",
+                      "ms_per_step": round(1e3 * t_g / args.single_stream_steps, 2), "steps": args.single_stream_steps,
+                      "kernel_ms": {k: round(v, 5) for k, v in single_kt.items()}}
         finally:
-            del os.environ["PPCX_STREAM_GROUPS"]
+            if prev is None:
+                del os.environ["PPCX_STREAM_GROUPS"]
+            else:
+                os.environ["PPCX_STREAM_GROUPS"] = prev
 
     if rank == 0:
         E = 0
@@ -220,15 +243,18 @@ def main():
             if args.mode == "shards":
                 b_grad = b_grad / world              # each rank streams its share of the genes
             achieved = b_grad * chains_per_launch / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "ppcx_loglik_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
+            piped = os.environ.get("PPCX_PIPELINE", "1") != "0" and args.mode == "chains"
+            roof = {"bound": "hbm", "kernel": "ppcx_ls_kernel" if piped else "ppcx_loglik_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(chains_per_launch), "fp64_issue": issue_profile(),
                     "algorithmic_bytes_per_launch": b_grad * chains_per_launch, "avg_launch_ms": round(ms, 5),
                     "timed_launches": int(kA_n),
+                    "sampled_in": "a fit on one in-order stream (PPCX_STREAM_GROUPS=1) after the timed fits" if args.mode == "chains" else "the timed fits",
                     "note": "achieved = algorithmic bytes (SURVEY 8d: count matrix + coordinates, per chain gradient) x chains per "
-                            "launch / launch time: an effective-throughput figure. The chains of a launch share the count "
-                            "matrix through L2 / Infinity Cache (traffic = FETCH_SIZE + WRITE_SIZE of the PMC passes is far "
-                            "below the algorithmic bytes), and the kernel is bound by fp64 vector issue, not by HBM "
-                            "(profiles/ README: instructions per cell, VALU busy share)."}
+                            "launch / launch time: an effective-throughput figure. ppcx_ls_kernel is the merged launch of a "
+                            "pipelined round: the log-likelihood workgroups of every chain beside the chains' state machines. "
+                            "The chains of a launch share the count matrix through L2 / Infinity Cache (traffic = FETCH_SIZE + "
+                            "WRITE_SIZE of the PMC passes is far below the algorithmic bytes), and the kernel is bound by fp64 "
+                            "vector issue, not by HBM (profiles/ README: instructions per cell, VALU busy share)."}
         cpu = None
         if not args.no_cpu_baseline and world == 1:        # reported at N = 1 only (rank 0's host cores)
             cpu = cpu_baseline(arrays, K, tot_ess, tot_grad, args)
@@ -249,9 +275,12 @@ def main():
                        "ess_median_intercept_sigma_raw_rank0_chains": round(ess_gene_median, 1),
                        "grad_evals": tot_grad, "mean_treedepth": round(float(np.mean(depth_mean)), 2),
                        "divergent_after_warmup": div_total,
-                       "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
+                       "round_structure": ("pipelined: merged log-likelihood / state-machine launch + gene kernel" if os.environ.get("PPCX_PIPELINE", "1") != "0" and args.mode == "chains"
+                                           else "three launches: log-likelihood, close, step + update"),
+                       "stream_groups": args.stream_groups if args.stream_groups > 0 else ("library default (2 from six chains on)" if args.mode == "chains" else 1),
+                       "rounds_last_step_all_groups": int(rounds_last),
                        "us_per_grad_eval_per_chain": round(1e6 * tot_time * world * nch / max(tot_grad, 1), 2)},
-            "roofline": roof, "cpu_baseline": cpu, "as_named_cfg3_one_chain_per_gpu": as_named, "chain_groups_on_streams": grouped,
+            "roofline": roof, "ppc": ppc_obj, "cpu_baseline": cpu, "as_named_cfg3_one_chain_per_gpu": as_named, "single_stream": single,
             "concordance": None if (args.no_cpu_baseline or world > 1) else outlier_concordance(),
         }
         print(json.dumps(out))
@@ -292,10 +321,49 @@ def issue_profile():
     try:
         with open(files[-1]) as fh:
             p = json.load(fh)
-        return {k: p[k] for k in ("vector_insts_per_cell_iteration", "vector_pipes_busy_frac_at_sustained_clock",
-                                  "sustained_clock_ghz_under_fp64_fma", "frac_of_cell_arithmetic_ceiling") if k in p} | {"profile": os.path.basename(files[-1])}
+        out = {k: p[k] for k in ("vector_insts_per_cell_iteration", "vector_pipes_busy_frac_at_sustained_clock",
+                                 "sustained_clock_ghz_under_fp64_fma", "frac_of_cell_arithmetic_ceiling") if k in p} | {"profile": os.path.basename(files[-1])}
+        # the counters belong to the kernel sources they were taken on: say so when those have changed since
+        out["kernel_sources_sha16"] = p.get("kernel_sources_sha16")
+        out["stale"] = p.get("kernel_sources_sha16") != kernel_sources_sha16()
+        return out
     except Exception:
         return None
+
+
+def kernel_sources_sha16():
+    """Hash of the HIP sources the log-likelihood kernel is built from (recorded in profiles/rNN_loglik_issue.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ppcx_math.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h", "ppcx_kernels.h", "ppcx_kernels.hip"):
+        with open(os.path.join(ROOT, "ppcseq_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def ppc_object(fit, K, S, C):
+    """The posterior-predictive kernel (inst/stan/negBinomial_MPI.stan:259-266 + the summary of R/utilities.R:685-703) on the
+    kept draws of a timed fit: every checked cell (K x S) draws one negative-binomial count per kept posterior draw, keeps
+    them in LDS and reduces them to mean / sd / two type-7 quantiles. Algorithmic bytes per posterior draw:
+    4 S K (the counts_rng the reference materialises) + 8 (S + K (C + 1)) (exposure and the K-slice of the parameters)."""
+    n_draws = fit.chains * fit.n_keep
+    fit.ppc(1.0, 0.025, 0.975, seed=1)                               # warm-up launch (code objects, clocks)
+    ms = []
+    for _ in range(3):
+        fit.ppc(1.0, 0.025, 0.975, seed=1)
+        ms.append(fit.ppc_timing()[0])
+    t = min(ms) * 1e-3
+    nb = fit.ppc_timing()[1]
+    b_draw = 4.0 * S * K + 8.0 * (S + K * (C + 1))
+    achieved = b_draw * n_draws / t / 1e9
+    return {"kernel": "ppcx_ppc_kernel", "workload": f"{K} checked genes x {S} samples x {n_draws} kept draws of the timed fit",
+            "nb_draws": int(nb), "kernel_ms": round(1e3 * t, 3), "nb_draws_per_s": round(nb / t, 1),
+            "algorithmic_bytes_per_posterior_draw": b_draw, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 6), "bound": "alu",
+            "note": "not memory bound: a negative-binomial draw is a Philox block, a Marsaglia-Tsang gamma and a Knuth / PTRS Poisson "
+                    "(rejection loops, log / exp / sqrt / lgamma) -- a few hundred fp64 instructions against 4 bytes; the draws never "
+                    "leave LDS unless save_generated_quantities asks for them, so the 4 S K bytes of the reference's counts_rng are "
+                    "not written at all (profiles/ README: instruction and traffic counters of this kernel)"}
 
 
 def outlier_concordance():
@@ -348,14 +416,16 @@ def outlier_concordance():
 
 
 def cpu_baseline(arrays, K, gpu_ess, gpu_grad, args):
-    """The oracle (CPU restatement, Stan-equivalent, NOT rstan: no R/Stan on this box) timed on this host on a bounded sample
-    of the same workload: the first gradient evaluations of chain 0's warm-up (init, step-size search, first NUTS
-    iterations), OpenMP threads over gene shards (mirrors map_rect / STAN_NUM_THREADS, R/utilities.R:1383-1386,1479), built
-    -O3 -march=native. A whole fit is 8 chains x 400 iterations, about 3e5 gradient evaluations = half a day here, so the
-    figure is an EXTRAPOLATION: gradient evaluations per second of the sample x the effective samples per gradient
-    evaluation measured on the GPU run of the same algorithm, seeds and estimator. It is a port of this repository, not
-    the reference's Stan build; the ratio to `value` says nothing about Stan itself."""
-    from oracle.oracle import Oracle
+    """Two CPU comparators timed on this host on a bounded sample of the same workload -- gradient evaluations of the
+    20 000 x 200 model at a fixed point for about --cpu-seconds in total, OpenMP threads over genes (mirrors map_rect /
+    STAN_NUM_THREADS, R/utilities.R:1383-1386,1479), built -O3 -march=native:
+      "port"            the oracle, a literal restatement of the Stan program (libm lgamma, series digamma, log1p_exp per cell);
+      "port-optimised"  the product's own formulation compiled for the host (oracle/cpu_fast.cpp: sufficient statistics, one
+                        table logarithm and one reciprocal per cell, Stirling tails) -- the faster one, quoted as `value`.
+    Neither is rstan (no R / Stan on this box). A whole fit is ~3e5 gradient evaluations, so `value` is an EXTRAPOLATION:
+    gradient evaluations per second x the effective samples per gradient evaluation of the GPU run (same algorithm, seeds
+    and estimator)."""
+    from oracle.oracle import CpuFast, Oracle
     try:
         O = Oracle(native=True)
         build = "-O3 -march=native"
@@ -367,32 +437,53 @@ def cpu_baseline(arrays, K, gpu_ess, gpu_grad, args):
         cores = min(len(os.sched_getaffinity(0)), 16)
     except AttributeError:
         cores = min(os.cpu_count() or 1, 16)
-    m = O.model(arrays["counts"], arrays["X"], arrays["exposure"], K, n_threads=cores)
-    u = np.zeros(O.dim(m.G, m.C, m.K))
-    O.log_prob_grad(m, u)                                        # page the matrix in
-    t0 = time.perf_counter()
-    for _ in range(3):
-        O.log_prob_grad(m, u)
-    t_one = (time.perf_counter() - t0) / 3
-    n_leap = max(8, int(args.cpu_seconds / max(t_one, 1e-3)))
-    cfg = O.cfg(chains=1, iter=args.nuts_warmup + args.draws_per_chain, warmup=args.nuts_warmup, seed=1,
-                max_leapfrogs_total=n_leap)
-    t0 = time.perf_counter()
-    r = O.nuts_model(m, cfg)
-    dt = time.perf_counter() - t0
-    done = int(r.iters_done[0])
-    leap = int(r.n_leapfrog[0, :done].sum()) + 2 * done + 4       # + init_stepsize / init evaluations (approx.)
-    rate = leap / dt
+    counts, X, expo = arrays["counts"], arrays["X"], arrays["exposure"]
+    G, S = counts.shape
+    cells = float(G) * S
     ess_per_grad = gpu_ess / max(gpu_grad, 1)
-    cells = float(m.G) * m.S
-    return {"value": round(rate * ess_per_grad, 5), "unit": "ESS/s", "cores": cores, "kind": "port",
-            "grad_evals_per_s": round(rate, 3), "ns_per_cell_per_thread": round(1e9 * cores / (rate * cells), 1),
-            "seconds_sampled": round(dt, 1), "grad_evals_sampled": leap, "build": build,
-            "extrapolated": True,
-            "sample": f"first {leap} gradient evaluations ({done} NUTS warm-up iterations after init and step-size search) of chain 0 "
-                      f"on the same {m.G}x{m.S} matrix, {cores} OpenMP threads over genes, {dt:.1f} s; value = gradient evaluations "
-                      f"per second x ESS per gradient evaluation of the GPU run (same algorithm, seeds and estimator). CPU "
-                      f"restatement of this repository (Stan-equivalent), not rstan."}
+    budget = max(float(args.cpu_seconds), 2.0) / 2.0
+
+    def rate(fn):
+        fn()                                                     # page the matrix in
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            fn()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget:
+                return n / dt, n, dt
+
+    m = O.model(counts, X, expo, K, n_threads=cores)
+    u = np.zeros(O.dim(m.G, m.C, m.K))
+    u[3:3 + G] = 5.0
+    r_port, n_port, t_port = rate(lambda: O.log_prob_grad(m, u))
+    lp_port, g_port = O.log_prob_grad(m, u)
+    fast = None
+    try:
+        F = CpuFast()
+        mf = F.model(counts, X, expo, K)
+        r_fast, n_fast, t_fast = rate(lambda: F.log_prob_grad(mf, u, threads=cores))
+        lp_fast, g_fast = F.log_prob_grad(mf, u, threads=cores)
+        F.free(mf)
+        fast = {"grad_evals_per_s": round(r_fast, 3), "ns_per_cell_per_thread": round(1e9 * cores / (r_fast * cells), 2),
+                "grad_evals_sampled": n_fast, "seconds_sampled": round(t_fast, 1), "value": round(r_fast * ess_per_grad, 5),
+                "agrees_with_port": {"lp_rel": float(abs(lp_fast - lp_port) / abs(lp_port)),
+                                     "grad_rel_max": float(np.max(np.abs(g_fast - g_port) / (1 + np.abs(g_port))))}}
+    except Exception as e:                                       # no g++ / OpenMP on the box: the literal port alone
+        fast = {"error": repr(e)}
+    port = {"grad_evals_per_s": round(r_port, 3), "ns_per_cell_per_thread": round(1e9 * cores / (r_port * cells), 1),
+            "grad_evals_sampled": n_port, "seconds_sampled": round(t_port, 1), "value": round(r_port * ess_per_grad, 5)}
+    best_kind = "port-optimised" if "value" in fast else "port"
+    best = fast if "value" in fast else port
+    return {"value": best["value"], "unit": "ESS/s", "cores": cores, "kind": best_kind, "build": build, "extrapolated": True,
+            "grad_evals_per_s": best["grad_evals_per_s"], "ns_per_cell_per_thread": best["ns_per_cell_per_thread"],
+            "port": port, "port_optimised": fast,
+            "sample": f"gradient evaluations of the same {G}x{S} model at a fixed point, {cores} OpenMP threads over genes: "
+                      f"{port['grad_evals_sampled']} by the literal port in {port['seconds_sampled']} s"
+                      + (f", {fast['grad_evals_sampled']} by the optimised comparator in {fast['seconds_sampled']} s" if "value" in fast else "")
+                      + "; value = gradient evaluations per second x ESS per gradient evaluation of the GPU run (same algorithm, seeds "
+                        "and estimator). CPU restatements of this repository (Stan-equivalent), not rstan."}
 
 
 if __name__ == "__main__":

@@ -117,6 +117,9 @@ PPCX_API int ppcx_fit_get_kernel_times(ppcx_fit* f, double* loglik_ms, double* c
  * n_gen = 0 means one predictive draw per kept posterior draw.                                      */
 PPCX_API int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double p_lo, double p_hi,
                  unsigned long long seed, int n_gen, int resample, double* ci, int32_t* counts_rng);
+/* duration (ms, HIP events) of the posterior-predictive kernel of the last ppcx_fit_ppc call and the negative-binomial
+ * draws it generated (n_gen x K x S)                                                                                   */
+PPCX_API int ppcx_fit_get_ppc_timing(ppcx_fit* f, double* kernel_ms, long long* nb_draws);
 PPCX_API void ppcx_fit_free(ppcx_fit* f);
 
 /* R .C() convention (all pointers, void return; character vectors arrive as char**): one do_inference() pass end to end --

@@ -178,3 +178,41 @@ class Oracle:
         self.lib.ppco_summarise(_p(x, C.c_int32), C.c_int(nd), C.c_int(ncell), C.c_double(p_lo), C.c_double(p_hi),
                                 _p(out, C.c_double))
         return out.reshape(x.shape[1:] + (4,))
+
+
+class CpuFast:
+    """BENCH / TEST INFRASTRUCTURE: optimised CPU comparator (oracle/cpu_fast.cpp) -- the product's formulation of the
+    log density and gradient compiled for the host (-O3 -march=native, OpenMP over genes). Loaded only by bench.py's
+    cpu_baseline leg and by tests/."""
+
+    def __init__(self):
+        path = os.path.join(_HERE, "libppc_cpu_fast.so")
+        src = os.path.join(_HERE, "cpu_fast.cpp")
+        hdr_dir = os.path.join(os.path.dirname(_HERE), "ppcseq_amd", "csrc")
+        deps = [src] + [os.path.join(hdr_dir, h) for h in ("ppcx_math.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h")]
+        if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(p) for p in deps):
+            subprocess.check_call(["make", "-C", _HERE, "fast"], stdout=subprocess.DEVNULL)
+        self.lib = C.CDLL(path)
+        self.lib.ppcf_model_create.restype = C.c_void_p
+        self.lib.ppcf_model_create.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]
+        self.lib.ppcf_model_destroy.argtypes = [C.c_void_p]
+        self.lib.ppcf_dim.argtypes = [C.c_void_p]
+        self.lib.ppcf_log_prob_grad.restype = C.c_double
+        self.lib.ppcf_log_prob_grad.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+
+    def model(self, counts, X, exposure, K, lambda_mu_mu=5.612671):
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        G, S = counts.shape
+        X = np.asfortranarray(np.asarray(X, dtype=np.float64).reshape(S, -1))
+        exposure = np.ascontiguousarray(exposure, dtype=np.float64)
+        return self.lib.ppcf_model_create(G, S, X.shape[1], int(K), _p(counts, C.c_int32), _p(X, C.c_double),
+                                          _p(exposure, C.c_double), float(lambda_mu_mu))
+
+    def log_prob_grad(self, m, u, threads=1, want_grad=True):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        g = np.zeros_like(u) if want_grad else None
+        lp = self.lib.ppcf_log_prob_grad(m, _p(u, C.c_double), _p(g, C.c_double), int(threads))
+        return float(lp), g
+
+    def free(self, m):
+        self.lib.ppcf_model_destroy(m)

@@ -21,7 +21,7 @@ EXPORTS = [
     "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_bench_gene_kernel",
     "ppcx_model_create_shard", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
     "ppcx_fit_nuts_comm", "ppcx_advi_config_default", "ppcx_fit_advi", "ppcx_fit_advi_info", "ppcx_fit_advi_iterative",
-    "ppcx_guard_decision", "ppcx_device_memory",
+    "ppcx_guard_decision", "ppcx_device_memory", "ppcx_fit_get_ppc_timing",
 ]
 ABI_VERSION = 300           # include/ppcx.h PPCX_VERSION this binding was written for
 
@@ -62,6 +62,7 @@ def load() -> C.CDLL:
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     lib.ppcx_guard_decision.argtypes = [dp, C.c_int]
     lib.ppcx_device_memory.argtypes = [C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.ppcx_fit_get_ppc_timing.argtypes = [C.c_void_p, dp, C.POINTER(C.c_longlong)]
     lib.ppcx_last_error.restype = C.c_char_p
     lib.ppcx_model_create.argtypes = [C.c_int] * 5 + [ip, dp, dp, C.c_double, C.c_int, ip, C.POINTER(C.c_void_p)]
     lib.ppcx_model_set_exclusions.argtypes = [C.c_void_p, C.c_int, ip]
@@ -330,6 +331,12 @@ class Fit:
         el, et = C.c_double(), C.c_double()
         _check(load().ppcx_fit_advi_info(self._h, C.byref(it), C.byref(cv), C.byref(el), C.byref(et)))
         return dict(iterations=it.value, converged=bool(cv.value), elbo=el.value, eta=et.value)
+
+    def ppc_timing(self):
+        """(kernel ms, NB draws) of the last ppc() call on this fit."""
+        ms, n = C.c_double(), C.c_longlong()
+        _check(load().ppcx_fit_get_ppc_timing(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, int(n.value)
 
     def kernel_times(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()

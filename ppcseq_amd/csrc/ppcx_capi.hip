@@ -38,7 +38,7 @@ struct ppcx_model {
   int nblocks_chosen = 0;                      // workgroups of the last planned launch (what ppcx_model_get_launch reports)
   // gene order of the log-likelihood launch (upload_counts): per position, the length of the gene's low-count list
   // and whether it has slopes -- what a pass of a wavefront costs (plan_launch)
-  std::vector<int> pos_low; std::vector<char> pos_slope;
+  std::vector<int> pos_low; std::vector<char> pos_slope, pos_tier;
   struct Plan { int nbpc = 0; int* d_bounds = nullptr; };
   std::map<std::pair<int, int>, Plan> plans;   // (chains in the launch, resident workgroups it may use) -> ranges
   std::mutex plan_mutex;
@@ -67,6 +67,7 @@ struct ppcx_fit {
   double kA_ms_mean = 0; long long kA_samples = 0; double kA_chain_launches_mean = 0;
   double kC_ms_mean = 0, kU_ms_mean = 0; long long launch_triples = 0;
   double advi_elbo = 0, advi_eta = 0; int advi_converged = 0;
+  double ppc_ms = 0; long long ppc_draws = 0;  // last ppcx_fit_ppc: kernel time (HIP events) and NB draws generated
 };
 
 extern "C" int ppcx_version(void) { return PPCX_VERSION; }
@@ -98,9 +99,12 @@ extern "C" int ppcx_device_memory(int device, unsigned long long* free_bytes, un
 //   cost crosses j / (wavefronts per chain) of the total; recomputed when chains finish and the others get their slots.
 static double pass_cost(const ppcx_model* m, int L, int p, int n) {
   const int S = m->d.S;
-  int lowmax = 0; bool slope = false;
-  for (int i = p; i < p + n; ++i) { if (m->pos_low[i] > lowmax) lowmax = m->pos_low[i]; slope = slope || m->pos_slope[i]; }
-  const double sweep = (double)((S + L - 1) / L) * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? 1.15 : 1.0));
+  int lowmax = 0, tier = 2; bool slope = false;
+  for (int i = p; i < p + n; ++i) { if (m->pos_low[i] > lowmax) lowmax = m->pos_low[i]; slope = slope || m->pos_slope[i]; if (m->pos_tier[i] < tier) tier = m->pos_tier[i]; }
+  // a pass of plain genes that all allow shorter Stirling tails saves 4 (tier 1) or 6 (tier 2) of the ~44 instructions of a cell-iteration
+  static const bool ignore_tiers = getenv("PPCX_PLAN_IGNORE_TIERS") != nullptr;     // development aid
+  const double tail = (slope || ignore_tiers) ? 1.0 : (tier >= 2 ? 0.86 : (tier >= 1 ? 0.91 : 1.0));
+  const double sweep = (double)((S + L - 1) / L) * tail * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? 1.15 : 1.0));
   return 5.8 + sweep + 0.75 * (double)((lowmax + L - 1) / L);
 }
 // reserve: workgroups of the same launch that are not log-likelihood workgroups (the state machines of a pipelined
@@ -199,17 +203,22 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
   std::vector<double> Sy(G, 0.0), SyE(G, 0.0), SyX((size_t)C * G, 0.0), SX((size_t)C * G, 0.0), ncell(G, 0.0), Lg1(G, 0.0);
   std::vector<unsigned> low; std::vector<int> low_start(G + 1, 0), nhi(G, 0);
   std::vector<unsigned short> low_m((size_t)G * 8, 0);
+  std::vector<int> tier(G, 0);
   for (int g = 0; g < G; ++g) {
     double sy = 0, sye = 0, nc = 0, lg1 = 0;
+    int ymin = 2147483647;                       // smallest count among the row-sweep cells
     low_start[g] = (int)low.size();
     for (int s = 0; s < S; ++s) {
       const int y = cnt[(size_t)g * S + s];
       if (y < 0) continue;
       sy += y; sye += (double)y * m->expo_host[s]; nc += 1.0; lg1 += lgamma((double)y + 1.0);
-      if (y < kLowCount) { low.push_back(((unsigned)y << 16) | (unsigned)s); for (int k = 0; k < y; ++k) low_m[(size_t)g * 8 + k]++; } else nhi[g]++;
+      if (y < kLowCount) { low.push_back(((unsigned)y << 16) | (unsigned)s); for (int k = 0; k < y; ++k) low_m[(size_t)g * 8 + k]++; } else { nhi[g]++; if (y < ymin) ymin = y; }
       for (int c = 0; c < C; ++c) { SyX[(size_t)c * G + g] += (double)y * m->X_host[(size_t)c * S + s]; SX[(size_t)c * G + g] += m->X_host[(size_t)c * S + s]; }
     }
     Sy[g] = sy; SyE[g] = sye; ncell[g] = nc; Lg1[g] = lg1;
+    tier[g] = tail_tier(ymin);
+    if (getenv("PPCX_NO_TAIL_TIERS")) tier[g] = 0;           // development aid: every pass with the full tails
+    nhi[g] |= tier[g] << 28;                                 // CellData::n_hi
   }
   low_start[G] = (int)low.size();
   low.resize(low.size() + 64, 0u);             // the cell loops request the next entry before testing the range
@@ -230,14 +239,18 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
     std::vector<int> ord(G);
     for (int g = 0; g < G; ++g) ord[g] = g;
     const int K = m->d.K;
+    // ... and then by tail tier, lowest first: a pass evaluates the Stirling tails with the shortest polynomials all of its
+    // genes allow (ppcx_gene.h lane_gene_sums), so genes of one tier should sit together
     std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
       const bool sa = a < K && C >= 2, sb = b < K && C >= 2;
       if (sa != sb) return sa;
-      return low_start[a + 1] - low_start[a] > low_start[b + 1] - low_start[b];
+      const int la = low_start[a + 1] - low_start[a], lb = low_start[b + 1] - low_start[b];
+      if (la != lb) return la > lb;
+      return tier[a] < tier[b];
     });
     HIPCHK(hipMemcpy(m->d_order, ord.data(), sizeof(int) * (size_t)G, hipMemcpyHostToDevice));
-    m->pos_low.resize(G); m->pos_slope.resize(G);
-    for (int p = 0; p < G; ++p) { m->pos_low[p] = low_start[ord[p] + 1] - low_start[ord[p]]; m->pos_slope[p] = ord[p] < K && C >= 2; }
+    m->pos_low.resize(G); m->pos_slope.resize(G); m->pos_tier.resize(G);
+    for (int p = 0; p < G; ++p) { m->pos_low[p] = low_start[ord[p] + 1] - low_start[ord[p]]; m->pos_slope[p] = ord[p] < K && C >= 2; m->pos_tier[p] = (char)tier[ord[p]]; }
     drop_plans(m);
   }
   HIPCHK(hipMemcpy(m->d_counts, cnt.data(), sizeof(int32_t) * cnt.size(), hipMemcpyHostToDevice));
@@ -529,7 +542,31 @@ static int launch_ls(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
 static int launch_gene_round(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
   GeneArgs ga;
   close_args(m, w, &ga.c);
-  ga.draws = io.draws; ga.draws_chain_stride = io.draws_stride; ga.logtab = m->d_logtab; ga.spec = 1;
+  ga.draws = io.draws; ga.draws_chain_stride = io.draws_stride; ga.logtab = m->d_logtab; ga.spec = 1; ga.trace = nullptr;
+#ifdef PPCX_TRACE_GENE
+  // development build: phase timestamps of the gene kernel launches of rounds PPCX_TRACE_ROUND .. + 7, dumped to PPCX_TRACE_FILE
+  static long long* d_tr = nullptr; static long tr_round = -2;
+  if (tr_round == -2) { const char* e = getenv("PPCX_TRACE_ROUND"); tr_round = e ? atol(e) : -1; }
+  const long rel = tr_round >= 0 ? (long)w.launches - tr_round : -1;
+  const size_t per = (size_t)w.nb_close * nchains * 8;
+  if (rel >= 0 && rel < 8) {
+    if (!d_tr) { (void)hipMalloc(&d_tr, sizeof(long long) * per * 8); (void)hipMemset(d_tr, 0, sizeof(long long) * per * 8); }
+    ga.trace = d_tr + per * rel;
+  }
+  if (rel == 40 && d_tr) {
+    std::vector<long long> h(per * 8);
+    (void)hipStreamSynchronize(w.stream);
+    (void)hipMemcpy(h.data(), d_tr, sizeof(long long) * per * 8, hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen(getenv("PPCX_TRACE_FILE") ? getenv("PPCX_TRACE_FILE") : "gene_trace.txt", "w")) {
+      for (size_t r = 0; r < 8; ++r) for (size_t b = 0; b < (size_t)w.nb_close * nchains; ++b) {
+        fprintf(fp, "%zu %zu", r, b);
+        for (int k = 0; k < 8; ++k) fprintf(fp, " %lld", h[(r * (size_t)w.nb_close * nchains + b) * 8 + k]);
+        fprintf(fp, "\n");
+      }
+      fclose(fp);
+    }
+  }
+#endif
   hipError_t e = launch_gene_kernel(m->CM, ga, w.nb_close, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("gene kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
@@ -891,9 +928,12 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   bool piped = m->ls_wgs_per_cu >= 1 && m->d.x0_is_one && (m->d.C < 2 || m->d.K == 0 || m->d.x1_binary);
   if (const char* e = getenv("PPCX_PIPELINE")) if (atoi(e) == 0) piped = false;
   // Chains can also be split into groups that run on their own streams from their own host threads
-  // (PPCX_STREAM_GROUPS=n): while one group sits in its latency-bound kernels another group's log-likelihood
-  // workgroups have the CUs.
-  int ngrp = 1;
+  // (PPCX_STREAM_GROUPS=n): while one group sits in its memory-bound gene kernel another group's log-likelihood
+  // workgroups have the CUs: measured at cfg3 / 8 chains, pipelined rounds: 3.36 s per fit on one stream, 3.13 s with two
+  // groups, 3.11 s with three. Default: two groups from six chains on. A chain's draws do not depend on the grouping
+  // (tests/test_gpu_configs.py); the per-kernel event timings of a fit are only meaningful with one group (bench.py takes
+  // its roofline sample from a fit with PPCX_STREAM_GROUPS=1).
+  int ngrp = nch >= 6 ? 2 : 1;
   if (const char* e = getenv("PPCX_STREAM_GROUPS")) { int v = atoi(e); if (v >= 1) ngrp = v < nch ? v : nch; }
   struct Group { int c0 = 0, n = 0; Work w; RunIO io; PumpStats ps; int rc = PPCX_OK; std::string err; long long leap = 0; };
   std::vector<Group> grp(ngrp);
@@ -1350,6 +1390,12 @@ extern "C" int ppcx_fit_get_kernel_times(ppcx_fit* f, double* loglik_ms, double*
   if (launch_triples) *launch_triples = f->launch_triples;
   return PPCX_OK;
 }
+extern "C" int ppcx_fit_get_ppc_timing(ppcx_fit* f, double* kernel_ms, long long* nb_draws) {
+  if (!f) return fail(PPCX_ERR_ARG, "fit is NULL");
+  if (kernel_ms) *kernel_ms = f->ppc_ms;
+  if (nb_draws) *nb_draws = f->ppc_draws;
+  return PPCX_OK;
+}
 extern "C" int ppcx_fit_get_timing(ppcx_fit* f, double* seconds, long long* grad_evals, double* gene_kernel_ms_mean,
                                    long long* gene_kernel_samples, double* gene_kernel_chain_launches_mean) {
   if (!f) return fail(PPCX_ERR_ARG, "fit is NULL");
@@ -1392,8 +1438,15 @@ extern "C" int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double 
   pa.d = m->d; pa.draws = f->d_draws; pa.n_draws = n_draws; pa.exposure = m->d_expo; pa.X = m->d_X;
   pa.truncation_compensation = truncation_compensation; pa.p_lo = p_lo; pa.p_hi = p_hi; pa.k0 = seed32(seed);
   pa.n_gen = n_gen; pa.resample = resample ? 1 : 0; pa.n_cells = n_cells; pa.ci = d_ci; pa.counts_rng = d_rng; pa.scratch = d_scratch;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
+  if (ev0) (void)hipEventRecord(ev0, m->stream);
   hipError_t e = launch_ppc_kernel(pa, nblocks, m->stream);
+  if (ev1) (void)hipEventRecord(ev1, m->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+  if (e == hipSuccess && ev0 && ev1) { float ms = 0; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { f->ppc_ms = ms; f->ppc_draws = (long long)n_gen * n_cells; } }
+  if (ev0) (void)hipEventDestroy(ev0);
+  if (ev1) (void)hipEventDestroy(ev1);
   if (e == hipSuccess) e = hipMemcpy(ci, d_ci, sizeof(double) * (size_t)n_cells * 4, hipMemcpyDeviceToHost);
   if (e == hipSuccess && counts_rng) e = hipMemcpy(counts_rng, d_rng, sizeof(int) * (size_t)n_gen * n_cells, hipMemcpyDeviceToHost);
   (void)hipFree(d_ci); (void)hipFree(d_rng); (void)hipFree(d_scratch);

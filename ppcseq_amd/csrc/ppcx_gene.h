@@ -90,11 +90,12 @@ struct CellData {                // the chain-independent inputs of the log-like
   const int* counts;             // G x S gene-major, excluded cells = -1
   const unsigned* low;           // the cells with 0 <= count <= 7, gene after gene: (count << 16) | sample
   const int* low_start;          // [G + 1] a gene's range in `low`
-  const int* n_hi;               // [G] number of cells with count >= 8
+  const int* n_hi;               // [G] number of cells with count >= 8 (bits 0..27) and the gene's tail tier (bits 28..29:
+                                 // ppcx_math.h tail_tier of the smallest of those counts)
   const unsigned short* low_m;   // [G][8] entry k < 7: number of list cells with count > k
 };
 
-template <int CM, int L, bool TWO>
+template <int CM, int L, bool TWO, int TAIL = 4>
 PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* sX1, int sub, double A, double A1,
                          const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& acc) {
   const int nmin = S / L;                                  // cells every lane of the gene has
@@ -106,9 +107,9 @@ PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* 
   int k = 0;
 #define PPCX_SWEEP_CELL(Y, E, XB, COND)                                                         \
   if ((COND) && (Y) >= kLowCount) {                                                             \
-    if (TWO) { const double rho_ = cell_eval<CM>(Y, E, (XB) != 0.0 ? A1 : A, gp, tab, acc);     \
+    if (TWO) { const double rho_ = cell_eval<CM, TAIL>(Y, E, (XB) != 0.0 ? A1 : A, gp, tab, acc); \
                acc.Tx[1] = fma(XB, rho_, acc.Tx[1]); }                                          \
-    else (void)cell_eval<CM>(Y, E, A, gp, tab, acc);                                            \
+    else (void)cell_eval<CM, TAIL>(Y, E, A, gp, tab, acc);                                      \
   }
   for (; k + 4 <= nmin; k += 4) {
     const double e0 = q[0], e1 = q[L], e2 = q[2 * L], e3 = q[3 * L];
@@ -195,7 +196,9 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   gp.phi = v.at(V_C0, i_sr); gp.invphi = v.at(V_C1, i_sr); gp.dlt = v.at(V_C2, i_sr); gp.dps = v.at(V_C3, i_sr);
   const double A = v.at(V_C0, d.off_intercept + g) * gp.invphi;       // exp(intercept + sigma_raw)
   const int lo = m.low_start[g], low_n = m.low_start[g + 1] - lo;
-  const double nhi = sub == 0 ? (double)m.n_hi[g] : 0.0;
+  const int nhi_w = m.n_hi[g];
+  const double nhi = sub == 0 ? (double)(nhi_w & 0x0fffffff) : 0.0;
+  const int tier = nhi_w >> 28;                            // wave-uniform use only: the pass takes the shortest tails all its genes allow
   const int* row = m.counts + (long)g * S;
   CellAcc<CM> acc; acc.zero();
   if (GEN) {
@@ -210,7 +213,13 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
         sweep_cells<CM, L, true>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc);
         low_cells<CM, L, true>(m.low + lo, low_n, sE, sX + S, sub, A, A1, gp, tab, acc);
       } else {
-        sweep_cells<CM, L, false>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+#ifdef PPCX_FORCE_TAIL          // development aid (timing only, wrong results): every pass with one tail length
+        (void)tier; sweep_cells<CM, L, false, PPCX_FORCE_TAIL>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+#else
+        if (PPCX_WAVE_ALL(tier >= 2)) sweep_cells<CM, L, false, 1>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+        else if (PPCX_WAVE_ALL(tier >= 1)) sweep_cells<CM, L, false, 2>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+        else sweep_cells<CM, L, false>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+#endif
         low_cells<CM, L, false>(m.low + lo, low_n, sE, sX, sub, A, A, gp, tab, acc);
       }
     }

@@ -46,6 +46,7 @@ struct GeneArgs {
   double* draws; long draws_chain_stride;   // PRE_STORE_DRAW
   const double* logtab;         // log table (global memory), staged in LDS for coord_consts
   int spec;                     // anticipate the next leaf's position (models whose cell paths read the constants only)
+  long long* trace;             // development builds (-DPPCX_TRACE_GENE): [workgroups][8] phase timestamps of one launch, else null
 };
 
 enum StepPhase : int { STEP_REDUCE = 1, STEP_ADVANCE = 2 };

@@ -55,6 +55,14 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
   const int sub = lane & (L - 1), gl = lane >> LG;
   int g_next = a.order[p0 + gl < p1 ? p0 + gl : p1 - 1];
   for (int p = p0; p < p1; p += GPW) {
+#ifdef PPCX_PRIO_BALANCE
+    // the SIMD serves its oldest wavefront first, so its four wavefronts finish one after the other and the last runs
+    // alone, at half the issue rate of dependent fp64 code: a wavefront with more passes left goes first instead
+    {
+      const int rem = (p1 - p + GPW - 1) / GPW;
+      if (rem >= 4) __builtin_amdgcn_s_setprio(3); else if (rem == 3) __builtin_amdgcn_s_setprio(2); else if (rem == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     const bool act = p + gl < p1;                // lanes past the end of the range repeat its last gene and store nothing
     const int g = g_next;
     const int pn = p + GPW + gl;
@@ -559,6 +567,11 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC_FAST) void ppcx_ls_kernel(Logl
   loglik_role<CM, false, true>(a, jb, col, lds);
 }
 
+#ifdef PPCX_TRACE_GENE
+#define PPCX_GT(k) do { if (ga.trace && threadIdx.x == 0) ga.trace[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define PPCX_GT(k) ((void)0)
+#endif
 template <int CM>
 __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gene_kernel(GeneArgs ga) {
   constexpr int NCM = CM + 1;
@@ -567,6 +580,7 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
   __shared__ double s_tab[2 * kLogTabSize];
   const CloseArgs& a = ga.c;
   const int chain = blockIdx.y;
+  PPCX_GT(0);
   const Cmd& c = a.cmds[chain];
   if (c.type == CMD_DONE) return;
   const bool do_update = !c.updated, do_close = c.evaluated && c.type != CMD_FLUSH;      // uniform over the launch's chain
@@ -627,6 +641,7 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
   }
   s_tab[tid] = tab0; s_tab[tid + 256] = tab1;
   __syncthreads();
+  PPCX_GT(1);
   // ---- the command's work on the gene's coordinates
   double T0 = 0.0;
   double* draws = ga.draws ? ga.draws + (long)chain * ga.draws_chain_stride : nullptr;
@@ -639,6 +654,7 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
     if (tid == 0) slab[PT_T0] = ((wacc[0] + wacc[PT_COUNT]) + wacc[2 * PT_COUNT]) + wacc[3 * PT_COUNT];
     return;
   }
+  PPCX_GT(2);
   // ---- close the evaluated position
   x.gp.coef[0] = x.q[0];
 #pragma unroll
@@ -648,6 +664,7 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
   double pn[NCM], gn[NCM], part[10];
   gene_finish_vals<CM>(d, c, v, x, acc, gd, p_cur, minv, part, pn, gn);
   part[PT_T0] = T0;
+  PPCX_GT(3);
   block_accumulate<10>(part, wacc, wave, lane);
   if (c.type == CMD_LEAF) {
     NodeVals nv[NCM];
@@ -677,9 +694,11 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
       for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_top_dots(v, x.idx[j], c.dir, pn[j], minv[j], nv[j], top);
       block_accumulate<6>(top, wacc + PT_TOP, wave, lane);
     }
+    PPCX_GT(4);
     // ahead of the state machine: the constants of the position the next leaf of this subtree direction evaluates
     if (ga.spec) gene_spec_consts<CM>(d, c, v, x, pn, gn, minv, s_tab);
   }
+  PPCX_GT(5);
   __syncthreads();
   const int np = parts_used(c);
   for (int k = tid; k < np; k += 256) {
@@ -687,6 +706,10 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
     const bool used = k < 10 || (k >= PT_DOTS && k < PT_DOTS + 6 * c.n_merge) || (k >= PT_TOP && c.subtree_complete);
     slab[k] = used ? ((wacc[k] + wacc[PT_COUNT + k]) + wacc[2 * PT_COUNT + k]) + wacc[3 * PT_COUNT + k] : 0.0;
   }
+  PPCX_GT(6);
+#ifdef PPCX_TRACE_GENE
+  if (ga.trace && threadIdx.x == 0) ga.trace[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = ((long long)c.type << 32) | ((long long)c.n_merge << 8) | (do_update ? 1 : 0) | (c.subtree_complete ? 2 : 0);
+#endif
 }
 
 // in-process gene shards: every shard ends with the sum over shards (fixed order => identical bits everywhere)

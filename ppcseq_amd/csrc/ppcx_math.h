@@ -140,6 +140,18 @@ PPCX_HD double fast_exp(double x) {
 // interval (scripts/fit/stirling_tails.py, mpmath at 60 digits): maximum absolute error of the double-precision
 // evaluation 3.7e-16 (lg_tail) and 4.9e-16 (dg_tail) over x in [8, 1e6] -- one regime for every x >= 8.
 // ---------------------------------------------------------------------------------------------
+// Shorter polynomials of the same F and G for large arguments (same script, other intervals): degree 2 on x >= 32
+// (maximum absolute error 5.4e-16 / 1.2e-16, the size of the degree-4 polynomials' own error), degree 1 on x >= 256
+// (9.0e-17 / 1.8e-18). The log-likelihood kernel uses them for whole passes of genes whose smallest row-sweep count is
+// that large (ppcx_gene.h lane_gene_sums; the host orders the genes by that tier).
+constexpr int kTailX2 = 32, kTailX1 = 256;
+constexpr double kStirlingF2[3] = {8.33333333333160509e-02, -2.77777745910256493e-03, 7.92780214438562267e-04};
+constexpr double kStirlingG2[3] = {8.33333333332123838e-02, -8.33333110387448305e-03, 3.96216261085104680e-03};
+constexpr double kStirlingF1[2] = {8.33333333333102361e-02, -2.77776566774899170e-03};
+constexpr double kStirlingG1[2] = {8.33333333332178378e-02, -8.33327278343192618e-03};
+// tier of a gene from its smallest count among the row-sweep cells (counts >= 8): 2, 1 or 0
+PPCX_HD int tail_tier(int min_sweep_count) { return min_sweep_count >= kTailX1 ? 2 : (min_sweep_count >= kTailX2 ? 1 : 0); }
+
 PPCX_HD void stirling_tails(double rx, double* lgt, double* dgt) {
   const double r2 = rx * rx;
   double t = fma(r2, 7.72651446721163817e-04, -5.94317590856362882e-04);

@@ -153,7 +153,7 @@ constexpr int kRenormEvery = 8;  // cells between renormalisations: a factor sta
 // one v_fma per Horner step with the coefficient in an SGPR pair (a VOP3 instruction may read one SGPR operand, so the
 // first step's second coefficient sits in a VGPR). v_rcp_f64 is a transcendental-unit instruction: the instruction after it
 // must not read its result (one wait state on gfx940-class chips), hence the independent product update there.
-template <int CM>
+template <int CM, int TAIL>
 __device__ __forceinline__ double cell_big_dev(int y, double e, double A, const GeneParams<CM>& gp, const double* tab,
                                                CellAcc<CM>& a) {
   double yd, w, xf, r2, rx, rho;
@@ -178,7 +178,7 @@ __device__ __forceinline__ double cell_big_dev(int y, double e, double A, const 
   a.Sr += rho;
   a.Px *= xf;
   double t, d;
-  {
+  if (TAIL == 4) {                       // every x >= 8
     const double F3 = -5.94317590856362882e-04, G3 = -4.15672846375406482e-03;
     asm("v_fma_f64 %[t], %[r2], %[F4], %[F3]\n\t"
         "v_fma_f64 %[d], %[r2], %[G4], %[G3]\n\t"
@@ -193,6 +193,21 @@ __device__ __forceinline__ double cell_big_dev(int y, double e, double A, const 
           [F4] "s"(7.72651446721163817e-04), [F2] "s"(7.93645716111539040e-04), [F1] "s"(-2.77777776791245188e-03),
           [F0] "s"(8.33333333333302478e-02), [G4] "s"(6.82627523986508236e-03), [G2] "s"(3.96819926156938719e-03),
           [G1] "s"(-8.33333322714054948e-03), [G0] "s"(8.33333333333001886e-02));
+  } else if (TAIL == 2) {                // x >= kTailX2: degree 2 (ppcx_math.h stirling_tails_short)
+    const double F1 = kStirlingF2[1], G1 = kStirlingG2[1];
+    asm("v_fma_f64 %[t], %[r2], %[F2], %[F1]\n\t"
+        "v_fma_f64 %[d], %[r2], %[G2], %[G1]\n\t"
+        "v_fma_f64 %[t], %[r2], %[t], %[F0]\n\t"
+        "v_fma_f64 %[d], %[r2], %[d], %[G0]"
+        : [t] "=&v"(t), [d] "=&v"(d)
+        : [r2] "v"(r2), [F1] "v"(F1), [G1] "v"(G1),
+          [F2] "s"(kStirlingF2[2]), [F0] "s"(kStirlingF2[0]), [G2] "s"(kStirlingG2[2]), [G0] "s"(kStirlingG2[0]));
+  } else {                               // x >= kTailX1: degree 1
+    const double F0 = kStirlingF1[0], G0 = kStirlingG1[0];
+    asm("v_fma_f64 %[t], %[r2], %[F1], %[F0]\n\t"
+        "v_fma_f64 %[d], %[r2], %[G1], %[G0]"
+        : [t] "=&v"(t), [d] "=&v"(d)
+        : [r2] "v"(r2), [F0] "v"(F0), [G0] "v"(G0), [F1] "s"(kStirlingF1[1]), [G1] "s"(kStirlingG1[1]));
   }
   a.TL = fma(rx, t, a.TL);
   a.TD = fma(r2, d, a.TD);
@@ -223,10 +238,12 @@ __device__ __forceinline__ double cell_big_dev(int y, double e, double A, const 
 
 // One cell of the row sweep (count y >= 8, hence x = y + phi >= 8 for every phi) with e^t = e A: adds the cell to the
 // sums and returns rho = x/(phi w). Straight-line code: one logarithm, one reciprocal, the two tails.
-template <int CM>
+// TAIL: degree of the Stirling-tail polynomials -- 4 for every x >= 8; 2 / 1 for cells known to have x >= kTailX2 / kTailX1
+// (whole passes of genes whose smallest row-sweep count is that large: the host orders the genes accordingly)
+template <int CM, int TAIL = 4>
 PPCX_HD double cell_eval(int y, double e, double A, const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& a) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PPCX_NO_ASM_CELL)
-  return cell_big_dev<CM>(y, e, A, gp, tab, a);
+  return cell_big_dev<CM, TAIL>(y, e, A, gp, tab, a);
 #else
   const double yd = (double)y;
   const double w = fma(e, A, 1.0);
@@ -240,15 +257,24 @@ PPCX_HD double cell_eval(int y, double e, double A, const GeneParams<CM>& gp, co
   a.Sr += rho;
   a.Px *= xf;
   const double r2 = rx * rx;
-  double t = fma(r2, 7.72651446721163817e-04, -5.94317590856362882e-04);     // stirling_tails (ppcx_math.h), fused with the sums
-  t = fma(r2, t, 7.93645716111539040e-04);
-  t = fma(r2, t, -2.77777776791245188e-03);
-  t = fma(r2, t, 8.33333333333302478e-02);
+  double t, dd;
+  if (TAIL == 4) {
+    t = fma(r2, 7.72651446721163817e-04, -5.94317590856362882e-04);     // stirling_tails (ppcx_math.h), fused with the sums
+    t = fma(r2, t, 7.93645716111539040e-04);
+    t = fma(r2, t, -2.77777776791245188e-03);
+    t = fma(r2, t, 8.33333333333302478e-02);
+    dd = fma(r2, 6.82627523986508236e-03, -4.15672846375406482e-03);
+    dd = fma(r2, dd, 3.96819926156938719e-03);
+    dd = fma(r2, dd, -8.33333322714054948e-03);
+    dd = fma(r2, dd, 8.33333333333001886e-02);
+  } else if (TAIL == 2) {
+    t = fma(r2, fma(r2, kStirlingF2[2], kStirlingF2[1]), kStirlingF2[0]);
+    dd = fma(r2, fma(r2, kStirlingG2[2], kStirlingG2[1]), kStirlingG2[0]);
+  } else {
+    t = fma(r2, kStirlingF1[1], kStirlingF1[0]);
+    dd = fma(r2, kStirlingG1[1], kStirlingG1[0]);
+  }
   a.TL = fma(rx, t, a.TL);
-  double dd = fma(r2, 6.82627523986508236e-03, -4.15672846375406482e-03);
-  dd = fma(r2, dd, 3.96819926156938719e-03);
-  dd = fma(r2, dd, -8.33333322714054948e-03);
-  dd = fma(r2, dd, 8.33333333333001886e-02);
   a.TD = fma(0.5, rx, fma(r2, dd, a.TD));
   return rho;
 #endif

@@ -16,7 +16,8 @@ for name, sub in [("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")]:
     for k, (s, n) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
         print(f"{k:60s} dispatches {n:8d}  mean/dispatch {s/max(n,1):14.2f}")
 
-# machine-readable copy for bench.py's roofline.traffic: mean KiB per dispatch of the log-likelihood kernel
+# machine-readable copy for bench.py's roofline.traffic: mean KiB per dispatch of the log-likelihood kernel (the merged
+# launch ppcx_ls_kernel of a pipelined round, or ppcx_loglik_kernel of the three-launch round)
 import json
 res = {}
 for name, sub in [("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")]:
@@ -24,7 +25,7 @@ for name, sub in [("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")]:
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if row.get("Counter_Name") == name and "loglik" in row.get("Kernel_Name", ""):
+                if row.get("Counter_Name") == name and ("ppcx_ls_kernel" in row.get("Kernel_Name", "") or "loglik" in row.get("Kernel_Name", "")):
                     tot += float(row["Counter_Value"]); n += 1
     res[name.lower() + "_kib_per_launch"] = tot / max(n, 1)
     res[name.lower() + "_dispatches"] = n

@@ -33,12 +33,12 @@ static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, c
   m.d.x1_binary = x1b;
   m.Sy.assign(G, 0); m.SyE.assign(G, 0); m.SyX.assign((size_t)C * G, 0); m.SX.assign((size_t)C * G, 0); m.ncell.assign(G, 0); m.Lg1.assign(G, 0);
   m.low_start.assign(G + 1, 0); m.nhi.assign(G, 0); m.low_m.assign((size_t)G * 8, 0);
-  for (int g = 0; g < G; ++g) { m.low_start[g] = (int)m.low.size(); for (int s = 0; s < S; ++s) {
+  for (int g = 0; g < G; ++g) { int ymin = 2147483647; m.low_start[g] = (int)m.low.size(); for (int s = 0; s < S; ++s) {
     int y = m.counts[(size_t)g * S + s]; if (y < 0) continue;
-    if (y < kLowCount) { m.low.push_back(((unsigned)y << 16) | (unsigned)s); for (int k = 0; k < y; ++k) m.low_m[(size_t)g * 8 + k]++; } else m.nhi[g]++;
+    if (y < kLowCount) { m.low.push_back(((unsigned)y << 16) | (unsigned)s); for (int k = 0; k < y; ++k) m.low_m[(size_t)g * 8 + k]++; } else { m.nhi[g]++; if (y < ymin) ymin = y; }
     m.Sy[g] += y; m.SyE[g] += (double)y * expo[s]; m.ncell[g] += 1; m.Lg1[g] += lgamma((double)y + 1.0);
     for (int c = 0; c < C; ++c) { m.SyX[(size_t)c * G + g] += (double)y * X[(size_t)c * S + s]; m.SX[(size_t)c * G + g] += X[(size_t)c * S + s]; }
-  } }
+  } m.nhi[g] |= tail_tier(ymin) << 28; }
   m.low_start[G] = (int)m.low.size();
   m.low.resize(m.low.size() + 64, 0u);
   return m;
