@@ -30,7 +30,7 @@ PPCX_HD void coord_consts(const Dims& d, const VecRef& v, int i, double q, const
     const double phi = fast_exp(-q);
     double dlt, dps;
     stirling_excess(phi, -q, tab, PPCX_WAVE_ANY(phi < 8.0), &dlt, &dps);
-    v.at(V_C0, i) = phi; v.at(V_C1, i) = fast_rcp(phi); v.at(V_C2, i) = dlt; v.at(V_C3, i) = dps;
+    v.at(V_C0, i) = phi; v.at(V_C2, i) = dlt; v.at(V_C3, i) = dps;      // 1/phi: the reader takes fast_rcp(phi) itself (V_C1 is unused)
   } else if (i >= d.off_intercept && i < d.off_sigma_raw) {
     v.at(V_C0, i) = fast_exp(q);
   }
@@ -193,7 +193,8 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   const bool two = has_slopes && d.x0_is_one && d.x1_binary;
   const bool generic = GEN && (!d.x0_is_one || (has_slopes && !two));
   GeneParams<CM> gp;
-  gp.phi = v.at(V_C0, i_sr); gp.invphi = v.at(V_C1, i_sr); gp.dlt = v.at(V_C2, i_sr); gp.dps = v.at(V_C3, i_sr);
+  gp.phi = v.at(V_C0, i_sr); gp.dlt = v.at(V_C2, i_sr); gp.dps = v.at(V_C3, i_sr);
+  gp.invphi = fast_rcp(gp.phi);                             // once per gene and pass: cheaper than a fourth constant in memory
   const double A = v.at(V_C0, d.off_intercept + g) * gp.invphi;       // exp(intercept + sigma_raw)
   const int lo = m.low_start[g], low_n = m.low_start[g + 1] - lo;
   const int nhi_w = m.n_hi[g];
@@ -242,6 +243,7 @@ PPCX_HD void gene_data_load(const Dims& d, int gg, const double* Sy, const doubl
   o.Sy = Sy[gg]; o.SyE = SyE[gg]; o.ncell = ncell[gg]; o.Lg1 = Lg1[gg];
 #pragma unroll
   for (int cc = 0; cc < CM; ++cc) {
+    if (cc == 0 && d.x0_is_one) { o.SyX[0] = o.Sy; o.SX[0] = o.ncell; continue; }     // X[,1] == 1: the same sums, bit for bit
     o.SyX[cc] = (cc < d.C) ? SyXg[(long)cc * d.G + gg] : 0.0;
     o.SX[cc] = (cc < d.C) ? SXg[(long)cc * d.G + gg] : 0.0;
   }
@@ -324,7 +326,7 @@ PPCX_HD void coord_update(const Dims& d, const Cmd& nc, const VecRef& v, int i, 
 template <int CM, bool CACHED = false>
 PPCX_HD void gene_coord_update(const Dims& d, const Cmd& c, const VecRef& v, GeneCtx<CM>& x, double* draws, double* T0,
                                const double* tab, bool consts, const CoordCache* cache = nullptr, double* p_out = nullptr,
-                               double* minv_out = nullptr) {
+                               double* minv_out = nullptr, bool store_p = true) {
   constexpr int NCM = CM + 1;
 #pragma unroll
   for (int j = 0; j < NCM; ++j) {
@@ -339,7 +341,7 @@ PPCX_HD void gene_coord_update(const Dims& d, const Cmd& c, const VecRef& v, Gen
       if (c.type != CMD_FLUSH) {
         if (c.eps != 0.0) {
           kick_drift(cv.q, cv.p, cv.g, c.eps, cv.minv, &ph, &qn);
-          v.at(V_P0 + 3 * c.dir, i) = ph;
+          if (store_p) v.at(V_P0 + 3 * c.dir, i) = ph;       // not when the close that follows overwrites it anyway
           v.at(V_Q0 + 3 * c.dir, i) = qn;
         }
         if (consts) coord_consts(d, v, i, qn, tab);

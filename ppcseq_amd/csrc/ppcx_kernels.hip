@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
     for (int j = 0; j < NCM; ++j) {
       pre[lev][j][0] = pre[lev][j][1] = pre[lev][j][2] = 0.0;
       if (lev < n_pre && j < x.ncoord) {
-        pre[lev][j][0] = v.at(V_LRHO + lev, x.idx[j]); pre[lev][j][1] = v.at(V_LPBEG + lev, x.idx[j]); pre[lev][j][2] = v.at(V_LPEND + lev, x.idx[j]);
+        coord_load_slot(v, x.idx[j], lev, &pre[lev][j][0], &pre[lev][j][1], &pre[lev][j][2]);
       }
     }
   }
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
       for (int j = 0; j < NCM; ++j) {
         pre[lev][j][0] = pre[lev][j][1] = pre[lev][j][2] = 0.0;
         if (lev < n_pre && j < x.ncoord) {
-          pre[lev][j][0] = v.at(V_LRHO + lev, x.idx[j]); pre[lev][j][1] = v.at(V_LPBEG + lev, x.idx[j]); pre[lev][j][2] = v.at(V_LPEND + lev, x.idx[j]);
+          coord_load_slot(v, x.idx[j], lev, &pre[lev][j][0], &pre[lev][j][1], &pre[lev][j][2]);
         }
       }
     }
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
   // ---- the command's work on the gene's coordinates
   double T0 = 0.0;
   double* draws = ga.draws ? ga.draws + (long)chain * ga.draws_chain_stride : nullptr;
-  if (do_update) gene_coord_update<CM, true>(d, c, v, x, draws, &T0, s_tab, !do_close, cache, p_cur, minv);
+  if (do_update) gene_coord_update<CM, true>(d, c, v, x, draws, &T0, s_tab, !do_close, cache, p_cur, minv, !do_close);
   double* slab = a.partials + ((long)chain * gridDim.x + blockIdx.x) * PT_COUNT;
   if (!do_close) {                             // the command's position has not been evaluated yet: nothing to close
     double t0v[1] = {T0};

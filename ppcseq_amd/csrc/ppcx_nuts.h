@@ -195,8 +195,17 @@ struct NodeVals { double nrho, npbeg; };
 // completed left sibling). Mirrors Stan's three compute_criterion calls inside build_tree.
 // Lr, Lb, Le: the parked left subtree of level d (rho, p_begin, p_end) of this coordinate
 PPCX_HD void coord_merge_dots_vals(double Lr, double Lb, double Le, double p_end, double minv, NodeVals* nv, double* dots);
+// the parked left subtree of level d of coordinate i: (rho, p_begin, p_end). A level-0 subtree is one leaf, whose three
+// values are the same number: only V_LRHO holds it (two stores and two loads less per coordinate and leaf pair).
+PPCX_HD void coord_load_slot(const VecRef& v, int i, int d, double* Lr, double* Lb, double* Le) {
+  *Lr = v.at(V_LRHO + d, i);
+  if (d == 0) { *Lb = *Lr; *Le = *Lr; }
+  else { *Lb = v.at(V_LPBEG + d, i); *Le = v.at(V_LPEND + d, i); }
+}
 PPCX_HD void coord_merge_dots(const VecRef& v, int i, int d, double p_end, double minv, NodeVals* nv, double* dots) {
-  coord_merge_dots_vals(v.at(V_LRHO + d, i), v.at(V_LPBEG + d, i), v.at(V_LPEND + d, i), p_end, minv, nv, dots);
+  double Lr, Lb, Le;
+  coord_load_slot(v, i, d, &Lr, &Lb, &Le);
+  coord_merge_dots_vals(Lr, Lb, Le, p_end, minv, nv, dots);
 }
 PPCX_HD void coord_merge_dots_vals(double Lr, double Lb, double Le, double p_end, double minv, NodeVals* nv, double* dots) {
   const double pes = minv * p_end;
@@ -213,7 +222,8 @@ PPCX_HD void coord_merge_dots_vals(double Lr, double Lb, double Le, double p_end
 }
 // park the node closed by this leaf in slot m (it is a left child at level m)
 PPCX_HD void coord_store_slot(const VecRef& v, int i, int m, double p_end, const NodeVals& nv) {
-  v.at(V_LRHO + m, i) = nv.nrho; v.at(V_LPBEG + m, i) = nv.npbeg; v.at(V_LPEND + m, i) = p_end;
+  v.at(V_LRHO + m, i) = nv.nrho;
+  if (m > 0) { v.at(V_LPBEG + m, i) = nv.npbeg; v.at(V_LPEND + m, i) = p_end; }     // level 0: all three are p_end (coord_load_slot)
 }
 // the subtree is complete: the three top-level criteria of base_nuts::transition, and rho += rho_subtree
 PPCX_HD void coord_top_dots(const VecRef& v, int i, int dir, double p_end, double minv, const NodeVals& nv, double* top) {
@@ -341,7 +351,13 @@ PPCX_HD bool cmd_evaluates(const Cmd& c) { return c.type == CMD_EVAL || c.type =
 // ----- helpers that fill in the next command ---------------------------------------------------------
 PPCX_HD void issue_eps_try(ChainScalars& st, Cmd& nc) {
   nc.type = CMD_EPS_TRY; nc.pre_flags |= PRE_EPS_TRY; nc.dir = 1; nc.eps = st.eps;
-  nc.rng_c1 = (unsigned)st.eps_call; nc.rng_c3 = (unsigned)st.eps_attempt;
+  // Opaque on purpose. Without it hipcc (ROCm 7.2, -O3) emits 0 here on the halving / doubling path of PH_EPS in
+  // ppcx_step_kernel (not in the other kernels built from this header, nor on the host): every trial after the second then
+  // drew the momenta of trial 0. Found in round 3 by running the two round structures side by side
+  // (tests/test_gpu_parity.py::test_round_structures_agree_with_the_oracle).
+  unsigned attempt = (unsigned)st.eps_attempt;
+  PPCX_OPAQUE(attempt);
+  nc.rng_c1 = (unsigned)st.eps_call; nc.rng_c3 = attempt;
   st.eps_attempt++;
   st.phase = PH_EPS;
 }
@@ -456,6 +472,12 @@ PPCX_HD void chain_advance(ChainScalars& st, TreeArrays& ta, const Cmd& ex, cons
       const double H0 = st.V_sample + 0.5 * rd.T0;
       double h = -lp + 0.5 * rd.T1; if (isnan(h)) h = INFINITY;
       const double dH = H0 - h;
+#if defined(PPCX_DEBUG_EPS)           // development aid: the energies of every step-size trial
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (threadIdx.x == 0 && blockIdx.x == 0)
+#endif
+      printf("eps trial: chain key %u eps %.6g V %.10g T0 %.10g lp %.10g T1 %.10g dH %.10g | attempt %d call %d ex.rng_c1 %u ex.rng_c3 %u ex.flags %d\n", st.k1, st.eps, st.V_sample, rd.T0, lp, rd.T1, dH, st.eps_attempt, st.eps_call, ex.rng_c1, ex.rng_c3, ex.pre_flags);
+#endif
       const double thr = -0.22314355131420976;   // log(0.8)
       bool finished = false;
       if (st.eps_dir == 0) st.eps_dir = dH > thr ? 1 : -1;

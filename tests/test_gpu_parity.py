@@ -183,6 +183,34 @@ def test_nuts_follows_oracle_at_equal_seed(L, oracle, G, S, C, K, seed):
     assert np.max(np.abs(dg["accept"][:, :n] - r.accept[:, :n])) < 1e-6
 
 
+def test_round_structures_agree_with_the_oracle(L, oracle, monkeypatch):
+    """Both round structures -- pipelined (two launches, the default) and the three-launch round that gene shards, ADVI and
+    single evaluations use -- against the oracle over 40 small problems: initial step size (the step-size search draws
+    fresh momenta per trial), tree sizes and step sizes of the first iterations. This is the sweep that exposed a
+    miscompiled Philox counter in the three-launch round's step kernel (ppcx_nuts.h issue_eps_try): one of these 40 had
+    come out with another initial step size."""
+    bad = []
+    for (G, S, K) in [(24, 6, 3), (30, 8, 4), (64, 21, 5), (16, 5, 3)]:
+        for dseed in range(1, 6):
+            d = ind.synth(G, S, K=K, seed=dseed)
+            m = L.Model(d["counts"], d["X"], d["exposure"], K)
+            mo = oracle.model(d["counts"], d["X"], d["exposure"], K)
+            try:
+                for seed in (9, 10):
+                    r = oracle.nuts_model(mo, oracle.cfg(chains=2, iter=12, warmup=8, seed=seed))
+                    for pipe in ("1", "0"):
+                        monkeypatch.setenv("PPCX_PIPELINE", pipe)
+                        f = m.fit_nuts(chains=2, iter=12, warmup=8, seed=seed)
+                        dg = f.diagnostics()
+                        f.close()
+                        if not (np.array_equal(dg["n_leapfrog"][:, :6], r.n_leapfrog[:, :6])
+                                and np.allclose(dg["stepsize"][:, :6], r.stepsize[:, :6], rtol=1e-9, atol=0)):
+                            bad.append((pipe, G, S, K, dseed, seed, dg["stepsize"][:, 0].tolist(), r.stepsize[:, 0].tolist()))
+            finally:
+                m.close()
+    assert not bad, bad
+
+
 def test_nuts_draws_follow_oracle_without_adaptation(L, oracle):
     d = ind.synth(16, 5, K=3, seed=9, C=2)
     mo = oracle.model(d["counts"], d["X"], d["exposure"], 3)
