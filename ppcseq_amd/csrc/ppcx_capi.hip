@@ -608,8 +608,15 @@ struct RcclApi {
 static RcclApi g_rccl;
 static int rccl_load() {
   if (g_rccl.h) return PPCX_OK;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.h) break; }
+  // PPCX_RCCL_LIB: another provider of the five nccl* entry points below (tests/loopback: ranks of one host over shared
+  // memory, so that the multi-rank path runs on a one-GPU box, where RCCL refuses two ranks on a device)
+  if (const char* e = getenv("PPCX_RCCL_LIB")) {
+    g_rccl.h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+    if (!g_rccl.h) return fail(PPCX_ERR_HIP, std::string("cannot load PPCX_RCCL_LIB=") + e + ": " + dlerror());
+  } else {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.h) break; }
+  }
   if (!g_rccl.h) return fail(PPCX_ERR_HIP, "cannot load librccl.so");
   g_rccl.GetUniqueId = (int (*)(ncclUniqueId_t*))dlsym(g_rccl.h, "ncclGetUniqueId");
   g_rccl.CommInitRank = (int (*)(ncclComm_t*, int, ncclUniqueId_t, int))dlsym(g_rccl.h, "ncclCommInitRank");

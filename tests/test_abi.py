@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), f"{name} declared in include/ppcx.h but not exported by libppcx.so"
     lib.ppcx_version.restype = ctypes.c_int
-    assert lib.ppcx_version() >= 100
+    assert lib.ppcx_version() == 300          # include/ppcx.h PPCX_VERSION
 
 
 def test_binding_lists_the_same_symbols():
@@ -52,3 +52,26 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
                 assert "ppc_oracle" not in txt and "libppc_oracle" not in txt, f
+
+
+def test_guard_decision_of_the_gene_shard_ranks():
+    """What the ranks of a gene-sharded run conclude at a poll from the max-reduced vector [rounds, -rounds, done, -done,
+    -(error)] (ppcx_capi.hip comm_guard): agreement, a peer's error, their own error, disagreement on rounds or chains."""
+    import numpy as np
+    from ppcseq_amd import build
+    lib = ctypes.CDLL(build.build())
+    lib.ppcx_guard_decision.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    lib.ppcx_guard_decision.restype = ctypes.c_int
+
+    def decide(vecs, local):
+        red = np.max(np.array(vecs, float), axis=0)                        # what ncclMax leaves on every rank
+        return lib.ppcx_guard_decision(red.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), local)
+
+    def vec(rounds, done, err=0):
+        return [rounds, -rounds, done, -done, -err if err else 0.0]
+    assert decide([vec(64, 1), vec(64, 1)], 0) == 0                        # all agree
+    assert decide([vec(64, 1), vec(96, 1)], 0) == -5                       # rounds issued differ: PPCX_ERR_STALL
+    assert decide([vec(64, 1), vec(64, 2)], 0) == -5                       # chains done differ
+    assert decide([vec(64, 0), vec(64, 0, err=-2)], 0) == -2               # a peer failed: its class
+    assert decide([vec(64, 0, err=-3), vec(64, 0)], -3) == -3              # this rank failed: its own status
+    assert decide([vec(64, 0, err=-2), vec(32, 0, err=-6)], -6) == -6      # both failed: each keeps its own

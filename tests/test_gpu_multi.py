@@ -1,7 +1,10 @@
 """Multi-GPU paths on whatever the box offers (`-m gpu`):
   * chains partitioned over ranks (one process per GPU; here two ranks share the one GPU over gloo) and over the devices
     of one process: the pooled credible intervals are those of a single fit of the same global chains, bit for bit;
-  * gene shards over ranks with the per-leapfrog RCCL all-reduce: needs two devices, skipped otherwise.
+  * gene shards over ranks with the per-leapfrog all-reduce and the rank-divergence guard: over RCCL where two devices are
+    visible (one rank per GPU; skipped otherwise), and on ANY box through tests/loopback -- a stand-in for the five nccl*
+    entry points over shared memory (PPCX_RCCL_LIB), because RCCL refuses two ranks on one device. The loopback runs
+    reproduce the in-process shards bit for bit, and a failure injected into one rank makes both ranks return together.
 """
 import os
 import socket
@@ -123,3 +126,97 @@ def test_gene_shards_over_two_ranks_equal_the_unsharded_run():
     for r in res:
         assert np.array_equal(r[1][:, :12], nl[:, :12])          # same decisions until rounding separates the runs
         assert np.max(np.abs(r[2][:, :3] - hy[:, :3])) < 1e-6    # hyper-parameter draws of the first kept iterations
+
+
+# ---- gene shards over two ranks on one device, through the loopback collective (tests/loopback/loopback_rccl.cpp) ----
+LOOPBACK_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loopback")
+
+
+def _loopback_lib():
+    import subprocess
+    lib, src = os.path.join(LOOPBACK_DIR, "libloopback_rccl.so"), os.path.join(LOOPBACK_DIR, "loopback_rccl.cpp")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-std=c++17", "-fPIC", "-shared",
+                               "-fvisibility=hidden", "-o", lib, src, "-lrt"])
+    return lib
+
+
+def _loopback_worker(rank, world, conn, q, G, K, kw):
+    """One rank = one process; both ranks on device 0. The communicator's id travels from rank 0 over a pipe."""
+    from ppcseq_amd import _lib as L
+    try:
+        d = ind.synth(G, 10, K=K, seed=4)
+        if rank == 0:
+            uid = L.Comm.unique_id()
+            conn.send(uid)
+        else:
+            uid = conn.recv()
+        comm = L.Comm(world, rank, uid, device=0)
+        g0, g1 = G * rank // world, G * (rank + 1) // world
+        m = L.Model(d["counts"][g0:g1], d["X"], d["exposure"], 0, device=0, shard=(G, K, g0, g1))
+        try:
+            f = m.fit_nuts_comm(comm, **kw)
+            q.put((rank, "ok", f.diagnostics()["n_leapfrog"], f.draws()))
+            f.close()
+        except L.PpcxError as e:
+            q.put((rank, "error", str(e), None))
+        m.close(); comm.close()
+    except Exception as e:                      # anything else: reported, so that the parent does not wait for the timeout
+        q.put((rank, "crash", repr(e), None))
+
+
+def _run_two_ranks(G, K, kw, monkeypatch, extra_env=None):
+    monkeypatch.setenv("PPCX_RCCL_LIB", _loopback_lib())
+    for k, v in (extra_env or {}).items():
+        monkeypatch.setenv(k, v)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    a, b = ctx.Pipe()
+    procs = [ctx.Process(target=_loopback_worker, args=(r, 2, (a, b)[r], q, G, K, kw)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_gene_shards_over_two_ranks_through_the_loopback_collective(monkeypatch):
+    """ppcx_fit_nuts_comm with nranks = 2 (the reference's map_rect over gene shards, inst/stan/negBinomial_MPI.stan:226-240,
+    one shard per process): the per-round all-reduce between reduce and advance, every rank replicating the state
+    machines, the guard's poll. The two ranks' draws are the columns of the in-process two-shard fit, bit for bit (same
+    order of the shard sum), and agree with the unsharded fit."""
+    from ppcseq_amd import _lib as L
+    G, K = 80, 6
+    kw = dict(chains=2, iter=40, warmup=25, seed=6)
+    d = ind.synth(G, 10, K=K, seed=4)
+    shards = [L.Model(d["counts"][g0:g1], d["X"], d["exposure"], 0, shard=(G, K, g0, g1)) for g0, g1 in ((0, 40), (40, 80))]
+    whole = L.Model(d["counts"], d["X"], d["exposure"], K)
+    try:
+        fits = L.fit_nuts_shards(shards, **kw)
+        ref = [(f.diagnostics()["n_leapfrog"].copy(), f.draws().copy()) for f in fits]
+        for f in fits:
+            f.close()
+        fw = whole.fit_nuts(**kw)
+        nl_w, hy_w = fw.diagnostics()["n_leapfrog"], fw.draws()[..., :3]
+        fw.close()
+    finally:
+        for m in shards + [whole]:
+            m.close()
+    res = _run_two_ranks(G, K, kw, monkeypatch)
+    for rank, status, nl, dr in res:
+        assert status == "ok", (rank, status, nl)
+        assert np.array_equal(nl, ref[rank][0]) and np.array_equal(dr, ref[rank][1])        # = the in-process shards
+        assert np.array_equal(nl[:, :12], nl_w[:, :12]) and np.max(np.abs(dr[:, :3, :3] - hy_w[:, :3])) < 1e-6   # ~ unsharded
+
+
+@pytest.mark.parametrize("failing_rank", [0, 1])
+def test_a_failing_rank_takes_its_peer_out_of_the_collectives(monkeypatch, failing_rank):
+    """Fault injection: one rank fails after round 64 (PPCX_TEST_FAIL_AT_ROUND). It keeps issuing the per-round all-reduces
+    until the poll, where the guard's max-reduction tells both ranks: both return the same error class, neither hangs."""
+    kw = dict(chains=2, iter=200, warmup=100, seed=6)
+    res = _run_two_ranks(80, 6, kw, monkeypatch, {"PPCX_TEST_FAIL_AT_ROUND": "64", "PPCX_TEST_FAIL_RANK": str(failing_rank)})
+    assert [r[1] for r in res] == ["error", "error"], res
+    assert all("ppcx error -2" in r[2] for r in res), res                     # PPCX_ERR_HIP, the class of the injected failure
+    assert "injected failure" in res[failing_rank][2] and "another rank" in res[1 - failing_rank][2]
