@@ -68,6 +68,19 @@ def max_over_ranks(value: float, device="cpu") -> float:
     return float(t.item())
 
 
+def raise_if_any_rank_failed(err: BaseException | None, device="cpu", what="a rank"):
+    """Collective error check: every rank passes its own exception (or None). If any rank failed, EVERY rank raises -- the
+    failing ones their own exception, the others a RuntimeError naming the lowest failing rank -- instead of the healthy
+    ranks blocking in the next collective for a peer that has already left."""
+    dist = _dist()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    worst = max_over_ranks(float(world - rank) if err is not None else 0.0, device=device)     # > 0: the lowest failing rank
+    if worst > 0.0:
+        if err is not None:
+            raise err
+        raise RuntimeError(f"{what}: rank {world - int(worst)} failed; this rank leaves with it")
+
+
 def do_inference(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_device="cpu", chains=None, cores=None,
                  approximate_posterior_analysis=False, lambda_mu_mu=5.612671, adj_prob_theshold=0.05,
                  how_many_posterior_draws=1000, to_exclude=None, truncation_compensation=1.0, seed=1, launch=None):
@@ -96,28 +109,35 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_
     cols = checked_columns(G, X.shape[1], K)
     n_keep = n_iter - 150
     local = np.zeros((per, n_keep, cols.size))
-    div_local = np.zeros(1)
+    err = None
     if n_local > 0:
-        m = _lib.Model(counts, X, exposure_rate, K, lambda_mu_mu=lambda_mu_mu, excl=_to_cell_ids(to_exclude, S), device=device)
         try:
-            if launch is not None:
-                m.set_launch(*launch)
-            f = m.fit_nuts(chains=n_local, iter=n_iter, warmup=150, seed=seed, chain_id_offset=rank * per)
+            m = _lib.Model(counts, X, exposure_rate, K, lambda_mu_mu=lambda_mu_mu, excl=_to_cell_ids(to_exclude, S), device=device)
             try:
-                local[:n_local] = f.columns(cols)
-                div_local[0] = float(f.diagnostics()["divergent"][:, 150:].sum())
+                if launch is not None:
+                    m.set_launch(*launch)
+                f = m.fit_nuts(chains=n_local, iter=n_iter, warmup=150, seed=seed, chain_id_offset=rank * per)
+                try:
+                    local[:n_local] = f.columns(cols)
+                finally:
+                    f.close()
             finally:
-                f.close()
-        finally:
-            m.close()
+                m.close()
+        except Exception as e:                     # out of memory, no finite initial point, a limit of this build ...
+            err = e
+    raise_if_any_rank_failed(err, device=coll_device, what="chains over ranks")      # before anybody waits in the gather
     pooled = all_gather_chains(local, device=coll_device)[:chains]        # ranks past the last chain contributed padding
-    res = [None]
+    res, err = [None], None
     if rank == 0:
-        r = pooled_summary(counts, X, exposure_rate, K, pooled, lambda_mu_mu=lambda_mu_mu,
-                           approximate_posterior_analysis=approximate_posterior_analysis, adj_prob_theshold=adj_prob_theshold,
-                           how_many_posterior_draws=how_many_posterior_draws, truncation_compensation=truncation_compensation,
-                           seed=seed, device=device)
-        r.chains, r.iter = chains, n_iter
-        res[0] = r
+        try:
+            r = pooled_summary(counts, X, exposure_rate, K, pooled, lambda_mu_mu=lambda_mu_mu,
+                               approximate_posterior_analysis=approximate_posterior_analysis, adj_prob_theshold=adj_prob_theshold,
+                               how_many_posterior_draws=how_many_posterior_draws, truncation_compensation=truncation_compensation,
+                               seed=seed, device=device)
+            r.chains, r.iter = chains, n_iter
+            res[0] = r
+        except Exception as e:
+            err = e
+    raise_if_any_rank_failed(err, device=coll_device, what="pooled summary")
     dist.broadcast_object_list(res, src=0)
     return res[0]

@@ -127,6 +127,9 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *,
     warmup = 150                                                    # R/utilities.R:1503
 
     excl = _to_cell_ids(to_exclude, S)
+    if devices is not None and len(devices) > 1 and (save_generated_quantities or pass_fit or model is not None or approximate_posterior_inference):
+        raise ValueError("devices=[...] splits the chains of a NUTS fit over several devices and pools their draws: it cannot "
+                         "be combined with save_generated_quantities, pass_fit, a caller's model or approximate_posterior_inference")
     if devices is not None and len(devices) > 1 and not approximate_posterior_inference:
         return _do_inference_devices(counts, X, exposure_rate, K, list(devices), chains, n_iter, warmup, excl,
                                      lambda_mu_mu, approximate_posterior_analysis, adj_prob_theshold,

@@ -56,3 +56,37 @@ def test_chain_partition_broadcast_and_gather():
         assert r[3] == np.linspace(-1, 1, 4).tolist()
         assert r[4] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]          # global chain order
         assert r[5] == 2.0
+
+
+def _failing_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from ppcseq_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        try:
+            D.raise_if_any_rank_failed(None, what="round 1")                # nobody failed: nobody raises
+            D.raise_if_any_rank_failed(MemoryError("out of device memory") if rank == 1 else None, what="round 2")
+            q.put((rank, "no exception"))
+        except Exception as e:
+            q.put((rank, type(e).__name__ + ": " + str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_is_seen_by_every_rank_before_the_gather():
+    """distributed.do_inference checks for failures collectively before its all-gather: when one rank's fit raises (out of
+    memory, no finite initial point), the others must leave with it instead of waiting in the gather for ever."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[1] == "MemoryError: out of device memory"
+    assert res[0].startswith("RuntimeError: round 2: rank 1 failed")

@@ -230,10 +230,10 @@ def test_nuts_draws_follow_oracle_without_adaptation(L, oracle):
 def test_nuts_posterior_matches_oracle_distribution(L, oracle):
     d = ind.synth(40, 10, K=4, seed=21, C=2)
     mo = oracle.model(d["counts"], d["X"], d["exposure"], 4, n_threads=4)
-    r = oracle.nuts_model(mo, oracle.cfg(chains=4, iter=400, warmup=150, seed=3))
+    r = oracle.nuts_model(mo, oracle.cfg(chains=4, iter=1350, warmup=150, seed=3))
     m = L.Model(d["counts"], d["X"], d["exposure"], 4)
     try:
-        f = m.fit_nuts(chains=4, iter=400, warmup=150, seed=3)
+        f = m.fit_nuts(chains=4, iter=1350, warmup=150, seed=3)
         D = f.D
         cols = [0, 1, 2, D - 3, D - 2, D - 1]
         b = f.columns(cols).reshape(-1, 6)
@@ -244,13 +244,15 @@ def test_nuts_posterior_matches_oracle_distribution(L, oracle):
     from ppcseq_amd.ess import ess_bulk
     a3, b3 = r.draws[..., cols], b.reshape(4, -1, 6)                   # [chains, draws, 6]
     a, b = a3.reshape(-1, 6), b3.reshape(-1, 6)
-    # two independent runs of the same sampler: tolerances from their own Monte-Carlo error (the slow hyper-parameters have
-    # an effective sample size of a few dozen here; var(log sd_hat) ~ 1 / (2 ESS))
-    ea = np.array([max(ess_bulk(a3[:, :, j]), 8.0) for j in range(6)])
-    eb = np.array([max(ess_bulk(b3[:, :, j]), 8.0) for j in range(6)])
+    # two independent runs of the same sampler: tolerances from their own Monte-Carlo error (4 x 1200 kept draws, so that
+    # the slow hyper-parameters reach an effective sample size of a few hundred; var(log sd_hat) ~ 1 / (2 ESS)), and the
+    # spread check is capped: a sampler whose posterior sd is off by 40 % fails whatever its ESS
+    ea = np.array([ess_bulk(a3[:, :, j]) for j in range(6)])
+    eb = np.array([ess_bulk(b3[:, :, j]) for j in range(6)])
+    assert ea.min() > 100 and eb.min() > 100, (ea, eb)
     se = np.sqrt(a.var(0) / ea + b.var(0) / eb)
     assert np.all(np.abs(a.mean(0) - b.mean(0)) < 5 * se)
-    assert np.all(np.abs(np.log(a.std(0) / b.std(0))) < 0.05 + 4.5 * np.sqrt(0.5 / ea + 0.5 / eb))
+    assert np.all(np.abs(np.log(a.std(0) / b.std(0))) < np.minimum(0.35, 0.05 + 4.5 * np.sqrt(0.5 / ea + 0.5 / eb)))
     assert dg["divergent"][:, 150:].mean() <= 0.02      # small hierarchical model: rare divergences are expected
     assert dg["stepsize"][:, -1].min() > 0
 
@@ -492,8 +494,10 @@ def test_advi_follows_oracle(L, oracle):
         assert info["eta"] == ro["eta"] and info["converged"] and ro["converged"]
         assert info["iterations"] == ro["iterations"]
         assert abs(info["elbo"] - ro["elbo"]) < 1e-5 * abs(ro["elbo"])
-        # 2900 SGD steps amplify rounding differences along the flat directions (the sigma_* hyper-parameters): 1e-3 there
-        assert np.max(np.abs(dr - ro["draws"]) / (1 + np.abs(ro["draws"]))) < 5e-3
+        # 2900 SGD steps amplify rounding differences along the flat directions -- the three sigma_* hyper-parameters, the
+        # last columns -- and only there: every other column to 5e-4
+        rel = np.abs(dr - ro["draws"]) / (1 + np.abs(ro["draws"]))
+        assert np.max(rel[:, :-3]) < 5e-4 and np.max(rel[:, -3:]) < 5e-3
         # and the approximation sits on the NUTS posterior (means; mean-field sd is known to be narrower)
         nu = oracle.nuts_model(mo, oracle.cfg(chains=4, iter=400, warmup=150, seed=3)).draws.reshape(-1, dr.shape[1])
         assert np.corrcoef(dr[:, 3:43].mean(0), nu[:, 3:43].mean(0))[0, 1] > 0.995
