@@ -277,6 +277,7 @@ static double gauss_lp(const void* ctx, const double* u, double* grad) {
 /*   init values      : counter (i, attempt, 0, 0)  -> 1 uniform per coordinate         */
 /*   momentum         : counter (i>>1, iter, 1, 0)   -> Box-Muller pair, cos=even i      */
 /*   tree scalars     : counter (j, iter, 2, 0)      -> j-th uniform of the transition   */
+/*   doubling direction: counter (depth, iter, 7, 0) -> forward iff the uniform > 1/2    */
 /*   init_stepsize p  : counter (i>>1, call, 3, attempt)                                 */
 /* ----------------------------------------------------------------------------------- */
 typedef struct {
@@ -310,6 +311,13 @@ static inline double coord_normal(const chain_t* c, int i, uint32_t c1, uint32_t
 }
 static inline double scalar_uniform(const chain_t* c, uint32_t j, uint32_t iter) {
   ppco_u4 r = ppco_philox4x32_10(j, iter, 2u, 0u, c->k0, c->k1);
+  return ppco_u01(r.v[0], r.v[1]);
+}
+
+/* the direction of doubling number `depth` of a transition has a stream of its own (the product anticipates the next
+ * doubling's direction while the current subtree is being built: ppcx_nuts.h doubling_dir) */
+static inline double dir_uniform(const chain_t* c, uint32_t depth, uint32_t iter) {
+  ppco_u4 r = ppco_philox4x32_10(depth, iter, 7u, 0u, c->k0, c->k1);
   return ppco_u01(r.v[0], r.v[1]);
 }
 
@@ -458,7 +466,7 @@ static void transition(chain_t* c, uint32_t iter, int max_depth, trans_info* inf
   while (depth < max_depth) {
     memset(rho_fwd, 0, sizeof(double) * D); memset(rho_bck, 0, sizeof(double) * D);
     int valid; double lsw_sub = -INFINITY;
-    if (scalar_uniform(c, t.rng_j++, iter) > 0.5) {
+    if (dir_uniform(c, (uint32_t)depth, iter) > 0.5) {
       ps_load(&z_fwd, c);
       memcpy(rho_bck, rho, sizeof(double) * D); memcpy(p_bck_fwd, p_fwd_fwd, sizeof(double) * D); memcpy(psh_bck_fwd, psh_fwd_fwd, sizeof(double) * D);
       valid = build_tree(&t, depth, &z_propose, psh_fwd_bck, psh_fwd_fwd, rho_fwd, p_fwd_bck, p_fwd_fwd, 1, &lsw_sub);

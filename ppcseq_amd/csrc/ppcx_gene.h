@@ -351,17 +351,21 @@ PPCX_HD void gene_coord_update(const Dims& d, const Cmd& c, const VecRef& v, Gen
     }
   }
 }
-// constants of the position the NEXT leaf would evaluate if the subtree continues in the same direction with the same
-// step: q + eps minv (pn + eps/2 gn), from the values the close has in registers
+// constants of the position the NEXT leaf evaluates if the tree goes on (Cmd::next_dir): inside a subtree, or into a new
+// doubling in the same direction, q + eps minv (pn + eps/2 gn) from the values the close has in registers; into a new
+// doubling in the OTHER direction the same step from the other end of the trajectory, with the step's sign turned.
 template <int CM>
 PPCX_HD void gene_spec_consts(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, const double* pn,
                               const double* gn, const double* minv, const double* tab) {
   constexpr int NCM = CM + 1;
+  const bool turn = c.next_dir != c.dir;
+  const int o = 1 - c.dir;
 #pragma unroll
   for (int j = 0; j < NCM; ++j) {
     if (j < x.ncoord) {
       double ph, qn;
-      kick_drift(x.q[j], pn[j], gn[j], c.eps, minv[j], &ph, &qn);
+      if (turn) kick_drift(v.at(V_Q0 + 3 * o, x.idx[j]), v.at(V_P0 + 3 * o, x.idx[j]), v.at(V_G0 + 3 * o, x.idx[j]), -c.eps, minv[j], &ph, &qn);
+      else kick_drift(x.q[j], pn[j], gn[j], c.eps, minv[j], &ph, &qn);
       coord_consts(d, v, x.idx[j], qn, tab);
     }
   }

@@ -61,6 +61,8 @@ struct Cmd {
   unsigned rng_c1, rng_c3;       // Philox counter words for momentum / init draws
   double init_radius;
   int leaf_n, n_merge, subtree_complete;   // tree position of this leaf inside the current subtree
+  int next_dir;                  // the direction the NEXT leaf advances if the tree goes on: dir inside a subtree, the next doubling's
+                                 // direction at a leaf that completes one (drawn from its own Philox stream, so it is known ahead)
   double hyp_q[6];               // hyper-parameter values (unconstrained) to evaluate the genes at
   uint32_t k0, k1;               // Philox key of this chain
   // pipelined rounds (ppcx_ls_kernel / ppcx_gene_kernel): has the log-likelihood kernel evaluated this command's position
@@ -334,15 +336,16 @@ PPCX_HD void state_init(ChainState& cs, const NutsConfig& cfg, int local_chain, 
 PPCX_HD void cmd_clear(Cmd& c) {
   c.type = CMD_DONE; c.dir = 1; c.eps = 0.0; c.pre_flags = 0; c.pre_dir = 1; c.prop_slot = 0; c.prop_src = -1;
   c.sample_src = -1; c.draw_index = 0; c.welford_n = 0; c.metric_n = 0; c.rng_c1 = 0; c.rng_c3 = 0;
-  c.init_radius = 0; c.leaf_n = 0; c.n_merge = 0; c.subtree_complete = 0;
+  c.init_radius = 0; c.leaf_n = 0; c.n_merge = 0; c.subtree_complete = 0; c.next_dir = 1;
   for (int k = 0; k < 6; ++k) c.hyp_q[k] = 0.0;
   c.k0 = 0; c.k1 = 0; c.evaluated = 0; c.updated = 0;
 }
-// Pipelined rounds: after closing leaf `ex` the gene kernel assumes that the next command is the next leaf of the same
-// subtree direction with the same step, and writes the constants of that position for the log-likelihood launch that
-// runs beside the state machine. True unless the transition ends, a new transition starts or the tree turns round.
+// Pipelined rounds: after closing leaf `ex` the gene kernel assumes that the tree goes on -- the next leaf of the same
+// subtree, or the first leaf of the next doubling in the direction ex.next_dir -- and writes the constants of that position
+// for the log-likelihood launch that runs beside the state machine. True unless the transition ends here.
 PPCX_HD bool spec_continues(const Cmd& ex, const Cmd& nc) {
-  return ex.type == CMD_LEAF && nc.type == CMD_LEAF && nc.dir == ex.dir && nc.eps == ex.eps &&
+  return ex.type == CMD_LEAF && nc.type == CMD_LEAF && nc.dir == ex.next_dir &&
+         nc.eps == (ex.next_dir == ex.dir ? ex.eps : -ex.eps) &&
          (nc.pre_flags & (PRE_NEW_TRANSITION | PRE_INIT | PRE_EPS_TRY | PRE_METRIC)) == 0;
 }
 // does a command wait for a gradient evaluation (as opposed to CMD_FLUSH / CMD_DONE, which only move data)
@@ -366,6 +369,13 @@ PPCX_HD void start_eps_heuristic(ChainScalars& st, Cmd& nc) {   // Stan base_hmc
   if (st.eps == 0 || st.eps > 1e7 || isnan(st.eps)) { st.error = 2; nc.type = CMD_DONE; st.phase = PH_DONE; return; }
   issue_eps_try(st, nc);
 }
+// direction of doubling number `depth` (0-based) of the current transition: forward if the uniform of Philox counter
+// (depth, iteration, 7, 0) exceeds 1/2. A stream of its own -- not the transition's sequence of scalar uniforms, whose
+// consumption depends on the data -- so that the direction of the NEXT doubling is known while the current one is built
+// (the gene kernel anticipates the first leaf of the next doubling, see Cmd::next_dir).
+PPCX_HD int doubling_dir(const ChainScalars& st, int depth) {
+  return coord_uniform((uint32_t)depth, (uint32_t)st.it, 7u, 0u, st.k0, st.k1) > 0.5 ? 1 : 0;
+}
 PPCX_HD void set_leaf(ChainScalars& st, Cmd& nc, int leaf_n) {
   st.leaf_n = leaf_n;
   nc.type = CMD_LEAF; nc.dir = st.dir; nc.eps = st.dir ? st.eps : -st.eps;
@@ -374,10 +384,11 @@ PPCX_HD void set_leaf(ChainScalars& st, Cmd& nc, int leaf_n) {
   while (m < st.depth && ((leaf_n >> m) & 1) == 0) ++m;          // trailing zeros, capped at the subtree depth
   nc.n_merge = m;
   nc.subtree_complete = (leaf_n == (1 << st.depth));
+  nc.next_dir = nc.subtree_complete ? doubling_dir(st, st.depth + 1) : st.dir;
   st.phase = PH_TREE;
 }
 PPCX_HD void start_doubling(ChainScalars& st, Cmd& nc) {
-  st.dir = tree_uniform(st) > 0.5 ? 1 : 0;
+  st.dir = doubling_dir(st, st.depth);
   nc.pre_flags |= PRE_SAVE_NEAR;
   set_leaf(st, nc, 1);
 }

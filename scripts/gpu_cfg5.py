@@ -26,7 +26,7 @@ t_frame = time.perf_counter() - t0
 t0 = time.perf_counter()
 res = identify_outliers(df, formula="~ Label", sample="sample", transcript="symbol", abundance="value", significance="PValue",
                         do_check="is_significant", percent_false_positive_genes=5, how_many_negative_controls=G - K,
-                        seed=20255, cores=int(os.environ.get("CORES", 8)),
+                        seed=int(os.environ.get("SEED", 20255)), cores=int(os.environ.get("CORES", 8)),
                         approximate_posterior_inference=False, approximate_posterior_analysis=False)
 t_all = time.perf_counter() - t0
 flag = {r["symbol"]: r["tot_deleterious_outliers"] for _, r in res.iterrows()}
@@ -47,4 +47,6 @@ print(json.dumps({
     "injected_outlier_cells": len(d["injected"]), "injected_cells_flagged_deleterious": int(hit),
     "clean_checked_genes": len(clean), "clean_checked_genes_with_a_deleterious_outlier": int(fp_genes),
     "false_positive_gene_rate": round(fp_genes / max(len(clean), 1), 4),
+    "sampler_seed": int(os.environ.get("SEED", 20255)),
+    "clean_checked_genes_flagged": [int(i) for i in clean if flag[genes[i]] > 0],
     "leapfrogs_discovery": leap(dg1), "leapfrogs_test": leap(dg2)}))

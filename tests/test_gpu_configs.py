@@ -368,6 +368,36 @@ def test_cfg1_stress_all_genes_as_controls(L, bundled):
     assert res.attrs["diagnostics_test"]["divergent"][:, 150:].mean() < 0.02
 
 
+def test_cfg3_warmup_follows_the_oracle_at_full_tree_depth(L):
+    """BASELINE config 3 at full size against the oracle's NUTS at Stan's defaults (max_treedepth 10): the first 30 warm-up
+    iterations of 2 chains. The oracle needs ~0.25 s per gradient here, so its run is a committed fixture
+    (tests/golden/cfg3_nuts_oracle.npz, written by tests/golden/make_cfg3_nuts_fixture.py: 756 gradient evaluations, trees up to
+    63 leapfrogs). Tree sizes, depths and divergences must be identical, step sizes equal to 1e-8, acceptance statistics to
+    1e-6, for every one of the 30 iterations -- in both round structures."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_nuts_oracle.npz"))
+    G, S, data_seed, chains, n_iter, seed = (int(v) for v in z["config"])
+    assert (G, S, data_seed) == (CONFIGS["cfg3"][0], CONFIGS["cfg3"][1], CONFIGS["cfg3"][2])
+    d = ind.synth(G, S, seed=data_seed)
+    m = L.Model(d["counts"], d["X"], d["exposure"], d["K"])
+    try:
+        for pipe in ("1", "0"):
+            os.environ["PPCX_PIPELINE"] = pipe
+            try:
+                f = m.fit_nuts(chains=chains, iter=n_iter, warmup=n_iter, seed=seed)
+            finally:
+                del os.environ["PPCX_PIPELINE"]
+            dg = f.diagnostics()
+            f.close()
+            assert np.array_equal(dg["n_leapfrog"], z["n_leapfrog"]), (pipe, dg["n_leapfrog"].tolist(), z["n_leapfrog"].tolist())
+            assert np.array_equal(dg["treedepth"], z["treedepth"]) and np.array_equal(dg["divergent"], z["divergent"])
+            assert np.max(np.abs(dg["stepsize"] / z["stepsize"] - 1)) < 1e-8
+            assert np.max(np.abs(dg["accept"] - z["accept"])) < 1e-6
+        assert z["n_leapfrog"].max() >= 63 and z["n_leapfrog"].sum() > 700
+    finally:
+        m.close()
+
+
 def test_a_chain_does_not_depend_on_the_chains_it_shares_launches_with(L, monkeypatch):
     """Chains are independent given their global id (Philox key) and the lanes per gene (summation order inside a gene).
     The same chain must therefore come out bit-identical from a 3-chain fit, from a fit with far more chains than the

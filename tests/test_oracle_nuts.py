@@ -25,8 +25,9 @@ def test_adaptation_schedule(oracle):
     cfg = oracle.cfg(chains=1, iter=160, warmup=150, seed=3)
     r = oracle.nuts_gauss(np.zeros(D), np.full(D, 0.01), cfg)
     ss = r.stepsize[0]
-    # tiny-scale target: before the metric update the step is ~0.01-scale, after it ~1-scale
-    assert ss[60:99].max() < 0.1 and ss[101:150].min() > 0.1
+    # tiny-scale target: before the metric update the step is ~0.01-scale, after it ~1-scale (dual averaging dips to ~0.1
+    # now and then: well separated from the 0.004-0.014 of the unit metric)
+    assert ss[60:99].max() < 0.02 and ss[101:150].min() > 0.05 and np.median(ss[101:150]) > 0.3
     assert np.all(ss[150:] == ss[150])          # frozen after warmup
 
 
