@@ -474,7 +474,7 @@ static void step_args(ppcx_model* m, Work& w, const RunIO& io, int phases, bool 
   sa.states_in = w.states[in]; sa.states_out = w.states[out];
   sa.cmds_in = w.cmds[in]; sa.cmds_out = w.cmds[out];
   sa.hyper_in = w.hyper_vecs[in]; sa.hyper_out = w.hyper_vecs[out];
-  sa.partials = w.partials; sa.nblocks_close = w.nb_close; sa.t0 = w.t0[in]; sa.nblocks_update = w.nb_update; sa.red = w.red;
+  sa.partials = w.partials; sa.nblocks_close = w.nb_close; sa.slab_stride = w.nb_close; sa.t0 = w.t0[in]; sa.nblocks_update = w.nb_update; sa.red = w.red;
   sa.draws = io.draws; sa.draws_chain_stride = io.draws_stride; sa.n_keep = io.n_keep; sa.iter = io.iter;
   sa.out_lp = io.lp; sa.out_stepsize = io.stepsize; sa.out_treedepth = io.treedepth; sa.out_n_leapfrog = io.nleap;
   sa.out_divergent = io.div; sa.out_accept = io.accept; sa.done = w.done;
@@ -542,31 +542,7 @@ static int launch_ls(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
 static int launch_gene_round(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
   GeneArgs ga;
   close_args(m, w, &ga.c);
-  ga.draws = io.draws; ga.draws_chain_stride = io.draws_stride; ga.logtab = m->d_logtab; ga.spec = 1; ga.trace = nullptr;
-#ifdef PPCX_TRACE_GENE
-  // development build: phase timestamps of the gene kernel launches of rounds PPCX_TRACE_ROUND .. + 7, dumped to PPCX_TRACE_FILE
-  static long long* d_tr = nullptr; static long tr_round = -2;
-  if (tr_round == -2) { const char* e = getenv("PPCX_TRACE_ROUND"); tr_round = e ? atol(e) : -1; }
-  const long rel = tr_round >= 0 ? (long)w.launches - tr_round : -1;
-  const size_t per = (size_t)w.nb_close * nchains * 8;
-  if (rel >= 0 && rel < 8) {
-    if (!d_tr) { (void)hipMalloc(&d_tr, sizeof(long long) * per * 8); (void)hipMemset(d_tr, 0, sizeof(long long) * per * 8); }
-    ga.trace = d_tr + per * rel;
-  }
-  if (rel == 40 && d_tr) {
-    std::vector<long long> h(per * 8);
-    (void)hipStreamSynchronize(w.stream);
-    (void)hipMemcpy(h.data(), d_tr, sizeof(long long) * per * 8, hipMemcpyDeviceToHost);
-    if (FILE* fp = fopen(getenv("PPCX_TRACE_FILE") ? getenv("PPCX_TRACE_FILE") : "gene_trace.txt", "w")) {
-      for (size_t r = 0; r < 8; ++r) for (size_t b = 0; b < (size_t)w.nb_close * nchains; ++b) {
-        fprintf(fp, "%zu %zu", r, b);
-        for (int k = 0; k < 8; ++k) fprintf(fp, " %lld", h[(r * (size_t)w.nb_close * nchains + b) * 8 + k]);
-        fprintf(fp, "\n");
-      }
-      fclose(fp);
-    }
-  }
-#endif
+  ga.draws = io.draws; ga.draws_chain_stride = io.draws_stride; ga.logtab = m->d_logtab; ga.spec = 1;
   hipError_t e = launch_gene_kernel(m->CM, ga, w.nb_close, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("gene kernel: ") + hipGetErrorString(e));
   return PPCX_OK;

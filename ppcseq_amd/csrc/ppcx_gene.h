@@ -421,7 +421,7 @@ PPCX_HD void chain_step(const Lanes& ln, const Dims& d, ChainScalars& st, TreeAr
     if (ln.leader()) {
       rd.lp_genes = red[PT_LP];
       for (int k = 0; k < 6; ++k) rd.hsum[k] = hs[k];
-      rd.T0 = red[PT_T0] + st.T0h; rd.T1 = red[PT_T1] + T1h; rd.nonfinite = red[PT_NONFINITE];
+      rd.T0 = (st.T0g_held ? st.T0g : red[PT_T0]) + st.T0h; rd.T1 = red[PT_T1] + T1h; rd.nonfinite = red[PT_NONFINITE];
     }
     if (ex.type == CMD_LEAF) {                 // tree terms of the hyper coordinates, level by level
       NodeVals nv[NK];
@@ -479,9 +479,11 @@ PPCX_HD bool chain_step_pipelined(const Lanes& ln, const Dims& d, ChainScalars& 
                                   const double* red, const VecRef& hv, const ChainIO& io, Reduced& rd, Cmd& nc, bool spec) {
   if (st.phase != PH_START && cmd_evaluates(ex) && !ex.evaluated) {
     nc = ex; nc.evaluated = 1; nc.updated = 1;
+    st.T0g = red[PT_T0]; st.T0g_held = 1;      // left by the round that applied the command (its slab is the one reduced here)
     return false;
   }
   chain_step(ln, d, st, ta, ex, red, st.phase != PH_START, hv, io, rd, nc);
+  st.T0g_held = 0;
   nc.updated = 0;
   nc.evaluated = (spec && spec_continues(ex, nc)) ? 1 : 0;
   return true;

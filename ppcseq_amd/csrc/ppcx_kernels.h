@@ -46,7 +46,6 @@ struct GeneArgs {
   double* draws; long draws_chain_stride;   // PRE_STORE_DRAW
   const double* logtab;         // log table (global memory), staged in LDS for coord_consts
   int spec;                     // anticipate the next leaf's position (models whose cell paths read the constants only)
-  long long* trace;             // development builds (-DPPCX_TRACE_GENE): [workgroups][8] phase timestamps of one launch, else null
 };
 
 enum StepPhase : int { STEP_REDUCE = 1, STEP_ADVANCE = 2 };
@@ -56,7 +55,8 @@ struct StepArgs {
   const ChainState* states_in; ChainState* states_out;   // double-buffered between rounds
   const Cmd* cmds_in; Cmd* cmds_out;
   const double* hyper_in; double* hyper_out;             // [chains][V_COUNT][8]
-  const double* partials; int nblocks_close;             // [chains][nblocks_close][PT_COUNT]
+  const double* partials; int nblocks_close;             // [chains][slab_stride][PT_COUNT], rows 0 .. nblocks_close - 1 are summed
+  int slab_stride;
   const double* t0; int nblocks_update;                  // [chains][nblocks_update]
   double* red;                                           // [chains][PT_COUNT]
   double* draws; long draws_chain_stride;

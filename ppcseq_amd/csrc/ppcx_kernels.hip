@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   if (a.upd_vecs) { r_tab[0] = a.upd_logtab[tid]; r_tab[1] = a.upd_logtab[tid + 256]; }
   static_assert(2 * kLogTabSize == 512, "two table entries per thread");
   if (a.phases & STEP_REDUCE) {
-    const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
+    const double* slab = a.partials + (long)chain * a.slab_stride * PT_COUNT;
     // one pass: thread (c, ch) sums rows ch, ch+8, ... of columns c, c+32, c+64, loads of several rows in flight; then
     // column v = sum over the eight row groups in a fixed order. All columns are loaded (stale ones included) so that
     // these loads do not wait for the command that says which sums it produced; the selection happens afterwards.
@@ -480,7 +480,7 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
   {
     // the gene kernel's slab, every column (the kinetic energy of fresh momenta arrives in column PT_T0 here); a carried
     // round reads a stale slab and ignores the sums
-    const double* slab = a.partials + (long)chain * a.nblocks_close * PT_COUNT;
+    const double* slab = a.partials + (long)chain * a.slab_stride * PT_COUNT;
     const int c = tid & 31, ch = tid >> 5;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     const bool in2 = c + 64 < PT_COUNT;
@@ -567,35 +567,26 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC_FAST) void ppcx_ls_kernel(Logl
   loglik_role<CM, false, true>(a, jb, col, lds);
 }
 
-#ifdef PPCX_TRACE_GENE
-#define PPCX_GT(k) do { if (ga.trace && threadIdx.x == 0) ga.trace[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = (long long)wall_clock64(); } while (0)
-#else
-#define PPCX_GT(k) ((void)0)
-#endif
+// One gene's part of a pipelined round, for the lane that owns gene g (g >= G: a lane without a gene, which only takes part
+// in the reductions): the command's work on the gene's coordinates, the close of the evaluated position, the anticipated
+// constants. No workgroup barrier inside; the wavefront's partial sums go to wacc[wave][...]. Everything the lane reads is
+// requested in one burst at the start: nothing else hides this kernel's latency.
+// (Kept apart from the kernel's barriers because a fused one-launch round was built on it in round 3 -- the wavefront that
+// swept a range of genes closed them itself after its chain's state machine, a workgroup of the same launch, had published the
+// command through a flag -- and measured: 90 us per launch against 63 + 20 for the two launches)
 template <int CM>
-__global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gene_kernel(GeneArgs ga) {
+__device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c, int chain, int g,
+                                               double* wacc, const double* s_tab, int wave, int lane, bool do_update, bool do_close) {
   constexpr int NCM = CM + 1;
   constexpr int NS = GeneSums<CM>::N;
-  __shared__ double wacc[4 * PT_COUNT];
-  __shared__ double s_tab[2 * kLogTabSize];
   const CloseArgs& a = ga.c;
-  const int chain = blockIdx.y;
-  PPCX_GT(0);
-  const Cmd& c = a.cmds[chain];
-  if (c.type == CMD_DONE) return;
-  const bool do_update = !c.updated, do_close = c.evaluated && c.type != CMD_FLUSH;      // uniform over the launch's chain
-  if (!do_update && !do_close) return;
   const Dims& d = a.d;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
   const double* sums = a.sums + (long)chain * NS * d.G;
-  const int g = blockIdx.x * 256 + tid;
   const bool any_generic = !d.x0_is_one || (d.C >= 2 && d.K > 0);
   GeneCtx<CM> x;
   gene_index<CM>(d, g, x);
-  // ---- everything this thread reads is requested here, in one round trip, before anything is stored
-  const double tab0 = ga.logtab[tid], tab1 = ga.logtab[tid + 256];
-  static_assert(2 * kLogTabSize == 512, "two table entries per thread");
+  // ---- everything this lane reads is requested here, in one round trip, before anything is stored
   CoordCache cache[NCM];
   double p_cur[NCM], minv[NCM];
 #pragma unroll
@@ -623,8 +614,8 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
 #pragma unroll
         for (int cc = 0; cc < CM; ++cc) if (cc < d.C) acc.Tx[cc] = sums[(3 + cc) * G + g];
       }
-      // phi of the position being closed: written with the constants the log-likelihood kernel evaluated (for a leaf
-      // anticipated by the previous gene kernel the update below does not touch them)
+      // phi of the position being closed: written with the constants the log-likelihood part evaluated (for a leaf
+      // anticipated by the previous round the update below does not touch them)
       phi = v.at(V_C0, x.idx[1]);
     }
     gene_data_load<CM>(d, x.gg, a.Sy, a.SyE, a.SyX, a.SX, a.ncell, a.Lg1, gd);
@@ -639,22 +630,15 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
       }
     }
   }
-  s_tab[tid] = tab0; s_tab[tid + 256] = tab1;
-  __syncthreads();
-  PPCX_GT(1);
   // ---- the command's work on the gene's coordinates
   double T0 = 0.0;
   double* draws = ga.draws ? ga.draws + (long)chain * ga.draws_chain_stride : nullptr;
   if (do_update) gene_coord_update<CM, true>(d, c, v, x, draws, &T0, s_tab, !do_close, cache, p_cur, minv, !do_close);
-  double* slab = a.partials + ((long)chain * gridDim.x + blockIdx.x) * PT_COUNT;
   if (!do_close) {                             // the command's position has not been evaluated yet: nothing to close
     double t0v[1] = {T0};
     block_accumulate<1>(t0v, wacc, wave, lane);
-    __syncthreads();
-    if (tid == 0) slab[PT_T0] = ((wacc[0] + wacc[PT_COUNT]) + wacc[2 * PT_COUNT]) + wacc[3 * PT_COUNT];
     return;
   }
-  PPCX_GT(2);
   // ---- close the evaluated position
   x.gp.coef[0] = x.q[0];
 #pragma unroll
@@ -664,7 +648,6 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
   double pn[NCM], gn[NCM], part[10];
   gene_finish_vals<CM>(d, c, v, x, acc, gd, p_cur, minv, part, pn, gn);
   part[PT_T0] = T0;
-  PPCX_GT(3);
   block_accumulate<10>(part, wacc, wave, lane);
   if (c.type == CMD_LEAF) {
     NodeVals nv[NCM];
@@ -694,22 +677,41 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
       for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_top_dots(v, x.idx[j], c.dir, pn[j], minv[j], nv[j], top);
       block_accumulate<6>(top, wacc + PT_TOP, wave, lane);
     }
-    PPCX_GT(4);
-    // ahead of the state machine: the constants of the position the next leaf of this subtree direction evaluates
+    // ahead of the state machine: the constants of the position the next leaf evaluates if the tree goes on
     if (ga.spec) gene_spec_consts<CM>(d, c, v, x, pn, gn, minv, s_tab);
   }
-  PPCX_GT(5);
-  __syncthreads();
+}
+// after a workgroup barrier: the four wavefronts' partial sums -> the workgroup's row of the slab
+__device__ __forceinline__ void gene_block_finish(const Cmd& c, bool do_update, bool do_close, const double* wacc, double* slab, int tid) {
+  if (!do_close) {
+    if (tid == 0) slab[PT_T0] = ((wacc[0] + wacc[PT_COUNT]) + wacc[2 * PT_COUNT]) + wacc[3 * PT_COUNT];
+    return;
+  }
   const int np = parts_used(c);
   for (int k = tid; k < np; k += 256) {
     if (k == PT_T0 && !do_update) continue;    // left by the round that applied the command
     const bool used = k < 10 || (k >= PT_DOTS && k < PT_DOTS + 6 * c.n_merge) || (k >= PT_TOP && c.subtree_complete);
     slab[k] = used ? ((wacc[k] + wacc[PT_COUNT + k]) + wacc[2 * PT_COUNT + k]) + wacc[3 * PT_COUNT + k] : 0.0;
   }
-  PPCX_GT(6);
-#ifdef PPCX_TRACE_GENE
-  if (ga.trace && threadIdx.x == 0) ga.trace[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = ((long long)c.type << 32) | ((long long)c.n_merge << 8) | (do_update ? 1 : 0) | (c.subtree_complete ? 2 : 0);
-#endif
+}
+
+template <int CM>
+__global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gene_kernel(GeneArgs ga) {
+  __shared__ double wacc[4 * PT_COUNT];
+  __shared__ double s_tab[2 * kLogTabSize];
+  const CloseArgs& a = ga.c;
+  const int chain = blockIdx.y;
+  const Cmd& c = a.cmds[chain];
+  if (c.type == CMD_DONE) return;
+  const bool do_update = !c.updated, do_close = c.evaluated && c.type != CMD_FLUSH;      // uniform over the launch's chain
+  if (!do_update && !do_close) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  s_tab[tid] = ga.logtab[tid]; s_tab[tid + 256] = ga.logtab[tid + 256];
+  static_assert(2 * kLogTabSize == 512, "two table entries per thread");
+  __syncthreads();
+  gene_wave_part<CM>(ga, c, chain, blockIdx.x * 256 + tid, wacc, s_tab, wave, lane, do_update, do_close);
+  __syncthreads();
+  gene_block_finish(c, do_update, do_close, wacc, a.partials + ((long)chain * gridDim.x + blockIdx.x) * PT_COUNT, tid);
 }
 
 // in-process gene shards: every shard ends with the sum over shards (fixed order => identical bits everywhere)

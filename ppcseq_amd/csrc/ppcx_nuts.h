@@ -284,6 +284,9 @@ struct ChainScalars {
   double H0, lsw_tree, sum_metro;
   double V_sample;
   double T0h;                    // kinetic energy of the fresh hyper momenta
+  double T0g; int T0g_held;      // pipelined rounds: the gene coordinates' share of it, taken when the command is carried (the
+                                 // round after the one that drew the momenta), so that it does not depend on the slab's
+                                 // layout at the round that closes the command
   double mu, s_bar, x_bar; int da_counter;
   int win_next, win_size, win_counter, wn;
   double lp_eval;                // CMD_EVAL result
@@ -326,7 +329,7 @@ PPCX_HD void state_init(ChainState& cs, const NutsConfig& cfg, int local_chain, 
   }
   st.it = 0; st.init_attempt = 0; st.eps_dir = 0; st.eps_attempt = 0; st.eps_call = 0; st.eps = cfg.stepsize0;
   st.depth = 0; st.leaf_n = 0; st.dir = 1; st.n_leapfrog = 0; st.divergent = 0; st.rng_j = 0;
-  st.H0 = 0; st.lsw_tree = 0; st.sum_metro = 0; st.V_sample = 0; st.T0h = 0;
+  st.H0 = 0; st.lsw_tree = 0; st.sum_metro = 0; st.V_sample = 0; st.T0h = 0; st.T0g = 0; st.T0g_held = 0;
   st.mu = 0; st.s_bar = 0; st.x_bar = 0; st.da_counter = 0;
   st.win_next = st.init_buffer + st.window - 1; st.win_size = st.window; st.win_counter = 0; st.wn = 0;
   st.lp_eval = 0; st.total_leapfrogs = 0;

@@ -8,7 +8,8 @@ from ppcseq_amd.synth import synth
 
 
 def fit(m, pipe, groups=1, **kw):
-    os.environ["PPCX_PIPELINE"] = str(pipe)
+    """pipe: 0 = three-launch round, 1 = pipelined (two launches)"""
+    os.environ["PPCX_PIPELINE"] = "0" if pipe == 0 else "1"
     os.environ["PPCX_STREAM_GROUPS"] = str(groups)
     t0 = time.perf_counter()
     f = m.fit_nuts(**kw)
@@ -37,8 +38,8 @@ d = synth(20000, 200, seed=20253)
 m = L.Model(d["counts"], d["X"], d["exposure"], d["K"])
 res = {}
 for rep in range(2):
-    for pipe in (0, 1):
-        for groups in (1, 2, 3):
+    for pipe in [int(x) for x in os.environ.get("MODES", "0,1").split(",")]:
+        for groups in [int(x) for x in os.environ.get("NGROUPS", "1,2,3").split(",")]:
             f, dt = fit(m, pipe, groups, chains=8, iter=400, warmup=150, seed=1 + rep)
             tm, kt = f.timing(), f.kernel_times()
             dg = f.diagnostics()

@@ -369,15 +369,16 @@ def test_cfg1_stress_all_genes_as_controls(L, bundled):
 
 
 def test_cfg3_warmup_follows_the_oracle_at_full_tree_depth(L):
-    """BASELINE config 3 at full size against the oracle's NUTS at Stan's defaults (max_treedepth 10): the first 30 warm-up
+    """BASELINE config 3 at full size against the oracle's NUTS at Stan's defaults (max_treedepth 10): the first 45 warm-up
     iterations of 2 chains. The oracle needs ~0.25 s per gradient here, so its run is a committed fixture
-    (tests/golden/cfg3_nuts_oracle.npz, written by tests/golden/make_cfg3_nuts_fixture.py: 756 gradient evaluations, trees up to
-    63 leapfrogs). Tree sizes, depths and divergences must be identical, step sizes equal to 1e-8, acceptance statistics to
-    1e-6, for every one of the 30 iterations -- in both round structures."""
+    (tests/golden/cfg3_nuts_oracle.npz, written by tests/golden/make_cfg3_nuts_fixture.py: 2144 gradient evaluations, trees up to
+    255 leapfrogs). Tree sizes, depths and divergences must be identical in every one of the 45 iterations; step sizes agree
+    to 1e-8 over the first 30 and to 1e-6 over all 45 (rounding differences of the two implementations grow along the
+    trajectories: 0 at the start, 9e-8 at iteration 45), acceptance statistics to 1e-5 -- in both round structures."""
     import os
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_nuts_oracle.npz"))
     G, S, data_seed, chains, n_iter, seed = (int(v) for v in z["config"])
-    assert (G, S, data_seed) == (CONFIGS["cfg3"][0], CONFIGS["cfg3"][1], CONFIGS["cfg3"][2])
+    assert (G, S, data_seed) == (CONFIGS["cfg3"][0], CONFIGS["cfg3"][1], CONFIGS["cfg3"][2]) and n_iter >= 45
     d = ind.synth(G, S, seed=data_seed)
     m = L.Model(d["counts"], d["X"], d["exposure"], d["K"])
     try:
@@ -391,9 +392,10 @@ def test_cfg3_warmup_follows_the_oracle_at_full_tree_depth(L):
             f.close()
             assert np.array_equal(dg["n_leapfrog"], z["n_leapfrog"]), (pipe, dg["n_leapfrog"].tolist(), z["n_leapfrog"].tolist())
             assert np.array_equal(dg["treedepth"], z["treedepth"]) and np.array_equal(dg["divergent"], z["divergent"])
-            assert np.max(np.abs(dg["stepsize"] / z["stepsize"] - 1)) < 1e-8
-            assert np.max(np.abs(dg["accept"] - z["accept"])) < 1e-6
-        assert z["n_leapfrog"].max() >= 63 and z["n_leapfrog"].sum() > 700
+            rel = np.abs(dg["stepsize"] / z["stepsize"] - 1)
+            assert rel[:, :30].max() < 1e-8 and rel.max() < 1e-6, (pipe, rel.max(axis=0))
+            assert np.max(np.abs(dg["accept"] - z["accept"])) < 1e-5
+        assert z["n_leapfrog"].max() >= 255 and z["n_leapfrog"].sum() > 2000
     finally:
         m.close()
 
