@@ -338,11 +338,13 @@ def test_cfg5_two_pass_full_size_against_generator_truth(L):
     for g, s in d["injected"]:
         sw = res.loc[res["symbol"] == genes[g], "sample_wise_data"].iloc[0]
         hit += bool(sw["deleterious_outliers"].to_numpy()[s])
-    assert hit >= 0.7 * len(d["injected"])
+    assert hit >= 0.78 * len(d["injected"])                # 82-83 of 100 at five sampler seeds (profiles/r03_cfg5_seeds.json)
     inj = {g for g, _ in d["injected"]}
     flag = dict(zip(res["symbol"], res["tot_deleterious_outliers"]))
     clean = [i for i in range(K) if i not in inj]
-    assert sum(flag[genes[i]] > 0 for i in clean) / len(clean) < 0.12       # nominal 5 % of genes
+    # nominal 5 % of genes; 6.2-7.3 % at five sampler seeds, mostly the same genes: the data's and the threshold arithmetic's
+    # property (profiles/r03_cfg5_seeds.json), not sampler noise
+    assert sum(flag[genes[i]] > 0 for i in clean) / len(clean) < 0.09
 
 
 def test_cfg1_stress_all_genes_as_controls(L, bundled):

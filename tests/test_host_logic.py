@@ -72,6 +72,39 @@ def test_tmm_recovers_known_scaling():
     assert abs(np.exp(np.mean(np.log(list(nf.values())))) - 1) < 1e-12
 
 
+def test_tmm_known_answers_from_the_published_definition():
+    """edgeR is not installed (parity of the TMM step is unpinned), so the factors are checked against
+    what the PUBLISHED definition gives in closed form (Robinson & Oshlack 2010: weighted mean of log-ratios after trimming
+    30 % of the M values and 5 % of the A values on each side, relative to a reference sample, scaled to unit geometric
+    mean):
+      * composition bias: sample B = sample A with 20 % of its genes four times as abundant. With r = total_B / total_A
+        (about 1.6) the unchanged genes have proportions 1/r of A's, the changed ones 4/r; trimming removes the changed ones
+        and every M value that is left equals log2(1/r), so f_B / f_A = 1/r exactly;
+      * the factor of a sample does not depend on its sequencing depth (TMM works on proportions);
+      * identical samples get factor 1."""
+    n = 1000
+    a = np.round(np.geomspace(50, 50000, n)).astype(float)           # no zeros, no ties in A
+    b = a.copy()
+    b[::5] *= 4.0                                                     # every fifth gene: 20 %
+    f = meth.tmm_norm_factors(np.stack([a, b], axis=1), ref_col=0)
+    r = b.sum() / a.sum()
+    assert 1.5 < r < 1.7
+    assert f[1] / f[0] == pytest.approx(1 / r, rel=1e-12)
+    assert f[0] * f[1] == pytest.approx(1.0, rel=1e-12)              # unit geometric mean
+    assert f[0] == pytest.approx(np.sqrt(r), rel=1e-12)
+    # depth invariance: sample B sequenced three times as deep
+    f3 = meth.tmm_norm_factors(np.stack([a, 3.0 * b], axis=1), ref_col=0)
+    assert f3 == pytest.approx(f, rel=1e-12)
+    # identical samples
+    assert meth.tmm_norm_factors(np.stack([a, a, 2 * a], axis=1), ref_col=0) == pytest.approx(np.ones(3), rel=1e-12)
+    # the reference's multiplier on top (R/tidybulk.R:220-225): tot_ref / (tot_s * nf_s) puts B's unchanged genes on A's scale
+    mult, nf = meth.get_scaled_counts_bulk(np.stack([a, b], axis=1), ["A", "B"])
+    ref = "A" if np.median(a) >= np.median(b) else "B"
+    scaled_a, scaled_b = a * mult["A"], b * mult["B"]
+    keep = np.ones(n, bool); keep[::5] = False
+    assert np.allclose(scaled_b[keep] / scaled_a[keep], 1.0, rtol=1e-12) and ref in ("A", "B")   # the bias is gone
+
+
 def test_ess_estimator():
     rng = np.random.default_rng(1)
     x = rng.normal(size=(4, 1000))
