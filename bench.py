@@ -7,7 +7,7 @@ on the synthetic 20,000 genes x 200 samples matrix of BASELINE config 3, inputs 
 HBM. `value` = sum over steps of the pooled bulk-ESS (min over the six hyper-parameters and lp__) divided
 by the summed wall time (barrier + device synchronise on both sides, max over ranks). Chains are the
 sharded unit (weak scaling: chains/GPU fixed); there is no collective on the data path. The timed fits run the
-library's defaults (pipelined rounds, two chain groups on their own streams); the `roofline` sample comes from one
+library's defaults (pipelined rounds, three chain groups on their own streams); the `roofline` sample comes from one
 more fit on a single in-order stream, where HIP events around a launch time that launch alone.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--stream-groups", type=int, default=0,
-                    help="chain groups on their own streams for the timed fits (0 = the library's default: 2 from six chains on)")
+                    help="chain groups on their own streams for the timed fits (0 = the library's default: 3 from eight chains on, 2 from six)")
     ap.add_argument("--single-stream-steps", type=int, default=1,
                     help="fits on ONE in-order stream (PPCX_STREAM_GROUPS=1) after the timed ones: the source of the roofline's "
                          "per-launch timings, reported beside the headline (0 = skip: no roofline object)")
@@ -277,7 +277,7 @@ def main():
                        "divergent_after_warmup": div_total,
                        "round_structure": ("pipelined: merged log-likelihood / state-machine launch + gene kernel" if os.environ.get("PPCX_PIPELINE", "1") != "0" and args.mode == "chains"
                                            else "three launches: log-likelihood, close, step + update"),
-                       "stream_groups": args.stream_groups if args.stream_groups > 0 else ("library default (2 from six chains on)" if args.mode == "chains" else 1),
+                       "stream_groups": args.stream_groups if args.stream_groups > 0 else ("library default (3 from eight chains on, 2 from six)" if args.mode == "chains" else 1),
                        "rounds_last_step_all_groups": int(rounds_last),
                        "us_per_grad_eval_per_chain": round(1e6 * tot_time * world * nch / max(tot_grad, 1), 2)},
             "roofline": roof, "ppc": ppc_obj, "cpu_baseline": cpu, "as_named_cfg3_one_chain_per_gpu": as_named, "single_stream": single,

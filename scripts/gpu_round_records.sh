@@ -9,7 +9,7 @@ set -e
 R=${1:-r03}
 OUT=gpurun_out/records_$R
 mkdir -p $OUT
-python3 bench.py 2> $OUT/bench_default.err | grep '^{' > $OUT/${R}_bench_default.json
+python3 bench.py --steps 20 --warmup 5 2> $OUT/bench_default.err | grep '^{' > $OUT/${R}_bench_default.json    # as the driver runs it
 python3 bench.py --mode shards --genes 50000 --samples 500 --chains-per-gpu 4 --steps 1 --warmup 0 --no-cpu-baseline --as-named-steps 0 2> $OUT/cfg4.err | grep '^{' > $OUT/${R}_bench_cfg4_shards_1gpu.json
 python3 scripts/gpu_cfg5.py 2> $OUT/cfg5.err | grep '^{' > $OUT/${R}_cfg5_two_pass.json
 python3 scripts/gpu_advi_time.py 2> $OUT/advi.err | grep '^{' > $OUT/${R}_advi_cfg3.json

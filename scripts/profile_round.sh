@@ -4,7 +4,7 @@
 #      log-likelihood / state-machine kernel then covers all 8 chains, which is what the bench line's roofline sample times
 #      (bench.py takes that sample from a single-stream fit also in its default run); the posterior-predictive kernel's
 #      launches of the `ppc` object are in the same statistics
-#   2. the same with the library's default (two chain groups on their own streams): what `value` is measured on
+#   2. the same with the library's default (chain groups on their own streams): what `value` is measured on
 #   3./4. PMC passes (FETCH_SIZE, WRITE_SIZE separately: TCC slots) on a shortened fit to bound the CSV size
 set -e
 R=${1:-r03}
