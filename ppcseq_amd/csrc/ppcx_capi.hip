@@ -216,7 +216,7 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
       for (int c = 0; c < C; ++c) { SyX[(size_t)c * G + g] += (double)y * m->X_host[(size_t)c * S + s]; SX[(size_t)c * G + g] += m->X_host[(size_t)c * S + s]; }
     }
     Sy[g] = sy; SyE[g] = sye; ncell[g] = nc; Lg1[g] = lg1;
-    tier[g] = tail_tier(ymin);
+    tier[g] = gene_tier(ymin, nhi[g], S);
     if (getenv("PPCX_NO_TAIL_TIERS")) tier[g] = 0;           // development aid: every pass with the full tails
     nhi[g] |= tier[g] << 28;                                 // CellData::n_hi
   }

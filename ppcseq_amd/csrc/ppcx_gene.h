@@ -91,7 +91,7 @@ struct CellData {                // the chain-independent inputs of the log-like
   const unsigned* low;           // the cells with 0 <= count <= 7, gene after gene: (count << 16) | sample
   const int* low_start;          // [G + 1] a gene's range in `low`
   const int* n_hi;               // [G] number of cells with count >= 8 (bits 0..27) and the gene's tail tier (bits 28..29:
-                                 // ppcx_math.h tail_tier of the smallest of those counts)
+                                 // ppcx_math.h gene_tier: from the smallest of those counts, 0 unless all S cells are such)
   const unsigned short* low_m;   // [G][8] entry k < 7: number of list cells with count > k
 };
 
@@ -106,7 +106,7 @@ PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* 
   int y0 = p[0], y1 = p[L], y2 = p[2 * L], y3 = p[3 * L];
   int k = 0;
 #define PPCX_SWEEP_CELL(Y, E, XB, COND)                                                         \
-  if ((COND) && (Y) >= kLowCount) {                                                             \
+  if ((COND) && (TAIL < 4 || (Y) >= kLowCount)) {      /* tiers 1, 2: every cell of the gene is a row-sweep cell */ \
     if (TWO) { const double rho_ = cell_eval<CM, TAIL>(Y, E, (XB) != 0.0 ? A1 : A, gp, tab, acc); \
                acc.Tx[1] = fma(XB, rho_, acc.Tx[1]); }                                          \
     else (void)cell_eval<CM, TAIL>(Y, E, A, gp, tab, acc);                                      \

@@ -151,6 +151,9 @@ constexpr double kStirlingF1[2] = {8.33333333333102361e-02, -2.77776566774899170
 constexpr double kStirlingG1[2] = {8.33333333332178378e-02, -8.33327278343192618e-03};
 // tier of a gene from its smallest count among the row-sweep cells (counts >= 8): 2, 1 or 0
 PPCX_HD int tail_tier(int min_sweep_count) { return min_sweep_count >= kTailX1 ? 2 : (min_sweep_count >= kTailX2 ? 1 : 0); }
+// ... granted only to a gene ALL of whose S cells are row-sweep cells (no count below 8, none excluded): a pass of tier 1 or 2
+// then evaluates every cell without looking at its count (no compare, no branch per cell)
+PPCX_HD int gene_tier(int min_sweep_count, int n_sweep, int S) { return n_sweep == S ? tail_tier(min_sweep_count) : 0; }
 
 PPCX_HD void stirling_tails(double rx, double* lgt, double* dgt) {
   const double r2 = rx * rx;

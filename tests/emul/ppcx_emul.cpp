@@ -38,7 +38,7 @@ static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, c
     if (y < kLowCount) { m.low.push_back(((unsigned)y << 16) | (unsigned)s); for (int k = 0; k < y; ++k) m.low_m[(size_t)g * 8 + k]++; } else { m.nhi[g]++; if (y < ymin) ymin = y; }
     m.Sy[g] += y; m.SyE[g] += (double)y * expo[s]; m.ncell[g] += 1; m.Lg1[g] += lgamma((double)y + 1.0);
     for (int c = 0; c < C; ++c) { m.SyX[(size_t)c * G + g] += (double)y * X[(size_t)c * S + s]; m.SX[(size_t)c * G + g] += X[(size_t)c * S + s]; }
-  } m.nhi[g] |= tail_tier(ymin) << 28; }
+  } m.nhi[g] |= gene_tier(ymin, m.nhi[g], S) << 28; }
   m.low_start[G] = (int)m.low.size();
   m.low.resize(m.low.size() + 64, 0u);
   return m;
