@@ -22,7 +22,8 @@ namespace ppcx {
 // Lean fp64 reciprocal and logarithm for the per-cell loop. ocml's log()/division are correctly
 // rounded via double-double arithmetic (~65 and ~22 VALU instructions); the cell loop is bound by
 // fp64 issue, so it uses:
-//   fast_rcp : v_rcp_f64 seed + one Newton step (relative error ~1e-16; two FMAs)
+//   fast_rcp : v_rcp_f64 seed (accurate to 4.6e-8 only) + one Newton step, two FMAs: relative error 1.2e-16 on average,
+//              2.2e-15 at most (scripts/micro/rcp_accuracy.hip, profiles/r03_valu_rates_micro.txt)
 //   fast_log : the classic argument reduction x = 2^k m, m in [sqrt(1/2), sqrt 2), s = f/(2+f),
 //              log m = f - (f^2/2 - s (f^2/2 + R(s^2))) with the 7-term minimax R of Sun's fdlibm
 //              e_log.c (public domain algorithm; max error < 1 ulp), ~30 VALU instructions.
