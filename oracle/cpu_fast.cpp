@@ -48,7 +48,7 @@ void* ppcf_model_create(int G, int S, int C, int K, const int32_t* counts, const
       m->Sy[g] += y; m->SyE[g] += (double)y * expo[s]; m->ncell[g] += 1; m->Lg1[g] += lgamma((double)y + 1.0);
       for (int c = 0; c < C; ++c) { m->SyX[(size_t)c * G + g] += (double)y * X[(size_t)c * S + s]; m->SX[(size_t)c * G + g] += X[(size_t)c * S + s]; }
     }
-    m->nhi[g] |= tail_tier(ymin) << 28;
+    m->nhi[g] |= gene_tier(ymin, m->nhi[g], S) << 28;
   }
   m->low_start[G] = (int)m->low.size(); m->low.resize(m->low.size() + 64, 0u);
   m->tab.resize(2 * kLogTabSize); fill_log_table(m->tab.data());

@@ -20,23 +20,23 @@ namespace {
 constexpr int kMaxRanks = 8;
 constexpr size_t kSlotDoubles = 16384;          // the library reduces chains x 76 sums, and 5 for the guard
 struct Shared {
-  volatile int arrived[2];                      // two alternating barrier counters
+  volatile long long arrived;                   // arrivals at barriers, ever: barrier k is complete when it reaches nranks (k + 1)
   volatile int attached;
   double slot[kMaxRanks][kSlotDoubles];
 };
-struct Comm { Shared* sh; int nranks, rank, phase; char name[64]; double* host; };
+struct Comm { Shared* sh; int nranks, rank; long long phase; char name[64]; double* host; };
 const double kTimeoutSeconds = 60.0;            // a peer that never arrives: report instead of hanging the box
 
 double now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
-// all ranks reach the barrier (counter `b` counts arrivals and is reset by the last rank of the NEXT use of the other one)
+// all ranks reach the barrier. One counter that only grows: nothing is ever reset, so a rank that runs ahead into the next
+// barrier cannot have its arrival wiped by a slower rank's reset (two alternating counters reset by the last arriver had
+// exactly that race: once in a few hundred runs both ranks then waited for the timeout).
 int barrier(Comm* c) {
   Shared* s = c->sh;
-  const int b = c->phase & 1;
-  c->phase++;
-  const int n = __sync_add_and_fetch(&s->arrived[b], 1);
-  if (n == c->nranks) s->arrived[b ^ 1] = 0;     // everybody has left the other counter's barrier long ago
+  const long long target = (long long)c->nranks * ++c->phase;
+  __sync_add_and_fetch(&s->arrived, 1LL);
   const double t0 = now();
-  while (s->arrived[b] < c->nranks) {
+  while (s->arrived < target) {
     sched_yield();
     if (now() - t0 > kTimeoutSeconds) return 1;
   }

@@ -101,6 +101,36 @@ def test_low_counts_across_the_lgamma_regimes(L, oracle, seed):
         m.close()
 
 
+def test_tail_tiers_only_for_genes_without_list_cells(L, oracle):
+    """Genes whose counts are all >= 32 / >= 256 take the shorter Stirling tails, in passes that evaluate every cell without
+    looking at its count (ppcx_math.h gene_tier) -- so a gene with large counts AND a count below 8 or an excluded cell
+    must not be among them. Large-count genes with a zero, a 7 and excluded cells beside genes without any, every number of
+    lanes per gene (genes of both kinds share passes), exclusions added and removed on the same model."""
+    G, S, K = 48, 37, 5
+    d = ind.synth(G, S, K=K, seed=11)
+    rng = np.random.default_rng(11)
+    counts = d["counts"].copy()
+    counts[:16] = rng.integers(300, 90000, (16, S))
+    counts[16:32] = rng.integers(32, 250, (16, S))
+    counts[2, 5] = 0; counts[3, 0] = 7; counts[20, 36] = 1; counts[7, :] = 1000; counts[7, 9] = 6
+    excl = np.array([9 * S + 4, 9 * S + 5, 25 * S + 0, 40 * S + 3], np.int32)      # cells of a tier-2, a tier-1 and a plain gene
+    u = rng.uniform(-0.6, 0.6, (2, oracle.dim(G, 2, K))); u[:, 3:3 + G] += 5.5
+    m = L.Model(counts, d["X"], d["exposure"], K)
+    try:
+        for ex in (None, excl, None):
+            m.set_exclusions(ex if ex is not None else np.zeros(0, np.int32))
+            mo = oracle.model(counts, d["X"], d["exposure"], K, excl=ex)
+            for lanes in (0, 1, 4, 8, 64):
+                m.set_launch(lanes, 0)
+                lp, g = m.log_prob_grad(u)
+                for i in range(2):
+                    lpo, go = oracle.log_prob_grad(mo, u[i])
+                    assert abs(lp[i] - lpo) <= 1e-11 * max(1.0, abs(lpo)), (lanes, i)
+                    assert np.max(np.abs(g[i] - go) / (1 + np.abs(go))) <= 1e-10, (lanes, i)
+    finally:
+        m.close()
+
+
 def test_extreme_counts_zero_rows_and_generic_design(L, oracle):
     """Zeros, the bundled maximum 2,580,228, an all-zero gene, and a design whose first column is not 1
     (no E_s*A_g factorisation)."""
