@@ -123,8 +123,12 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
   const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
   for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
   if (any_generic) {
-    for (int i = tid; i < S; i += 256) sExpo[i] = a.exposure[i];
-    for (int i = tid; i < S * C; i += 256) sX[i] = a.X[i];
+    if (GEN) {
+      for (int i = tid; i < S; i += 256) sExpo[i] = a.exposure[i];
+      for (int i = tid; i < S * C; i += 256) sX[i] = a.X[i];
+    } else {                                   // the two-group path reads the group column only
+      for (int i = tid; i < S; i += 256) sX[S + i] = a.X[S + i];
+    }
   }
   __syncthreads();
   if (p0 >= p1) return;
