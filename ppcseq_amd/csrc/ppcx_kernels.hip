@@ -119,9 +119,13 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
   double* sums = a.sums + (long)chain * NS * d.G;
   const int wave = tid >> 6, lane = tid & 63;
   const int p0 = a.bounds[jb * 4 + wave], p1 = a.bounds[jb * 4 + wave + 1];
-  for (int i = tid; i < 2 * kLogTabSize; i += 256) stab[i] = a.logtab[i];
+  // the fill: every workgroup of the launch reads the same few KB at the same time, so as few requests as possible -- 16 bytes
+  // per lane (the table and, for an even S, exp(exposure) are 16-byte aligned on both sides)
+  static_assert(2 * kLogTabSize == 2 * 256, "one 16-byte request per thread fills the table");
+  reinterpret_cast<double2*>(stab)[tid] = reinterpret_cast<const double2*>(a.logtab)[tid];
   const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
-  for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
+  if ((S & 1) == 0) { for (int i = tid; i < S / 2; i += 256) reinterpret_cast<double2*>(sE)[i] = reinterpret_cast<const double2*>(a.sampleE)[i]; }
+  else for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
   if (any_generic) {
     if (GEN) {
       for (int i = tid; i < S; i += 256) sExpo[i] = a.exposure[i];
@@ -702,7 +706,7 @@ __device__ __forceinline__ void gene_block_finish(const Cmd& c, bool do_update, 
 template <int CM>
 __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gene_kernel(GeneArgs ga) {
   __shared__ double wacc[4 * PT_COUNT];
-  __shared__ double s_tab[2 * kLogTabSize];
+  __shared__ __attribute__((aligned(16))) double s_tab[2 * kLogTabSize];
   const CloseArgs& a = ga.c;
   const int chain = blockIdx.y;
   const Cmd& c = a.cmds[chain];
@@ -710,8 +714,8 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
   const bool do_update = !c.updated, do_close = c.evaluated && c.type != CMD_FLUSH;      // uniform over the launch's chain
   if (!do_update && !do_close) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  s_tab[tid] = ga.logtab[tid]; s_tab[tid + 256] = ga.logtab[tid + 256];
   static_assert(2 * kLogTabSize == 512, "two table entries per thread");
+  reinterpret_cast<double2*>(s_tab)[tid] = reinterpret_cast<const double2*>(ga.logtab)[tid];     // one 16-byte request per thread
   __syncthreads();
   gene_wave_part<CM>(ga, c, chain, blockIdx.x * 256 + tid, wacc, s_tab, wave, lane, do_update, do_close);
   __syncthreads();
