@@ -709,7 +709,9 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
   __shared__ __attribute__((aligned(16))) double s_tab[2 * kLogTabSize];
   const CloseArgs& a = ga.c;
   const int chain = blockIdx.y;
-  const Cmd& c = a.cmds[chain];
+  // the chain's command, copied into registers HERE: read through the reference its fields would be requested where they are
+  // first used -- after the barrier below, a scalar round trip in front of the loads whose addresses depend on them
+  const Cmd c = a.cmds[chain];
   if (c.type == CMD_DONE) return;
   const bool do_update = !c.updated, do_close = c.evaluated && c.type != CMD_FLUSH;      // uniform over the launch's chain
   if (!do_update && !do_close) return;
