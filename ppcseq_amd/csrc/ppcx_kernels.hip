@@ -98,6 +98,25 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
 template <int CM, bool GEN, bool PIPE>
 __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col, double* lds) {
   if (jb >= a.nbpc) return;
+  constexpr int NS = GeneSums<CM>::N;
+  const Dims& d = a.d;
+  const int S = d.S, C = d.C;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  // What the workgroup stages in LDS and the wavefront's range are requested FIRST, before the chain's command is looked at
+  // (three dependent scalar round trips: active list, command, its fields): the start of a launch is a chain of round trips
+  // that every wavefront of the chip walks at the same time, and these need not be links of it. The first 256 (512) entries
+  // travel in registers across the checks; longer per-sample arrays are completed afterwards.
+  static_assert(2 * kLogTabSize == 2 * 256, "one 16-byte request per thread fills the table");
+  const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
+  const bool evenS = (S & 1) == 0;             // then exp(exposure) is 16-byte aligned on both sides
+  const int p0 = a.bounds[jb * 4 + wave], p1 = a.bounds[jb * 4 + wave + 1];
+  const double2 f_tab = reinterpret_cast<const double2*>(a.logtab)[tid];
+  double2 f_e = {0.0, 0.0};
+  if (evenS) { if (tid < S / 2) f_e = reinterpret_cast<const double2*>(a.sampleE)[tid]; }
+  else if (tid < S) f_e.x = a.sampleE[tid];
+  double f_x = 0.0;
+  if (!GEN && any_generic && tid < S) f_x = a.X[S + tid];      // the two-group path reads the group column only
   const int chain = a.active ? a.active[col] : col;
   const Cmd& c = a.cmds[chain];
   if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
@@ -107,31 +126,29 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
     // a command that has not been evaluated left its own)
     if (c.evaluated && c.type != CMD_LEAF) return;
   }
-  constexpr int NS = GeneSums<CM>::N;
-  const Dims& d = a.d;
-  const int S = d.S, C = d.C;
   double* stab = lds;                          // log table: 256 x 1/c then 256 x log c (4 KB)
   double* sE = lds + 2 * kLogTabSize;          // exp(exposure_s), readable kLdsPad entries past S (sweep_cells)
   double* sExpo = sE + S + kLdsPad;
   double* sX = sExpo + S;                      // S x C column-major, readable kLdsPad entries past its end
-  const int tid = threadIdx.x;
   const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
   double* sums = a.sums + (long)chain * NS * d.G;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int p0 = a.bounds[jb * 4 + wave], p1 = a.bounds[jb * 4 + wave + 1];
   // the fill: every workgroup of the launch reads the same few KB at the same time, so as few requests as possible -- 16 bytes
-  // per lane (the table and, for an even S, exp(exposure) are 16-byte aligned on both sides)
-  static_assert(2 * kLogTabSize == 2 * 256, "one 16-byte request per thread fills the table");
-  reinterpret_cast<double2*>(stab)[tid] = reinterpret_cast<const double2*>(a.logtab)[tid];
-  const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
-  if ((S & 1) == 0) { for (int i = tid; i < S / 2; i += 256) reinterpret_cast<double2*>(sE)[i] = reinterpret_cast<const double2*>(a.sampleE)[i]; }
-  else for (int i = tid; i < S; i += 256) sE[i] = a.sampleE[i];
+  // per lane where the alignment allows
+  reinterpret_cast<double2*>(stab)[tid] = f_tab;
+  if (evenS) {
+    if (tid < S / 2) reinterpret_cast<double2*>(sE)[tid] = f_e;
+    for (int i = tid + 256; i < S / 2; i += 256) reinterpret_cast<double2*>(sE)[i] = reinterpret_cast<const double2*>(a.sampleE)[i];
+  } else {
+    if (tid < S) sE[tid] = f_e.x;
+    for (int i = tid + 256; i < S; i += 256) sE[i] = a.sampleE[i];
+  }
   if (any_generic) {
     if (GEN) {
       for (int i = tid; i < S; i += 256) sExpo[i] = a.exposure[i];
       for (int i = tid; i < S * C; i += 256) sX[i] = a.X[i];
-    } else {                                   // the two-group path reads the group column only
-      for (int i = tid; i < S; i += 256) sX[S + i] = a.X[S + i];
+    } else {
+      if (tid < S) sX[S + tid] = f_x;
+      for (int i = tid + 256; i < S; i += 256) sX[S + i] = a.X[S + i];
     }
   }
   __syncthreads();
