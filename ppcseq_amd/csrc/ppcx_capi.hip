@@ -126,13 +126,23 @@ static int workgroups_per_chain(const ppcx_model* m, int L, int nch, int n_res, 
 }
 static void choose_launch(ppcx_model* m, int nchains) {
   const int G = m->d.G, S = m->d.S;
-  int bestL = 64; double best = 1e300;
+  // lanes per gene: passes of the busiest wavefront x pass cost, smallest first -- among the choices that leave no wavefront
+  // slot of the chip without a pass (fill >= 1.2 passes per slot). Without that condition few large passes look cheapest
+  // for small numbers of chains (one pass of 32 genes per wavefront at 5 chains: 157 of 204 workgroups per chain with work,
+  // and L = 2 reads four times the cache lines per request), measured at cfg3, whole fits: 1 chain 30.0 -> 28.5 us per round
+  // (L = 8 -> 16), 2 chains 44.2 -> 35.3 (4 -> 16), 3 chains 45.9 -> 43.2 (4 -> 8), 5 chains 76.8 -> 59.4 (2 -> 4),
+  // 6 chains 81.2 -> 62.9 (2 -> 4); 4, 7 and 8 chains keep L = 8.
+  const double slots = 4.0 * (double)resident_workgroups(m, 0);
+  int bestL = 64, bestL_any = 64; double best = 1e300, best_any = 1e300;
   for (int L = 1; L <= 64; L <<= 1) {
     const int gpw = 64 / L;
     const int wpc = 4 * workgroups_per_chain(m, L, nchains, resident_workgroups(m, 0));
-    const double t = ceil(ceil((double)G / gpw) / wpc) * (5.8 + (double)((S + L - 1) / L));   // passes of the busiest wavefront x pass cost
-    if (t < best) { best = t; bestL = L; }
+    const double npass = ceil((double)G / gpw);
+    const double t = ceil(npass / wpc) * (5.8 + (double)((S + L - 1) / L));   // passes of the busiest wavefront x pass cost
+    if (t < best_any) { best_any = t; bestL_any = L; }
+    if (npass * nchains >= 1.2 * slots && t < best) { best = t; bestL = L; }
   }
+  if (best >= 1e300) bestL = bestL_any;         // a small model: no choice fills the chip
   const int L = m->L_override > 0 ? m->L_override : bestL;
   if (L != m->L) {
     std::lock_guard<std::mutex> lk(m->plan_mutex);
