@@ -51,7 +51,7 @@ def main():
                     help="fits on ONE in-order stream (PPCX_STREAM_GROUPS=1) after the timed ones: the source of the roofline's "
                          "per-launch timings, reported beside the headline (0 = skip: no roofline object)")
     ap.add_argument("--no-ppc", action="store_true", help="skip the posterior-predictive kernel's object")
-    ap.add_argument("--as-named-steps", type=int, default=1,
+    ap.add_argument("--as-named-steps", type=int, default=4,
                     help="fits of the configuration AS BASELINE cfg3 names it (1 chain per GPU), reported beside the headline "
                          "(0 = skip); outside the timed region of the headline")
     args = ap.parse_args()
