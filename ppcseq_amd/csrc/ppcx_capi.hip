@@ -924,9 +924,10 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   // (PPCX_STREAM_GROUPS=n): while one group sits in its memory-bound gene kernel another group's log-likelihood
   // workgroups have the CUs: measured at cfg3 / 8 chains, pipelined rounds (final kernels of round 3, mean of two fits):
   // 3.13 s per fit on one stream, 2.97 s with two groups, 2.93 s with three. Default: three groups from eight chains on, two
-  // from six. A chain's draws do not depend on the grouping (tests/test_gpu_configs.py); the per-kernel event timings of a
+  // from four (whole fits at cfg3 size, one group -> two: 4 chains 2.00 -> 1.82 s, 5 chains 2.40 -> 2.07, 6 chains
+  // 2.86 -> 2.37, 7 chains 3.21 -> 2.64; three chains are faster on one stream; four groups are slower everywhere). A chain's draws do not depend on the grouping (tests/test_gpu_configs.py); the per-kernel event timings of a
   // fit are only meaningful with one group (bench.py takes its roofline sample from a fit with PPCX_STREAM_GROUPS=1).
-  int ngrp = nch >= 8 ? 3 : (nch >= 6 ? 2 : 1);
+  int ngrp = nch >= 8 ? 3 : (nch >= 4 ? 2 : 1);
   if (const char* e = getenv("PPCX_STREAM_GROUPS")) { int v = atoi(e); if (v >= 1) ngrp = v < nch ? v : nch; }
   struct Group { int c0 = 0, n = 0; Work w; RunIO io; PumpStats ps; int rc = PPCX_OK; std::string err; long long leap = 0; };
   std::vector<Group> grp(ngrp);
