@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--stream-groups", type=int, default=0,
-                    help="chain groups on their own streams for the timed fits (0 = the library's default: 3 from seven chains on, 2 from four)")
+                    help="chain groups on their own streams for the timed fits (0 = the library's default: 3 from eight chains on, 2 from four)")
     ap.add_argument("--single-stream-steps", type=int, default=1,
                     help="fits on ONE in-order stream (PPCX_STREAM_GROUPS=1) after the timed ones: the source of the roofline's "
                          "per-launch timings, reported beside the headline (0 = skip: no roofline object)")
@@ -277,7 +277,7 @@ def main():
                        "divergent_after_warmup": div_total,
                        "round_structure": ("pipelined: merged log-likelihood / state-machine launch + gene kernel" if os.environ.get("PPCX_PIPELINE", "1") != "0" and args.mode == "chains"
                                            else "three launches: log-likelihood, close, step + update"),
-                       "stream_groups": args.stream_groups if args.stream_groups > 0 else ("library default (3 from seven chains on, 2 from four)" if args.mode == "chains" else 1),
+                       "stream_groups": args.stream_groups if args.stream_groups > 0 else ("library default (3 from eight chains on, 2 from four)" if args.mode == "chains" else 1),
                        "rounds_last_step_all_groups": int(rounds_last),
                        "us_per_grad_eval_per_chain": round(1e6 * tot_time * world * nch / max(tot_grad, 1), 2)},
             "roofline": roof, "ppc": ppc_obj, "cpu_baseline": cpu, "as_named_cfg3_one_chain_per_gpu": as_named, "single_stream": single,

@@ -125,7 +125,7 @@ static int workgroups_per_chain(const ppcx_model* m, int L, int nch, int n_res, 
   return nbpc;
 }
 // chain groups on their own streams (ppcx_fit_nuts): the default for a fit of `nch` chains
-static int default_stream_groups(int nch) { return nch >= 7 ? 3 : (nch >= 4 ? 2 : 1); }
+static int default_stream_groups(int nch) { return nch >= 8 ? 3 : (nch >= 4 ? 2 : 1); }
 static void choose_launch(ppcx_model* m, int nchains) {
   const int G = m->d.G, S = m->d.S;
   // lanes per gene: passes of the busiest wavefront x pass cost, smallest first -- among the choices that leave no wavefront
@@ -134,32 +134,20 @@ static void choose_launch(ppcx_model* m, int nchains) {
   // and L = 2 reads four times the cache lines per request), measured at cfg3, whole fits: 1 chain 30.0 -> 28.5 us per round
   // (L = 8 -> 16), 2 chains 44.2 -> 35.3 (4 -> 16), 3 chains 45.9 -> 43.2 (4 -> 8), 5 chains 76.8 -> 59.4 (2 -> 4),
   // 6 chains 81.2 -> 62.9 (2 -> 4); 4, 7 and 8 chains keep L = 8.
-  // With three or more chain groups (the default from seven chains on) the launches hold a third of the chains each and
-  // other groups' workgroups take the slots a launch leaves idle: what counts then is the sum over the groups' launches, and
-  // a launch need only fill its share of the chip. cfg3, 8 chains in groups of 3, 3, 2: L = 4 (every wavefront one pass of 16
-  // genes) instead of 8 (two passes of 8 for most): 2.75 -> 2.48 s per fit (means over 16 seeds), 3.01 -> 3.10 s on one stream.
+  // (Choosing L for the chain groups a fit runs in -- launches of a third of the chains, whose idle slots other groups fill:
+  // L = 4 at 7 and 8 chains, one pass of 16 genes per wavefront -- made regular 8-chain fits 9 % faster, 2.75 -> 2.50 s, but of
+  // 61 seeds two ended warm-up with a chain at tree depth 10 (13.5 and 4.8 s; none of 93 seeds with L = 8 did; Fisher p = 0.15):
+  // the means over all fits tried are 2.72 and 2.75 s. Not adopted)
   const double slots = 4.0 * (double)resident_workgroups(m, 0);
-  const int ngrp = default_stream_groups(nchains);
   int bestL = 64, bestL_any = 64; double best = 1e300, best_any = 1e300;
   for (int L = 1; L <= 64; L <<= 1) {
     const int gpw = 64 / L;
     // (L = 1, 2: a lane's four counts of a trip lie 4 L bytes apart, every request touches 64 / L times the lines: +20 %)
     const double npass = ceil((double)G / gpw), c_pass = (5.8 + (double)((S + L - 1) / L)) * (L <= 2 ? 1.2 : 1.0);
-    double t = 0.0; bool fills = true;
-    if (ngrp >= 3) {
-      for (int g = 0; g < ngrp; ++g) {
-        const int n_g = (int)((long)nchains * (g + 1) / ngrp) - (int)((long)nchains * g / ngrp);
-        const int wpc = 4 * workgroups_per_chain(m, L, n_g, resident_workgroups(m, 0));
-        t += ceil(npass / wpc) * c_pass;
-        fills = fills && npass * n_g >= 1.2 / ngrp * slots;
-      }
-    } else {
-      const int wpc = 4 * workgroups_per_chain(m, L, nchains, resident_workgroups(m, 0));
-      t = ceil(npass / wpc) * c_pass;           // passes of the busiest wavefront x pass cost
-      fills = npass * nchains >= 1.2 * slots;
-    }
+    const int wpc = 4 * workgroups_per_chain(m, L, nchains, resident_workgroups(m, 0));
+    const double t = ceil(npass / wpc) * c_pass;           // passes of the busiest wavefront x pass cost
     if (t < best_any) { best_any = t; bestL_any = L; }
-    if (fills && t < best) { best = t; bestL = L; }
+    if (npass * nchains >= 1.2 * slots && t < best) { best = t; bestL = L; }
   }
   if (best >= 1e300) bestL = bestL_any;         // a small model: no choice fills the chip
   const int L = m->L_override > 0 ? m->L_override : bestL;
@@ -942,7 +930,7 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   // Chains can also be split into groups that run on their own streams from their own host threads
   // (PPCX_STREAM_GROUPS=n): while one group sits in its memory-bound gene kernel another group's log-likelihood
   // workgroups have the CUs: measured at cfg3 / 8 chains, pipelined rounds (final kernels of round 3, mean of two fits):
-  // 3.13 s per fit on one stream, 2.97 s with two groups, 2.93 s with three. Default: three groups from seven chains on (7 chains, with the L = 4 that goes with it: 2.54 -> 2.36 s), two
+  // 3.13 s per fit on one stream, 2.97 s with two groups, 2.93 s with three. Default: three groups from eight chains on, two
   // from four (whole fits at cfg3 size, one group -> two: 4 chains 2.00 -> 1.82 s, 5 chains 2.40 -> 2.07, 6 chains
   // 2.86 -> 2.37, 7 chains 3.21 -> 2.64; three chains are faster on one stream; four groups are slower everywhere). A chain's draws do not depend on the grouping (tests/test_gpu_configs.py); the per-kernel event timings of a
   // fit are only meaningful with one group (bench.py takes its roofline sample from a fit with PPCX_STREAM_GROUPS=1).
