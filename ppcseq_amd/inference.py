@@ -75,6 +75,24 @@ class InferenceResult:
         return pd.DataFrame(d)
 
 
+def hmc_warnings(diagnostics, warmup, max_treedepth=10):
+    """What rstan::sampling tells the reference's user after a NUTS fit (check_hmc_diagnostics: divergent transitions after
+    warm-up, transitions that hit the maximum tree depth), as a list of messages. A chain that ends the short warm-up of the
+    reference (150 iterations, R/utilities.R:1503) with a step size far below the others' runs every transition at the
+    maximum tree depth -- the fit then takes several times as long and this is how the caller learns why."""
+    msgs = []
+    div = np.asarray(diagnostics["divergent"])[:, warmup:]
+    depth = np.asarray(diagnostics["treedepth"])[:, warmup:]
+    if div.size and div.sum() > 0:
+        msgs.append(f"There were {int(div.sum())} divergent transitions after warmup.")
+    n_max = int((depth >= max_treedepth).sum()) if depth.size else 0
+    if n_max > 0:
+        chains = np.nonzero((depth >= max_treedepth).any(axis=1))[0].tolist()
+        msgs.append(f"There were {n_max} transitions after warmup that exceeded the maximum treedepth of {max_treedepth} "
+                    f"(chains {chains}): those chains adapted a very small step size and dominate the run time.")
+    return msgs
+
+
 def do_inference(counts, X, exposure_rate, how_many_to_check, *,
                  approximate_posterior_inference=False,
                  approximate_posterior_analysis=False,
@@ -168,6 +186,10 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *,
         res.total_draws = S * K * int(how_many_posterior_draws)   # R/utilities.R:1544
         res.chains, res.iter = chains, n_iter
         res.diagnostics = fit.advi_info() if approximate_posterior_inference else fit.diagnostics()
+        if not approximate_posterior_inference:
+            import warnings
+            for msg in hmc_warnings(res.diagnostics, warmup):
+                warnings.warn(msg, RuntimeWarning, stacklevel=2)
         res.counts_rng = rng
         if pass_fit:
             res.fit = fit

@@ -184,3 +184,16 @@ def test_device_memory_model_of_the_full_analysis():
     D = 2 * 20000 + 1000 + 6
     assert need >= 8 * 20000 * D and need < 8 * 20000 * D * 1.1       # dominated by the draws: 6.6 GB
     assert meth.required_device_memory(20000, 2, 1000, 200, 1000, 8, True) < 2e9       # ADVI: 32 evaluation slots + 1000 draws
+
+
+def test_hmc_warnings_follow_rstan_checks():
+    """The two messages rstan gives after sampling (divergences, maximum tree depth), from a fit's diagnostics: warm-up
+    iterations do not count, and the chains that hit the maximum depth are named."""
+    from ppcseq_amd.inference import hmc_warnings
+    depth = np.full((3, 10), 6); div = np.zeros((3, 10), int)
+    depth[1, :4] = 10; div[2, 2] = 1                         # during warm-up only
+    assert hmc_warnings({"treedepth": depth, "divergent": div}, warmup=4) == []
+    depth[1, 7:] = 10; div[0, 5] = 1; div[2, 9] = 1
+    msgs = hmc_warnings({"treedepth": depth, "divergent": div}, warmup=4)
+    assert len(msgs) == 2 and "2 divergent transitions after warmup" in msgs[0]
+    assert "3 transitions after warmup that exceeded the maximum treedepth of 10" in msgs[1] and "chains [1]" in msgs[1]
