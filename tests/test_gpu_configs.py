@@ -455,6 +455,26 @@ def test_launch_plan_invariants(L, G, S, K):
         m.close()
 
 
+def test_lanes_per_gene_leave_no_wavefront_slot_without_a_pass(L):
+    """The automatic lanes per gene at cfg3 size for 1..8 chains: every choice hands out at least 1.2 passes per wavefront
+    slot of the chip (4 x 4 x 256), none is below 4 lanes (whose requests touch 16+ times the cache lines), and the choices are
+    the ones measured fastest per number of chains (16, 16, 8, 8, 4, 4, 8, 8)."""
+    G, S = CONFIGS["cfg3"][0], CONFIGS["cfg3"][1]
+    d = ind.synth(G, S, seed=CONFIGS["cfg3"][2])
+    m = L.Model(d["counts"], d["X"], d["exposure"], d["K"])
+    try:
+        chosen = []
+        for nch in range(1, 9):
+            lanes, nb, b = m.get_plan(nch)
+            chosen.append(lanes)
+            npass = -(-G // (64 // lanes))
+            assert lanes >= 4 and npass * nch >= 1.2 * 4 * 4 * 256, (nch, lanes)
+            assert nb * nch <= 4 * 256
+        assert chosen == [16, 16, 8, 8, 4, 4, 8, 8], chosen
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("G,S,C,K", [(24, 2500, 2, 6), (16, 4300, 2, 0), (9, 1, 1, 0), (5, 3, 2, 5)])
 def test_extreme_sample_counts(L, oracle, G, S, C, K):
     """Many samples: the per-sample constants need more than the default 64 KB of dynamic LDS (88 KB at S = 2500, 146 KB at
