@@ -447,7 +447,7 @@ static int work_alloc(Work& w, ppcx_model* m, int nchains) {
   HIPCHK(hipMalloc(&w.done, sizeof(int) * nchains));
   HIPCHK(hipMalloc(&w.red, sizeof(double) * (size_t)nchains * PT_COUNT));
   HIPCHK(hipMemsetAsync(w.red, 0, sizeof(double) * (size_t)nchains * PT_COUNT, w.stream));
-  HIPCHK(hipHostMalloc(&w.done_host, sizeof(int) * nchains));
+  HIPCHK(hipHostMalloc(&w.done_host, sizeof(int) * 2 * nchains));     // two polls in flight (pump)
   HIPCHK(hipHostMalloc(&w.active_host, sizeof(int) * nchains));
   HIPCHK(hipMalloc(&w.active, sizeof(int) * nchains));
   for (int i = 0; i < 2; ++i) {
@@ -684,13 +684,21 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
   }
   const int batch = 32, sample_every = 16;
   struct Events {                // destroyed on every exit path
-    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
   } evs;
-  if (time_kernels) for (hipEvent_t& x : evs.e) if (hipEventCreate(&x) != hipSuccess) { x = nullptr; time_kernels = false; }
+  if (time_kernels) for (int i = 0; i < 4; ++i) if (hipEventCreate(&evs.e[i]) != hipSuccess) { evs.e[i] = nullptr; time_kernels = false; }
   hipEvent_t &ev0 = evs.e[0], &ev1 = evs.e[1], &ev2 = evs.e[2], &ev3 = evs.e[3];
-  long long pairs = 0; int n_done = 0;
+  // The poll. Plain: after every batch of rounds the done flags are copied back and the stream is waited for -- the GPU then
+  // idles until the host has woken up and launched again. A pipelined single-process fit polls ONE BATCH BEHIND instead: the
+  // flags of batch b are looked at while batch b + 1 is already queued, so the queue never runs dry (single stream: 2 % of a
+  // fit were such bubbles). The chains notice one batch later that they are all done (32 rounds of kernels that return at
+  // once), and the list of active chains is still rewritten on an idle stream, a few times per fit.
+  bool lookahead = piped && !guarded;
+  if (lookahead) for (int i = 4; i < 6; ++i) if (hipEventCreateWithFlags(&evs.e[i], hipEventDisableTiming) != hipSuccess) { evs.e[i] = nullptr; lookahead = false; }
+  long long pairs = 0; int n_done = 0, n_done_applied = 0;
   Work& w0 = *sh[0].w;
+  int cur = 0; bool have_prev = false, sampled_prev = false;
   while (true) {
     bool sampled = false;
     for (int i = 0; i < batch; ++i, ++pairs) {
@@ -731,9 +739,19 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       if (at > 0 && pairs >= at && local_rc == PPCX_OK && (!rk || !comm || atoi(rk) == comm->rank))
         local_rc = fail(PPCX_ERR_HIP, "injected failure (PPCX_TEST_FAIL_AT_ROUND)");
     }
-    PUMP_HIP(hipMemcpyAsync(w0.done_host, w0.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
-    PUMP_HIP(hipStreamSynchronize(st));
-    if (sampled && n_done == 0 && local_rc == PPCX_OK) {   // only launches in which every chain was still active
+    int* flags = w0.done_host + (lookahead ? cur * nchains : 0);
+    PUMP_HIP(hipMemcpyAsync(flags, w0.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
+    bool sampled_chk = sampled;
+    if (lookahead) {
+      PUMP_HIP(hipEventRecord(evs.e[4 + cur], st));
+      if (!have_prev) { have_prev = true; sampled_prev = sampled; cur ^= 1; continue; }   // the first batch is looked at after the second is queued
+      flags = w0.done_host + (cur ^ 1) * nchains;
+      PUMP_HIP(hipEventSynchronize(evs.e[4 + (cur ^ 1)]));
+      sampled_chk = sampled_prev; sampled_prev = sampled;
+    } else {
+      PUMP_HIP(hipStreamSynchronize(st));
+    }
+    if (sampled_chk && n_done == 0 && local_rc == PPCX_OK) {   // only launches in which every chain was still active
       float ms = 0;
       if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
         stats->kA_ms_sum += ms; stats->kA_samples++; stats->chain_launches += nchains;
@@ -744,9 +762,9 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
     n_done = 0;
     rc = local_rc;
     if (local_rc == PPCX_OK) for (int c = 0; c < nchains; ++c) {
-      if (w0.done_host[c]) ++n_done;
-      if (w0.done_host[c] == 2) rc = fail(PPCX_ERR_INIT, "no finite initial point after 100 attempts");
-      if (w0.done_host[c] == 3) rc = fail(PPCX_ERR_STEPSIZE, "step-size heuristic diverged");
+      if (flags[c]) ++n_done;
+      if (flags[c] == 2) rc = fail(PPCX_ERR_INIT, "no finite initial point after 100 attempts");
+      if (flags[c] == 3) rc = fail(PPCX_ERR_STEPSIZE, "step-size heuristic diverged");
     }
     if (pairs > max_pairs && n_done < nchains && rc == PPCX_OK) rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished");
     if (guarded) {
@@ -756,10 +774,18 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       if (all_rc != PPCX_OK) { rc = all_rc; break; }
     } else if (rc != PPCX_OK) break;
     if (n_done == nchains) break;
-    // fewer chains in the launch: the others get their wavefronts (the stream is idle here, the list can be rewritten)
-    if (n_done > 0) {
+    // fewer chains in the launch: the others get their wavefronts (the list is rewritten on an idle stream: with the poll one
+    // batch behind the queued batch is waited for first, and its newer flags are the ones applied)
+    if (n_done > n_done_applied) {
+      if (lookahead) {
+        PUMP_HIP(hipStreamSynchronize(st));
+        flags = w0.done_host + cur * nchains;
+        have_prev = false;                       // both batches are finished and looked at: start over
+      }
       int na = 0;
-      for (int c = 0; c < nchains; ++c) if (!w0.done_host[c]) w0.active_host[na++] = c;
+      for (int c = 0; c < nchains; ++c) if (!flags[c]) w0.active_host[na++] = c;
+      n_done_applied = nchains - na;
+      if (na == 0) { n_done = nchains; break; }
       for (int k = 0; k < ns; ++k) {
         Work& wk = *sh[k].w;
         PUMP_HIP(hipMemcpyAsync(wk.active, w0.active_host, sizeof(int) * na, hipMemcpyHostToDevice, st));
@@ -767,7 +793,9 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       }
       PUMP_HIP(hipStreamSynchronize(st));
     }
+    if (lookahead) cur ^= 1;
   }
+  if (lookahead) (void)hipStreamSynchronize(st);   // a queued batch may still be running: nothing is freed under it
 #undef PUMP_TRY
 #undef PUMP_HIP
   stats->pairs = pairs;
