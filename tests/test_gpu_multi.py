@@ -220,3 +220,42 @@ def test_a_failing_rank_takes_its_peer_out_of_the_collectives(monkeypatch, faili
     assert [r[1] for r in res] == ["error", "error"], res
     assert all("ppcx error -2" in r[2] for r in res), res                     # PPCX_ERR_HIP, the class of the injected failure
     assert "injected failure" in res[failing_rank][2] and "another rank" in res[1 - failing_rank][2]
+
+
+def _rccl_single_rank_worker(port, q):
+    """The collectives of the chains-over-ranks path on device tensors over RCCL (backend "nccl"), a group of one rank: what
+    bench.py and distributed.do_inference issue on a GPU node, as far as one GPU can run it."""
+    import torch
+    import torch.distributed as dist
+    from ppcseq_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        counts, X, expo, K = _data()
+        got = D.broadcast_arrays(dict(counts=counts, X=X, exposure=expo, K=np.array([K], np.int64)), device="cuda:0")
+        ok = all(np.array_equal(got[k], v) and got[k].dtype == v.dtype
+                 for k, v in dict(counts=counts, X=X, exposure=expo, K=np.array([K], np.int64)).items())
+        x = np.arange(24, dtype=np.float64).reshape(2, 3, 4)
+        ok = ok and np.array_equal(D.all_gather_chains(x, device="cuda:0"), x) and D.max_over_ranks(2.5, device="cuda:0") == 2.5
+        r = D.do_inference(counts, X, expo, K, device=0, coll_device="cuda:0", chains=3, launch=LAUNCH, **KW)
+        q.put(("ok" if ok else "mismatch", r.lower, r.upper, r.deleterious_outliers))
+    except Exception as e:
+        q.put(("crash: " + repr(e), None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collectives_over_rccl_with_one_rank():
+    from ppcseq_amd.inference import do_inference
+    counts, X, expo, K = _data()
+    one = do_inference(counts, X, expo, K, chains=3, launch=LAUNCH, **KW)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    status, lower, upper, flags = q.get(timeout=600)
+    p.join(120)
+    assert status == "ok" and p.exitcode == 0, status
+    assert np.array_equal(lower, one.lower) and np.array_equal(upper, one.upper) and np.array_equal(flags, one.deleterious_outliers)
