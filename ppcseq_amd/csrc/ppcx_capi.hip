@@ -136,7 +136,7 @@ static void choose_launch(ppcx_model* m, int nchains) {
   // 6 chains 81.2 -> 62.9 (2 -> 4); 4, 7 and 8 chains keep L = 8.
   // (Choosing L for the chain groups a fit runs in -- launches of a third of the chains, whose idle slots other groups fill:
   // L = 4 at 7 and 8 chains, one pass of 16 genes per wavefront -- made regular 8-chain fits 9 % faster, 2.75 -> 2.50 s, but of
-  // 61 seeds two ended warm-up with a chain at tree depth 10 (13.5 and 4.8 s; none of 93 seeds with L = 8 did; Fisher p = 0.15):
+  // 61 seeds two ended warm-up with a chain at tree depth 10 (13.5 and 4.8 s; none of 233 fits with L = 8 did; Fisher p = 0.04):
   // the means over all fits tried are 2.72 and 2.75 s. Not adopted)
   const double slots = 4.0 * (double)resident_workgroups(m, 0);
   int bestL = 64, bestL_any = 64; double best = 1e300, best_any = 1e300;
