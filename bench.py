@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--stream-groups", type=int, default=0,
                     help="chain groups on their own streams for the timed fits (0 = the library's default: 3 from eight chains on, 2 from four)")
     ap.add_argument("--single-stream-steps", type=int, default=1,
-                    help="fits on ONE in-order stream (PPCX_STREAM_GROUPS=1) after the timed ones: the source of the roofline's "
+                    help="fits on ONE in-order stream (stream_groups = 1) after the timed ones: the source of the roofline's "
                          "per-launch timings, reported beside the headline (0 = skip: no roofline object)")
     ap.add_argument("--no-ppc", action="store_true", help="skip the posterior-predictive kernel's object")
     ap.add_argument("--as-named-steps", type=int, default=4,
@@ -115,7 +115,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.stream_groups > 0:
-        os.environ["PPCX_STREAM_GROUPS"] = str(args.stream_groups)
+        model.set_rounds(stream_groups=args.stream_groups)
 
     def one_fit(step_seed):
         if comm is not None:                   # every rank runs the same chains on its genes
@@ -201,8 +201,7 @@ def main():
     # roofline object needs (with chain groups on several streams another group's kernels run inside the bracket).
     single = None
     if args.mode == "chains" and args.single_stream_steps > 0:
-        prev = os.environ.get("PPCX_STREAM_GROUPS")
-        os.environ["PPCX_STREAM_GROUPS"] = "1"
+        model.set_rounds(stream_groups=1)
         try:
             t_g, ess_g = 0.0, 0.0
             for k in range(args.single_stream_steps):
@@ -228,10 +227,7 @@ def main():
                       "ms_per_step": round(1e3 * t_g / args.single_stream_steps, 2), "steps": args.single_stream_steps,
                       "kernel_ms": {k: round(v, 5) for k, v in single_kt.items()}}
         finally:
-            if prev is None:
-                del os.environ["PPCX_STREAM_GROUPS"]
-            else:
-                os.environ["PPCX_STREAM_GROUPS"] = prev
+            model.set_rounds(stream_groups=args.stream_groups)
 
     if rank == 0:
         E = 0
@@ -248,7 +244,7 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(chains_per_launch), "fp64_issue": issue_profile(),
                     "algorithmic_bytes_per_launch": b_grad * chains_per_launch, "avg_launch_ms": round(ms, 5),
                     "timed_launches": int(kA_n),
-                    "sampled_in": "a fit on one in-order stream (PPCX_STREAM_GROUPS=1) after the timed fits" if args.mode == "chains" else "the timed fits",
+                    "sampled_in": "a fit on one in-order stream (stream_groups = 1) after the timed fits" if args.mode == "chains" else "the timed fits",
                     "note": "achieved = algorithmic bytes (SURVEY 8d: count matrix + coordinates, per chain gradient) x chains per "
                             "launch / launch time: an effective-throughput figure. ppcx_ls_kernel is the merged launch of a "
                             "pipelined round: the log-likelihood workgroups of every chain beside the chains' state machines. "

@@ -64,6 +64,11 @@ PPCX_API int ppcx_model_create(int device, int G, int S, int C, int K, const int
 PPCX_API int ppcx_model_set_exclusions(ppcx_model* m, int n_excl, const int32_t* excl);   /* pass 2 of R/methods.R:320-342 */
 PPCX_API int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int workgroups); /* 0 = automatic; lanes: power of two <= 64 */
 PPCX_API int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int* nblocks);
+/* round structure of the NUTS fits of this model. pipelined: -1 = two launches per leapfrog wherever the model allows it
+   (default), 0 = always the three-launch round; stream_groups: 0 = by the number of chains (default), n = the chains run in
+   n groups on their own streams. A chain's draws do not depend on stream_groups. The initial values come from the
+   environment variables PPCX_PIPELINE / PPCX_STREAM_GROUPS, read once when the model is created. */
+PPCX_API int ppcx_model_set_rounds(ppcx_model* m, int pipelined, int stream_groups);
 /* diagnostic: the log-likelihood launch planned for `nchains` chains -- lanes per gene, workgroups per chain and the
    gene-order positions bounds[0 .. 4 * workgroups_per_chain] delimiting the wavefronts' ranges (NULL to skip) */
 PPCX_API int ppcx_model_get_plan(ppcx_model* m, int nchains, int* lanes_per_gene, int* workgroups_per_chain, int* bounds, int cap);
@@ -174,11 +179,6 @@ PPCX_API int ppcx_fit_nuts_comm(ppcx_model* shard, const ppcx_nuts_config* cfg, 
  * [rounds, -rounds, chains done, -chains done, -(error status)] and their own status: PPCX_OK, the peer's / own error
  * class, or PPCX_ERR_STALL when the ranks disagree. Pure host logic, exported so that it can be tested without two GPUs. */
 PPCX_API int ppcx_guard_decision(const double* reduced5, int local_status);
-
-/* Development aid, not part of the reference boundary: mean duration (ms) of `reps` back-to-back launches of
- * the gene kernel on the command the chains hold after `warm_pairs` launch pairs (n_merge < 0: as is).       */
-PPCX_API int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs, int reps, int n_merge,
-                           double* ms_per_launch, int* cmd_type);
 
 #ifdef __cplusplus
 }

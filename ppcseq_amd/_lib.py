@@ -18,7 +18,7 @@ EXPORTS = [
     "ppcx_version", "ppcx_device_count", "ppcx_last_error", "ppcx_model_create", "ppcx_model_set_exclusions",
     "ppcx_model_set_launch", "ppcx_model_get_launch", "ppcx_model_get_plan", "ppcx_model_dim", "ppcx_model_destroy", "ppcx_log_prob_grad",
     "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_from_draws", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
-    "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_bench_gene_kernel",
+    "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_model_set_rounds",
     "ppcx_model_create_shard", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
     "ppcx_fit_nuts_comm", "ppcx_advi_config_default", "ppcx_fit_advi", "ppcx_fit_advi_info", "ppcx_fit_advi_iterative",
     "ppcx_guard_decision", "ppcx_device_memory", "ppcx_fit_get_ppc_timing",
@@ -44,6 +44,15 @@ class AdviConfig(C.Structure):
 
 
 _lib = None
+
+
+def use_library(path=None):
+    """Bind another build of the library from now on (None: back to the product build). For the tests that need the
+    testing build (tests/libppcx_testing.so: fault injection, forced cell paths, kernel-level timing); every Model / Fit /
+    Comm of the previous library must have been closed."""
+    global _lib, LIB_PATH
+    _lib = None
+    LIB_PATH = path if path else os.environ.get("PPCX_LIB", os.path.join(_HERE, "libppcx.so"))
 
 
 def load() -> C.CDLL:
@@ -85,7 +94,11 @@ def load() -> C.CDLL:
     lib.ppcx_fit_get_kernel_times.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_longlong)]
     lib.ppcx_fit_ppc.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_ulonglong, C.c_int, C.c_int, dp, ip]
     lib.ppcx_fit_free.argtypes = [C.c_void_p]
-    lib.ppcx_bench_gene_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.POINTER(C.c_int)]
+    lib.ppcx_model_set_rounds.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    if hasattr(lib, "ppcx_testing_set"):         # the testing build (csrc/ppcx_testing.h)
+        lib.ppcx_testing_set.argtypes = [C.c_char_p, C.c_longlong]
+        lib.ppcx_testing_set_nccl_provider.argtypes = [C.c_char_p]
+        lib.ppcx_testing_bench_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, C.POINTER(C.c_int)]
     lib.ppcx_fit_free.restype = None
     lib.ppcx_advi_config_default.argtypes = [C.POINTER(AdviConfig)]
     lib.ppcx_advi_config_default.restype = None
@@ -110,6 +123,21 @@ def _check(rc: int):
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def testing_set(key: str, value: int):
+    """A test hook of the testing build (csrc/ppcx_testing.h); the product build has none."""
+    lib = load()
+    if not hasattr(lib, "ppcx_testing_set"):
+        raise PpcxError(f"{LIB_PATH} is not the testing build")
+    _check(lib.ppcx_testing_set(key.encode(), int(value)))
+
+
+def testing_set_nccl_provider(path: str):
+    lib = load()
+    if not hasattr(lib, "ppcx_testing_set_nccl_provider"):
+        raise PpcxError(f"{LIB_PATH} is not the testing build")
+    _check(lib.ppcx_testing_set_nccl_provider(path.encode() if path else None))
 
 
 def device_count() -> int:
@@ -227,9 +255,18 @@ class Model:
         _check(load().ppcx_fit_nuts_comm(self._h, C.byref(cfg), comm._h, C.byref(h)))
         return Fit(self, h)
 
-    def bench_gene_kernel(self, nchains=1, warm_pairs=40, reps=50, n_merge=1):
+    def set_rounds(self, pipelined=-1, stream_groups=0):
+        """Round structure of this model's NUTS fits: pipelined -1 = wherever the model allows it (default), 0 = the
+        three-launch round; stream_groups 0 = by the number of chains, n = n chain groups on their own streams."""
+        _check(load().ppcx_model_set_rounds(self._h, int(pipelined), int(stream_groups)))
+
+    def bench_kernel(self, which=0, nchains=1, warm_rounds=40, reps=50, n_merge=1):
+        """(ms per launch, command type) of one kernel of the three-launch round -- testing build only."""
+        lib = load()
+        if not hasattr(lib, "ppcx_testing_bench_kernel"):
+            raise PpcxError(f"{LIB_PATH} is not the testing build")
         ms, t = C.c_double(), C.c_int()
-        _check(load().ppcx_bench_gene_kernel(self._h, nchains, warm_pairs, reps, n_merge, C.byref(ms), C.byref(t)))
+        _check(lib.ppcx_testing_bench_kernel(self._h, int(which), nchains, warm_rounds, reps, n_merge, C.byref(ms), C.byref(t)))
         return ms.value, t.value
 
     def close(self):

@@ -8,28 +8,54 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppcx.so")
+# the testing build (-DPPCX_TESTING: fault injection, forced cell paths, kernel-level timing; csrc/ppcx_testing.h) lives
+# with the tests, not in the package
+TESTING_LIB = os.path.join(os.path.dirname(HERE), "tests", "libppcx_testing.so")
 SOURCES = ["ppcx_kernels.hip", "ppcx_capi.hip"]
-HEADERS = ["ppcx_math.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h", "ppcx_kernels.h", os.path.join("..", "..", "include", "ppcx.h")]
+HEADERS = ["ppcx_math.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h", "ppcx_kernels.h", "ppcx_testing.h",
+           os.path.join("..", "..", "include", "ppcx.h")]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib: str) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return LIB
+def _compile(lib: str, extra, verbose: bool) -> None:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Wno-unused-result", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    objs = []
+    procs = []
+    for s in SOURCES:                            # the two translation units side by side
+        o = lib + "." + s + ".o"
+        objs.append(o)
+        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"] + extra + \
+              ["-c", "-o", o, os.path.join(CSRC, s)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append(subprocess.Popen(cmd))
+    for p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, p.args)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    for o in objs:
+        os.remove(o)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if force or _stale(LIB):
+        _compile(LIB, [], verbose)
     return LIB
+
+
+def build_testing(force: bool = False, verbose: bool = False) -> str:
+    if force or _stale(TESTING_LIB):
+        _compile(TESTING_LIB, ["-DPPCX_TESTING"], verbose)
+    return TESTING_LIB
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--testing" in sys.argv:
+        print(build_testing(force="--force" in sys.argv, verbose=True))

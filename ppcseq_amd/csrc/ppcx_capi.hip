@@ -28,6 +28,19 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
       return fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
   } while (0)
 
+// Test hooks exist only in the testing build (-DPPCX_TESTING: tests/libppcx_testing.so, built by __graft_entry__.build()
+// for tests/ and scripts/); the shipped library has none of them and reads no environment variable after model creation.
+#ifdef PPCX_TESTING
+#include "ppcx_testing.h"
+struct TestHooks {
+  long long fail_at_round = 0; int fail_rank = -1;   // fault injection into the pump of a gene-sharded run
+  int force_generic = 0;                             // every gene with slopes takes the per-cell-eta path
+  int no_tail_tiers = 0, plan_ignore_tiers = 0;      // timing experiments on the Stirling-tail tiers
+  std::string rccl_lib;                              // another provider of the nccl* entry points (tests/loopback)
+};
+static TestHooks g_test;
+#endif
+
 struct ppcx_model {
   int device;
   Dims d;
@@ -36,6 +49,9 @@ struct ppcx_model {
   int n_cu = 256, wgs_per_cu = 4;              // resident workgroups of the log-likelihood kernel = n_cu * wgs_per_cu
   int ls_wgs_per_cu = 0;                       // the same for the merged launch of a pipelined round (0: cannot run)
   int nblocks_chosen = 0;                      // workgroups of the last planned launch (what ppcx_model_get_launch reports)
+  // round structure of a NUTS fit (ppcx_model_set_rounds; initial values from PPCX_PIPELINE / PPCX_STREAM_GROUPS, read
+  // once when the model is created): pipelined -1 = where it applies, 0 = never; stream_groups 0 = by the number of chains
+  int opt_pipelined = -1, opt_stream_groups = 0;
   // gene order of the log-likelihood launch (upload_counts): per position, the length of the gene's low-count list
   // and whether it has slopes -- what a pass of a wavefront costs (plan_launch)
   std::vector<int> pos_low; std::vector<char> pos_slope, pos_tier;
@@ -102,7 +118,11 @@ static double pass_cost(const ppcx_model* m, int L, int p, int n) {
   int lowmax = 0, tier = 2; bool slope = false;
   for (int i = p; i < p + n; ++i) { if (m->pos_low[i] > lowmax) lowmax = m->pos_low[i]; slope = slope || m->pos_slope[i]; if (m->pos_tier[i] < tier) tier = m->pos_tier[i]; }
   // a pass of plain genes that all allow shorter Stirling tails saves 4 (tier 1) or 6 (tier 2) of the ~44 instructions of a cell-iteration
-  static const bool ignore_tiers = getenv("PPCX_PLAN_IGNORE_TIERS") != nullptr;     // development aid
+#ifdef PPCX_TESTING
+  const bool ignore_tiers = g_test.plan_ignore_tiers != 0;
+#else
+  const bool ignore_tiers = false;
+#endif
   const double tail = (slope || ignore_tiers) ? 1.0 : (tier >= 2 ? 0.86 : (tier >= 1 ? 0.91 : 1.0));
   const double sweep = (double)((S + L - 1) / L) * tail * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? 1.15 : 1.0));
   return 5.8 + sweep + 0.75 * (double)((lowmax + L - 1) / L);
@@ -234,7 +254,9 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
     }
     Sy[g] = sy; SyE[g] = sye; ncell[g] = nc; Lg1[g] = lg1;
     tier[g] = gene_tier(ymin, nhi[g], S);
-    if (getenv("PPCX_NO_TAIL_TIERS")) tier[g] = 0;           // development aid: every pass with the full tails
+#ifdef PPCX_TESTING
+    if (g_test.no_tail_tiers) tier[g] = 0;                   // every pass with the full tails
+#endif
     nhi[g] |= tier[g] << 28;                                 // CellData::n_hi
   }
   low_start[G] = (int)low.size();
@@ -314,8 +336,13 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   m->d.x0_is_one = x0;
   int x1b = (C == 2);                          // two-group design: the second column is an indicator
   for (int s = 0; s < S && x1b; ++s) if (X[(size_t)S + s] != 0.0 && X[(size_t)S + s] != 1.0) x1b = 0;
-  if (const char* e = getenv("PPCX_TWO_GROUP")) if (atoi(e) == 0) x1b = 0;     // development aid: force the generic cell path
+#ifdef PPCX_TESTING
+  if (g_test.force_generic) x1b = 0;
+#endif
   m->d.x1_binary = x1b;
+  // the two tuning knobs of a fit's round structure, read from the environment HERE and nowhere else
+  if (const char* e = getenv("PPCX_PIPELINE")) if (atoi(e) == 0) m->opt_pipelined = 0;
+  if (const char* e = getenv("PPCX_STREAM_GROUPS")) { const int v = atoi(e); if (v >= 1) m->opt_stream_groups = v; }
   m->wgs_per_cu = loglik_resident_workgroups_per_cu(m->CM, m->d);      // of the instantiation this model runs
   if (m->wgs_per_cu < 1) { delete m; return fail(PPCX_ERR_LIMIT, "the log-likelihood kernel cannot be resident with S * (2 + C) doubles of per-sample constants in LDS"); }
   m->ls_wgs_per_cu = ls_resident_workgroups_per_cu(m->CM, m->d);
@@ -364,6 +391,12 @@ extern "C" int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int work
   m->L_override = lanes_per_gene; m->wgs_override = workgroups;
   drop_plans(m);
   choose_launch(m, 1);
+  return PPCX_OK;
+}
+extern "C" int ppcx_model_set_rounds(ppcx_model* m, int pipelined, int stream_groups) {
+  if (!m) return fail(PPCX_ERR_ARG, "model is NULL");
+  if (pipelined < -1 || pipelined > 1 || stream_groups < 0 || stream_groups > 64) return fail(PPCX_ERR_ARG, "pipelined must be -1, 0 or 1 and stream_groups 0 .. 64");
+  m->opt_pipelined = pipelined; m->opt_stream_groups = stream_groups;
   return PPCX_OK;
 }
 extern "C" int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int* nblocks) {
@@ -601,12 +634,15 @@ struct RcclApi {
 static RcclApi g_rccl;
 static int rccl_load() {
   if (g_rccl.h) return PPCX_OK;
-  // PPCX_RCCL_LIB: another provider of the five nccl* entry points below (tests/loopback: ranks of one host over shared
-  // memory, so that the multi-rank path runs on a one-GPU box, where RCCL refuses two ranks on a device)
-  if (const char* e = getenv("PPCX_RCCL_LIB")) {
-    g_rccl.h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
-    if (!g_rccl.h) return fail(PPCX_ERR_HIP, std::string("cannot load PPCX_RCCL_LIB=") + e + ": " + dlerror());
-  } else {
+#ifdef PPCX_TESTING
+  // another provider of the five nccl* entry points below (tests/loopback: ranks of one host over shared memory, so that
+  // the RCCL path runs with two ranks on a one-GPU box, where RCCL itself refuses two ranks on a device)
+  if (!g_test.rccl_lib.empty()) {
+    g_rccl.h = dlopen(g_test.rccl_lib.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!g_rccl.h) return fail(PPCX_ERR_HIP, std::string("cannot load the nccl provider ") + g_test.rccl_lib + ": " + dlerror());
+  }
+#endif
+  if (!g_rccl.h) {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.h) break; }
   }
@@ -733,12 +769,11 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       }
       if (smp) PUMP_HIP(hipEventRecord(ev3, st));
     }
-    if (const char* e = getenv("PPCX_TEST_FAIL_AT_ROUND")) {       // fault injection for the guard's tests (tests/test_gpu_multi.py)
-      const long long at = atoll(e);
-      const char* rk = getenv("PPCX_TEST_FAIL_RANK");
-      if (at > 0 && pairs >= at && local_rc == PPCX_OK && (!rk || !comm || atoi(rk) == comm->rank))
-        local_rc = fail(PPCX_ERR_HIP, "injected failure (PPCX_TEST_FAIL_AT_ROUND)");
-    }
+#ifdef PPCX_TESTING
+    if (g_test.fail_at_round > 0 && pairs >= g_test.fail_at_round && local_rc == PPCX_OK &&
+        (g_test.fail_rank < 0 || !comm || g_test.fail_rank == comm->rank))      // fault injection for the guard's tests
+      local_rc = fail(PPCX_ERR_HIP, "injected failure (ppcx_testing_set fail_at_round)");
+#endif
     int* flags = w0.done_host + (lookahead ? cur * nchains : 0);
     PUMP_HIP(hipMemcpyAsync(flags, w0.done, sizeof(int) * nchains, hipMemcpyDeviceToHost, st));
     bool sampled_chk = sampled;
@@ -851,15 +886,30 @@ extern "C" int ppcx_log_prob_grad(ppcx_model* m, int n_points, const double* u, 
   return PPCX_OK;
 }
 
-// Development aid (not part of the reference boundary): time `reps` back-to-back launches of the gene kernel
-// on the command the chains hold after `warm_pairs` launch pairs of a real run. n_merge >= 0 overrides the
-// tree position of that command (number of subtree merges the leaf closes), so every variant is timed on the
-// same work.
-extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs, int reps, int n_merge,
-                                      double* ms_per_launch, int* cmd_type) {
-  const int which = n_merge >= 100 ? (n_merge / 100) : 0;      // 0 loglik, 1 close, 2 both, 3 step, 4 update, 5 step:reduce, 6 step:advance, 7 step + update in one launch (development aid)
-  if (n_merge >= 100) n_merge %= 100;
-  if (!m || nchains < 1 || reps < 1 || !ms_per_launch) return fail(PPCX_ERR_ARG, "bad arguments");
+#ifdef PPCX_TESTING
+// ---- testing build only (ppcx_testing.h) ---------------------------------------------------------------------------
+extern "C" int ppcx_testing_set(const char* key, long long value) {
+  if (!key) return fail(PPCX_ERR_ARG, "key is NULL");
+  const std::string k(key);
+  if (k == "fail_at_round") g_test.fail_at_round = value;
+  else if (k == "fail_rank") g_test.fail_rank = (int)value;
+  else if (k == "force_generic") g_test.force_generic = (int)value;
+  else if (k == "no_tail_tiers") g_test.no_tail_tiers = (int)value;
+  else if (k == "plan_ignore_tiers") g_test.plan_ignore_tiers = (int)value;
+  else return fail(PPCX_ERR_ARG, "unknown test hook " + k);
+  return PPCX_OK;
+}
+extern "C" int ppcx_testing_set_nccl_provider(const char* path) {
+  if (g_rccl.h) return fail(PPCX_ERR_ARG, "the nccl entry points are bound already");
+  g_test.rccl_lib = path ? path : "";
+  return PPCX_OK;
+}
+// Kernel-level timing: mean duration (ms) of `reps` back-to-back launches of one kernel (`which`, ppcx_testing.h) of the
+// three-launch round on the command the chains hold after `warm_rounds` rounds of a real run. n_merge >= 0 overrides the
+// tree position of that command (number of subtree merges the leaf closes), so every variant is timed on the same work.
+extern "C" int ppcx_testing_bench_kernel(ppcx_model* m, int which, int nchains, int warm_rounds, int reps, int n_merge,
+                                         double* ms_per_launch, int* cmd_type) {
+  if (!m || nchains < 1 || reps < 1 || !ms_per_launch || which < 0 || which > PPCX_BENCH_STEP_UPDATE) return fail(PPCX_ERR_ARG, "bad arguments");
   HIPCHK(hipSetDevice(m->device));
   choose_launch(m, nchains);
   Work w;
@@ -875,7 +925,7 @@ extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs
   hipStream_t st = m->stream;
   if ((rc = launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE)) != PPCX_OK) return rc;
   if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
-  for (int i = 0; i < warm_pairs; ++i) {
+  for (int i = 0; i < warm_rounds; ++i) {
     if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
     if ((rc = launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE)) != PPCX_OK) return rc;
     if ((rc = launch_update(m, w, nchains, io)) != PPCX_OK) return rc;
@@ -890,18 +940,30 @@ extern "C" int ppcx_bench_gene_kernel(ppcx_model* m, int nchains, int warm_pairs
     cmds[c].eps *= 1e-3;                         // keep the repeated second half kicks on a bounded trajectory
   }
   HIPCHK(hipMemcpy(dcmds, cmds.data(), sizeof(Cmd) * nchains, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  auto one = [&]() -> int {
+    switch (which) {
+      case PPCX_BENCH_CLOSE: return launch_close(m, w, nchains);
+      case PPCX_BENCH_LOGLIK_CLOSE: return launch_gene(m, w, nchains);
+      case PPCX_BENCH_STEP: return launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE);
+      case PPCX_BENCH_UPDATE: return launch_update(m, w, nchains, io);
+      case PPCX_BENCH_STEP_REDUCE: return launch_step(m, w, nchains, io, STEP_REDUCE);
+      case PPCX_BENCH_STEP_ADVANCE: return launch_step(m, w, nchains, io, STEP_ADVANCE);
+      case PPCX_BENCH_STEP_UPDATE: return launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE, true);
+      default: return launch_loglik(m, w, nchains);
+    }
+  };
+  struct Ev { hipEvent_t e0 = nullptr, e1 = nullptr; ~Ev() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); } } ev;   // destroyed on every return
+  HIPCHK(hipEventCreate(&ev.e0)); HIPCHK(hipEventCreate(&ev.e1));
   for (int i = 0; i < 3; ++i) if ((rc = launch_gene(m, w, nchains)) != PPCX_OK) return rc;
-  HIPCHK(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) if ((rc = (which == 1 ? launch_close(m, w, nchains) : (which == 2 ? launch_gene(m, w, nchains) : (which == 3 ? launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE) : (which == 4 ? launch_update(m, w, nchains, io) : (which == 5 ? launch_step(m, w, nchains, io, STEP_REDUCE) : (which == 6 ? launch_step(m, w, nchains, io, STEP_ADVANCE) : (which == 7 ? launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE, true) : launch_loglik(m, w, nchains))))))))) != PPCX_OK) return rc;
-  HIPCHK(hipEventRecord(e1, st));
+  HIPCHK(hipEventRecord(ev.e0, st));
+  for (int i = 0; i < reps; ++i) if ((rc = one()) != PPCX_OK) return rc;
+  HIPCHK(hipEventRecord(ev.e1, st));
   HIPCHK(hipStreamSynchronize(st));
-  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   *ms_per_launch = (double)ms / reps;
   return PPCX_OK;
 }
+#endif
 
 static void fit_attach(ppcx_fit* f, ppcx_model* m) { f->m = m; m->live_fits++; }
 extern "C" void ppcx_fit_free(ppcx_fit* f) {
@@ -952,18 +1014,18 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   // constants only (no per-cell linear predictor). The choice must not depend on the number of chains: the two round
   // structures sum the kinetic energy of fresh momenta in different orders, and a chain's draws may not depend on its
   // company. (With more chains than the chip holds workgroups the state machines simply run ahead of the log-likelihood
-  // workgroups instead of beside them.) PPCX_PIPELINE=0 selects the three-launch round.
+  // workgroups instead of beside them.) ppcx_model_set_rounds(m, 0, ...) selects the three-launch round.
   bool piped = m->ls_wgs_per_cu >= 1 && m->d.x0_is_one && (m->d.C < 2 || m->d.K == 0 || m->d.x1_binary);
-  if (const char* e = getenv("PPCX_PIPELINE")) if (atoi(e) == 0) piped = false;
+  if (m->opt_pipelined == 0) piped = false;
   // Chains can also be split into groups that run on their own streams from their own host threads
-  // (PPCX_STREAM_GROUPS=n): while one group sits in its memory-bound gene kernel another group's log-likelihood
+  // (ppcx_model_set_rounds): while one group sits in its memory-bound gene kernel another group's log-likelihood
   // workgroups have the CUs: measured at cfg3 / 8 chains, pipelined rounds (final kernels of round 3, mean of two fits):
   // 3.13 s per fit on one stream, 2.97 s with two groups, 2.93 s with three. Default: three groups from eight chains on, two
   // from four (whole fits at cfg3 size, one group -> two: 4 chains 2.00 -> 1.82 s, 5 chains 2.40 -> 2.07, 6 chains
   // 2.86 -> 2.37, 7 chains 3.21 -> 2.64; three chains are faster on one stream; four groups are slower everywhere). A chain's draws do not depend on the grouping (tests/test_gpu_configs.py); the per-kernel event timings of a
-  // fit are only meaningful with one group (bench.py takes its roofline sample from a fit with PPCX_STREAM_GROUPS=1).
+  // fit are only meaningful with one group (bench.py takes its roofline sample from a fit on one stream).
   int ngrp = default_stream_groups(nch);
-  if (const char* e = getenv("PPCX_STREAM_GROUPS")) { int v = atoi(e); if (v >= 1) ngrp = v < nch ? v : nch; }
+  if (m->opt_stream_groups >= 1) ngrp = m->opt_stream_groups < nch ? m->opt_stream_groups : nch;
   struct Group { int c0 = 0, n = 0; Work w; RunIO io; PumpStats ps; int rc = PPCX_OK; std::string err; long long leap = 0; };
   std::vector<Group> grp(ngrp);
   const long long max_pairs = ((long long)iter * ((1LL << cfg->max_treedepth) + 8) + 100000) * (piped ? 2 : 1);

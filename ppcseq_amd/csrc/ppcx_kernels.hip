@@ -24,6 +24,13 @@
 
 namespace ppcx {
 
+// ChainState / Cmd travel between global memory, registers and LDS word by word (one 4-byte word per thread). The word type
+// may alias any object: reading a struct with double members through a plain `int` lvalue is undefined under the strict
+// aliasing rule that -O3 applies, whatever the copy looks like in practice.
+typedef int __attribute__((may_alias)) word_t;
+// 16-byte requests of arrays of doubles (LDS fills)
+typedef double2 __attribute__((may_alias)) dpair_t;
+
 // -----------------------------------------------------------------------------------------------------
 // kernel A1: the log-likelihood kernel. Streams the count matrix once and leaves, per gene, the sums of
 // GeneSumsV (ppcx_model.h): the likelihood part of the gene's log density, its d/dphi part, sum rho
@@ -111,9 +118,9 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
   const bool any_generic = !d.x0_is_one || (C >= 2 && d.K > 0);
   const bool evenS = (S & 1) == 0;             // then exp(exposure) is 16-byte aligned on both sides
   const int p0 = a.bounds[jb * 4 + wave], p1 = a.bounds[jb * 4 + wave + 1];
-  const double2 f_tab = reinterpret_cast<const double2*>(a.logtab)[tid];
+  const double2 f_tab = reinterpret_cast<const dpair_t*>(a.logtab)[tid];
   double2 f_e = {0.0, 0.0};
-  if (evenS) { if (tid < S / 2) f_e = reinterpret_cast<const double2*>(a.sampleE)[tid]; }
+  if (evenS) { if (tid < S / 2) f_e = reinterpret_cast<const dpair_t*>(a.sampleE)[tid]; }
   else if (tid < S) f_e.x = a.sampleE[tid];
   double f_x = 0.0;
   if (!GEN && any_generic && tid < S) f_x = a.X[S + tid];      // the two-group path reads the group column only
@@ -134,10 +141,10 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
   double* sums = a.sums + (long)chain * NS * d.G;
   // the fill: every workgroup of the launch reads the same few KB at the same time, so as few requests as possible -- 16 bytes
   // per lane where the alignment allows
-  reinterpret_cast<double2*>(stab)[tid] = f_tab;
+  reinterpret_cast<dpair_t*>(stab)[tid] = f_tab;
   if (evenS) {
-    if (tid < S / 2) reinterpret_cast<double2*>(sE)[tid] = f_e;
-    for (int i = tid + 256; i < S / 2; i += 256) reinterpret_cast<double2*>(sE)[i] = reinterpret_cast<const double2*>(a.sampleE)[i];
+    if (tid < S / 2) reinterpret_cast<dpair_t*>(sE)[tid] = f_e;
+    for (int i = tid + 256; i < S / 2; i += 256) reinterpret_cast<dpair_t*>(sE)[i] = reinterpret_cast<const dpair_t*>(a.sampleE)[i];
   } else {
     if (tid < S) sE[tid] = f_e.x;
     for (int i = tid + 256; i < S; i += 256) sE[i] = a.sampleE[i];
@@ -338,10 +345,10 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   // overlaps the reduction below
   int r_st[4], r_cmd = 0; double r_hv[3];
   {
-    const int* s2 = reinterpret_cast<const int*>(st_in);
+    const word_t* s2 = reinterpret_cast<const word_t*>(st_in);
 #pragma unroll
     for (int k = 0; k < 4; ++k) r_st[k] = tid + 256 * k < NST ? s2[tid + 256 * k] : 0;
-    if (tid < NCMD) r_cmd = reinterpret_cast<const int*>(a.cmds_in + chain)[tid];
+    if (tid < NCMD) r_cmd = reinterpret_cast<const word_t*>(a.cmds_in + chain)[tid];
     const double* hvg = a.hyper_in + (long)chain * NHV;
 #pragma unroll
     for (int k = 0; k < 3; ++k) r_hv[k] = tid + 256 * k < NHV ? hvg[tid + 256 * k] : 0.0;
@@ -404,10 +411,10 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
     return;
   }
   {
-    int* d2 = reinterpret_cast<int*>(&s_st);
+    word_t* d2 = reinterpret_cast<word_t*>(&s_st);
 #pragma unroll
     for (int k = 0; k < 4; ++k) if (tid + 256 * k < NST) d2[tid + 256 * k] = r_st[k];
-    if (tid < NCMD) reinterpret_cast<int*>(&s_ex)[tid] = r_cmd;
+    if (tid < NCMD) reinterpret_cast<word_t*>(&s_ex)[tid] = r_cmd;
 #pragma unroll
     for (int k = 0; k < 3; ++k) if (tid + 256 * k < NHV) hv[tid + 256 * k] = r_hv[k];
     s_tab[tid] = r_tab[0]; s_tab[tid + 256] = r_tab[1];
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   if (lead) {
     double* hvo = a.hyper_out + (long)chain * V_COUNT * 8;
     for (int i = tid; i < V_COUNT * 8; i += 256) hvo[i] = hv[i];
-    const int* s2 = reinterpret_cast<const int*>(&s_st); int* d2 = reinterpret_cast<int*>(a.states_out + chain);
+    const word_t* s2 = reinterpret_cast<const word_t*>(&s_st); word_t* d2 = reinterpret_cast<word_t*>(a.states_out + chain);
     for (int i = tid; i < (int)(sizeof(ChainState) / sizeof(int)); i += 256) d2[i] = s2[i];
   }
   if (!a.upd_vecs) return;
@@ -494,10 +501,10 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
   const bool done = st_in->sc.phase == PH_DONE;
   int r_st[4], r_cmd = 0; double r_hv[3];
   {
-    const int* s2 = reinterpret_cast<const int*>(st_in);
+    const word_t* s2 = reinterpret_cast<const word_t*>(st_in);
 #pragma unroll
     for (int k = 0; k < 4; ++k) r_st[k] = tid + 256 * k < NST ? s2[tid + 256 * k] : 0;
-    if (tid < NCMD) r_cmd = reinterpret_cast<const int*>(a.cmds_in + chain)[tid];
+    if (tid < NCMD) r_cmd = reinterpret_cast<const word_t*>(a.cmds_in + chain)[tid];
     const double* hvg = a.hyper_in + (long)chain * NHV;
 #pragma unroll
     for (int k = 0; k < 3; ++k) r_hv[k] = tid + 256 * k < NHV ? hvg[tid + 256 * k] : 0.0;
@@ -536,10 +543,10 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
     return;
   }
   {
-    int* d2 = reinterpret_cast<int*>(&s.st);
+    word_t* d2 = reinterpret_cast<word_t*>(&s.st);
 #pragma unroll
     for (int k = 0; k < 4; ++k) if (tid + 256 * k < NST) d2[tid + 256 * k] = r_st[k];
-    if (tid < NCMD) reinterpret_cast<int*>(&s.ex)[tid] = r_cmd;
+    if (tid < NCMD) reinterpret_cast<word_t*>(&s.ex)[tid] = r_cmd;
 #pragma unroll
     for (int k = 0; k < 3; ++k) if (tid + 256 * k < NHV) s.hv[tid + 256 * k] = r_hv[k];
   }
@@ -565,9 +572,9 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
   __syncthreads();
   double* hvo = a.hyper_out + (long)chain * NHV;
   for (int i = tid; i < NHV; i += 256) hvo[i] = s.hv[i];
-  const int* s2 = reinterpret_cast<const int*>(&s.st); int* d2 = reinterpret_cast<int*>(a.states_out + chain);
+  const word_t* s2 = reinterpret_cast<const word_t*>(&s.st); word_t* d2 = reinterpret_cast<word_t*>(a.states_out + chain);
   for (int i = tid; i < NST; i += 256) d2[i] = s2[i];
-  const int* c2 = reinterpret_cast<const int*>(&s.nc); int* e2 = reinterpret_cast<int*>(a.cmds_out + chain);
+  const word_t* c2 = reinterpret_cast<const word_t*>(&s.nc); word_t* e2 = reinterpret_cast<word_t*>(a.cmds_out + chain);
   if (tid < NCMD) e2[tid] = c2[tid];
 }
 
@@ -734,7 +741,7 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
   if (!do_update && !do_close) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   static_assert(2 * kLogTabSize == 512, "two table entries per thread");
-  reinterpret_cast<double2*>(s_tab)[tid] = reinterpret_cast<const double2*>(ga.logtab)[tid];     // one 16-byte request per thread
+  reinterpret_cast<dpair_t*>(s_tab)[tid] = reinterpret_cast<const dpair_t*>(ga.logtab)[tid];     // one 16-byte request per thread
   __syncthreads();
   gene_wave_part<CM>(ga, c, chain, blockIdx.x * 256 + tid, wacc, s_tab, wave, lane, do_update, do_close);
   __syncthreads();

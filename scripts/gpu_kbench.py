@@ -5,6 +5,8 @@ import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ppcseq_amd import _lib as L
+from ppcseq_amd import build as _b
+L.use_library(os.environ.get("PPCX_LIB") or _b.build_testing())          # kernel-level timing lives in the testing build
 from ppcseq_amd.synth import synth
 G, S = int(os.environ.get("G", 20000)), int(os.environ.get("S", 200))
 d = synth(G, S, seed=20253); K = d["K"]
@@ -21,7 +23,7 @@ for r in range(int(os.environ.get("ROUNDS", 5))):
     for cfg in cfgs:
         chains, lanes, wgs = cfg
         m.set_launch(lanes, wgs)
-        ms, t = m.bench_gene_kernel(chains, 10 if r else 40, reps, 1)
+        ms, t = m.bench_kernel(0, chains, 10 if r else 40, reps, 1)
         res[cfg].append((ms, m.get_launch(), t))
 for cfg in cfgs:
     chains, lanes, wgs = cfg

@@ -9,8 +9,7 @@ from ppcseq_amd.synth import synth
 
 def fit(m, pipe, groups=1, **kw):
     """pipe: 0 = three-launch round, 1 = pipelined (two launches)"""
-    os.environ["PPCX_PIPELINE"] = "0" if pipe == 0 else "1"
-    os.environ["PPCX_STREAM_GROUPS"] = str(groups)
+    m.set_rounds(pipelined=0 if pipe == 0 else -1, stream_groups=groups)
     t0 = time.perf_counter()
     f = m.fit_nuts(**kw)
     dt = time.perf_counter() - t0

@@ -30,6 +30,24 @@ def test_library_exports_every_declared_symbol():
     assert lib.ppcx_version() == 300          # include/ppcx.h PPCX_VERSION
 
 
+def test_test_hooks_are_not_in_the_shipped_library():
+    """Fault injection, forced cell paths, the stand-in nccl provider and the kernel-level timing exist only in the testing
+    build (tests/libppcx_testing.so, -DPPCX_TESTING); the product library exports none of it and carries none of the old
+    environment switches."""
+    from ppcseq_amd import build
+    lib = ctypes.CDLL(build.build())
+    for name in ("ppcx_testing_set", "ppcx_testing_set_nccl_provider", "ppcx_testing_bench_kernel", "ppcx_bench_gene_kernel"):
+        assert not hasattr(lib, name), name
+    blob = open(build.build(), "rb").read()
+    for s in (b"PPCX_TEST_FAIL", b"PPCX_RCCL_LIB", b"PPCX_TWO_GROUP", b"PPCX_NO_TAIL_TIERS", b"PPCX_PLAN_IGNORE_TIERS", b"injected failure"):
+        assert s not in blob, s
+    tlib = ctypes.CDLL(build.build_testing())
+    for name in ("ppcx_testing_set", "ppcx_testing_set_nccl_provider", "ppcx_testing_bench_kernel"):
+        assert hasattr(tlib, name), name
+    for name in _declared():                     # the testing build is the product plus the hooks
+        assert hasattr(tlib, name), name
+
+
 def test_binding_lists_the_same_symbols():
     from ppcseq_amd import _lib
     assert sorted(_lib.EXPORTS) == _declared()
@@ -75,3 +93,23 @@ def test_guard_decision_of_the_gene_shard_ranks():
     assert decide([vec(64, 0), vec(64, 0, err=-2)], 0) == -2               # a peer failed: its class
     assert decide([vec(64, 0, err=-3), vec(64, 0)], -3) == -3              # this rank failed: its own status
     assert decide([vec(64, 0, err=-2), vec(32, 0, err=-6)], -6) == -6      # both failed: each keeps its own
+
+
+def test_r_shim_is_a_source_file_written_for_this_abi_version():
+    """r/ppcx_do_inference.R (the .C() shim that replaces R/utilities.R:1482-1531) and r/zzz.R are source files of the
+    repository; the version the shim passes as dims[1] is the header's PPCX_VERSION, and its .C() call names every argument
+    of ppcx_do_inference_C in the header's order. (R is not installed here: the call itself is exercised by the plain-C host
+    tests/c_host/dot_c_host.c on the GPU box.)"""
+    hdr = open(os.path.join(ROOT, "include", "ppcx.h")).read()
+    version = int(re.search(r"#define PPCX_VERSION (\d+)", hdr).group(1))
+    shim = open(os.path.join(ROOT, "r", "ppcx_do_inference.R")).read()
+    assert re.search(r"as\.integer\(c\(%dL," % version, shim), "the shim's dims[1] must be PPCX_VERSION"
+    call = shim[shim.index('.C("ppcx_do_inference_C"'):]
+    names = re.findall(r"^\s+(\w+)\s*=", call[:call.index("if (out$status")], re.M)
+    assert names == ["dims", "counts", "X", "expo", "excl", "reals", "ci", "slope", "counts_rng", "status", "errbuf", "errlen"]
+    proto = hdr[hdr.index("PPCX_API void ppcx_do_inference_C"):]
+    proto = proto[:proto.index(";")]
+    assert proto.count(",") + 1 == len(names)
+    assert "dyn.load" in open(os.path.join(ROOT, "r", "zzz.R")).read()
+    host = open(os.path.join(ROOT, "tests", "c_host", "dot_c_host.c")).read()
+    assert "int dims[16] = {%d," % version in host

@@ -385,12 +385,9 @@ def test_cfg3_warmup_follows_the_oracle_at_full_tree_depth(L):
     d = ind.synth(G, S, seed=data_seed)
     m = L.Model(d["counts"], d["X"], d["exposure"], d["K"])
     try:
-        for pipe in ("1", "0"):
-            os.environ["PPCX_PIPELINE"] = pipe
-            try:
-                f = m.fit_nuts(chains=chains, iter=n_iter, warmup=n_iter, seed=seed)
-            finally:
-                del os.environ["PPCX_PIPELINE"]
+        for pipe in (-1, 0):
+            m.set_rounds(pipelined=pipe)
+            f = m.fit_nuts(chains=chains, iter=n_iter, warmup=n_iter, seed=seed)
             dg = f.diagnostics()
             f.close()
             assert np.array_equal(dg["n_leapfrog"], z["n_leapfrog"]), (pipe, dg["n_leapfrog"].tolist(), z["n_leapfrog"].tolist())
@@ -408,7 +405,7 @@ def test_a_chain_does_not_depend_on_the_chains_it_shares_launches_with(L, monkey
     The same chain must therefore come out bit-identical from a 3-chain fit, from a fit with far more chains than the
     chip holds resident workgroups per chain for (130 chains: the launch plan has fewer than 8 workgroups per chain, and
     chains finish at different times, so the plan is redone many times), and from a fit whose chains are split into groups
-    on separate streams (PPCX_STREAM_GROUPS)."""
+    on separate streams (ppcx_model_set_rounds)."""
     d = ind.synth(300, 12, K=20, seed=17)
     m = L.Model(d["counts"], d["X"], d["exposure"], 20)
     try:
@@ -422,12 +419,12 @@ def test_a_chain_does_not_depend_on_the_chains_it_shares_launches_with(L, monkey
         assert np.array_equal(g130[:3], g3) and np.array_equal(d130[:3], d3)
         assert len({tuple(r) for r in g130.tolist()}) > 100          # the chains are genuinely different trajectories
         f130.close()
-        monkeypatch.setenv("PPCX_STREAM_GROUPS", "3")
+        m.set_rounds(stream_groups=3)
         f7 = m.fit_nuts(chains=7, **kw)
         assert np.array_equal(f7.diagnostics()["n_leapfrog"][:3], g3) and np.array_equal(f7.draws()[:3], d3)
         f7.close()
         # a chain placed by its global id: chain 2 of the 3-chain fit alone in a fit with chain_id_offset = 2
-        monkeypatch.delenv("PPCX_STREAM_GROUPS")
+        m.set_rounds(stream_groups=0)
         f1 = m.fit_nuts(chains=1, chain_id_offset=2, **kw)
         assert np.array_equal(f1.draws()[0], d3[2])
         f1.close()

@@ -3,7 +3,7 @@
     of one process: the pooled credible intervals are those of a single fit of the same global chains, bit for bit;
   * gene shards over ranks with the per-leapfrog all-reduce and the rank-divergence guard: over RCCL where two devices are
     visible (one rank per GPU; skipped otherwise), and on ANY box through tests/loopback -- a stand-in for the five nccl*
-    entry points over shared memory (PPCX_RCCL_LIB), because RCCL refuses two ranks on one device. The loopback runs
+    entry points over shared memory (bound by the testing build of the library), because RCCL refuses two ranks on one device. The loopback runs
     reproduce the in-process shards bit for bit, and a failure injected into one rank makes both ranks return together.
 """
 import os
@@ -141,10 +141,20 @@ def _loopback_lib():
     return lib
 
 
-def _loopback_worker(rank, world, conn, q, G, K, kw):
-    """One rank = one process; both ranks on device 0. The communicator's id travels from rank 0 over a pipe."""
+def _testing_lib():
+    from ppcseq_amd import build
+    return build.build_testing()
+
+
+def _loopback_worker(rank, world, conn, q, G, K, kw, hooks):
+    """One rank = one process; both ranks on device 0. The communicator's id travels from rank 0 over a pipe. The ranks
+    bind the TESTING build of the library: the stand-in nccl provider and the fault injection exist only there."""
     from ppcseq_amd import _lib as L
     try:
+        L.use_library(_testing_lib())
+        L.testing_set_nccl_provider(_loopback_lib())
+        for k, v in (hooks or {}).items():
+            L.testing_set(k, v)
         d = ind.synth(G, 10, K=K, seed=4)
         if rank == 0:
             uid = L.Comm.unique_id()
@@ -165,14 +175,12 @@ def _loopback_worker(rank, world, conn, q, G, K, kw):
         q.put((rank, "crash", repr(e), None))
 
 
-def _run_two_ranks(G, K, kw, monkeypatch, extra_env=None):
-    monkeypatch.setenv("PPCX_RCCL_LIB", _loopback_lib())
-    for k, v in (extra_env or {}).items():
-        monkeypatch.setenv(k, v)
+def _run_two_ranks(G, K, kw, hooks=None):
+    _loopback_lib(); _testing_lib()              # built once, here, not by both ranks at the same time
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     a, b = ctx.Pipe()
-    procs = [ctx.Process(target=_loopback_worker, args=(r, 2, (a, b)[r], q, G, K, kw)) for r in range(2)]
+    procs = [ctx.Process(target=_loopback_worker, args=(r, 2, (a, b)[r], q, G, K, kw, hooks)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
@@ -182,7 +190,7 @@ def _run_two_ranks(G, K, kw, monkeypatch, extra_env=None):
     return res
 
 
-def test_gene_shards_over_two_ranks_through_the_loopback_collective(monkeypatch):
+def test_gene_shards_over_two_ranks_through_the_loopback_collective():
     """ppcx_fit_nuts_comm with nranks = 2 (the reference's map_rect over gene shards, inst/stan/negBinomial_MPI.stan:226-240,
     one shard per process): the per-round all-reduce between reduce and advance, every rank replicating the state
     machines, the guard's poll. The two ranks' draws are the columns of the in-process two-shard fit, bit for bit (same
@@ -204,7 +212,7 @@ def test_gene_shards_over_two_ranks_through_the_loopback_collective(monkeypatch)
     finally:
         for m in shards + [whole]:
             m.close()
-    res = _run_two_ranks(G, K, kw, monkeypatch)
+    res = _run_two_ranks(G, K, kw)
     for rank, status, nl, dr in res:
         assert status == "ok", (rank, status, nl)
         assert np.array_equal(nl, ref[rank][0]) and np.array_equal(dr, ref[rank][1])        # = the in-process shards
@@ -212,11 +220,11 @@ def test_gene_shards_over_two_ranks_through_the_loopback_collective(monkeypatch)
 
 
 @pytest.mark.parametrize("failing_rank", [0, 1])
-def test_a_failing_rank_takes_its_peer_out_of_the_collectives(monkeypatch, failing_rank):
-    """Fault injection: one rank fails after round 64 (PPCX_TEST_FAIL_AT_ROUND). It keeps issuing the per-round all-reduces
+def test_a_failing_rank_takes_its_peer_out_of_the_collectives(failing_rank):
+    """Fault injection: one rank fails after round 64 (testing build, ppcx_testing_set). It keeps issuing the per-round all-reduces
     until the poll, where the guard's max-reduction tells both ranks: both return the same error class, neither hangs."""
     kw = dict(chains=2, iter=200, warmup=100, seed=6)
-    res = _run_two_ranks(80, 6, kw, monkeypatch, {"PPCX_TEST_FAIL_AT_ROUND": "64", "PPCX_TEST_FAIL_RANK": str(failing_rank)})
+    res = _run_two_ranks(80, 6, kw, {"fail_at_round": 64, "fail_rank": failing_rank})
     assert [r[1] for r in res] == ["error", "error"], res
     assert all("ppcx error -2" in r[2] for r in res), res                     # PPCX_ERR_HIP, the class of the injected failure
     assert "injected failure" in res[failing_rank][2] and "another rank" in res[1 - failing_rank][2]

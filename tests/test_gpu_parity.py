@@ -54,7 +54,7 @@ def test_log_prob_grad_matches_oracle(L, oracle, G, S, C, K, seed):
         m.close()
 
 
-def test_continuous_covariate_and_two_group_designs(L, oracle, monkeypatch):
+def test_continuous_covariate_and_two_group_designs(L, oracle):
     """C = 2: a 0/1 second column lets the checked genes use the factorised cell path (two constants per gene); a
     continuous one keeps the per-cell exp. Both against the oracle, and the two-group shortcut against the generic path."""
     d = ind.synth(70, 19, K=9, seed=6, C=2)
@@ -66,20 +66,28 @@ def test_continuous_covariate_and_two_group_designs(L, oracle, monkeypatch):
         mo = oracle.model(d["counts"], X, d["exposure"], 9)
         ref = [oracle.log_prob_grad(mo, u[i]) for i in range(2)]
         res = {}
-        for flag in ("1", "0"):
-            monkeypatch.setenv("PPCX_TWO_GROUP", flag)
-            m = L.Model(d["counts"], X, d["exposure"], 9)
-            try:
-                for lanes in (0, 4, 64):
-                    m.set_launch(lanes, 0)
-                    lp, g = m.log_prob_grad(u)
-                    for i in range(2):
-                        assert abs(lp[i] - ref[i][0]) <= 1e-11 * abs(ref[i][0])
-                        assert np.max(np.abs(g[i] - ref[i][1]) / (1 + np.abs(ref[i][1]))) < 1e-10
-                res[flag] = lp
-            finally:
-                m.close()
-        assert np.max(np.abs(res["0"] - res["1"]) / np.abs(res["0"])) < 1e-13
+        try:
+            for flag in (0, 1):                  # 1: the testing build with every gene with slopes on the per-cell-eta path
+                if flag:
+                    from ppcseq_amd import build
+                    L.use_library(build.build_testing())
+                    L.testing_set("force_generic", 1)
+                m = L.Model(d["counts"], X, d["exposure"], 9)
+                try:
+                    for lanes in (0, 4, 64):
+                        m.set_launch(lanes, 0)
+                        lp, g = m.log_prob_grad(u)
+                        for i in range(2):
+                            assert abs(lp[i] - ref[i][0]) <= 1e-11 * abs(ref[i][0])
+                            assert np.max(np.abs(g[i] - ref[i][1]) / (1 + np.abs(ref[i][1]))) < 1e-10
+                    res[flag] = lp
+                finally:
+                    m.close()
+        finally:
+            if L.LIB_PATH.endswith("libppcx_testing.so"):
+                L.testing_set("force_generic", 0)
+            L.use_library(None)
+        assert np.max(np.abs(res[0] - res[1]) / np.abs(res[0])) < 1e-13
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
@@ -228,8 +236,8 @@ def test_round_structures_agree_with_the_oracle(L, oracle, monkeypatch):
             try:
                 for seed in (9, 10):
                     r = oracle.nuts_model(mo, oracle.cfg(chains=2, iter=12, warmup=8, seed=seed))
-                    for pipe in ("1", "0"):
-                        monkeypatch.setenv("PPCX_PIPELINE", pipe)
+                    for pipe in (-1, 0):
+                        m.set_rounds(pipelined=pipe)
                         f = m.fit_nuts(chains=2, iter=12, warmup=8, seed=seed)
                         dg = f.diagnostics()
                         f.close()
@@ -497,9 +505,9 @@ def test_rccl_communicator_single_rank(L, monkeypatch):
     try:
         comm = L.Comm(1, 0, L.Comm.unique_id())
         fp = m.fit_nuts(chains=2, iter=25, warmup=15, seed=9)
-        monkeypatch.setenv("PPCX_PIPELINE", "0")
+        m.set_rounds(pipelined=0)
         f = m.fit_nuts(chains=2, iter=25, warmup=15, seed=9)
-        monkeypatch.delenv("PPCX_PIPELINE")
+        m.set_rounds(pipelined=-1)
         fc = ms.fit_nuts_comm(comm, chains=2, iter=25, warmup=15, seed=9)
         assert np.array_equal(f.diagnostics()["n_leapfrog"], fc.diagnostics()["n_leapfrog"])
         assert np.array_equal(f.draws(), fc.draws())

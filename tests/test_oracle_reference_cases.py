@@ -78,6 +78,53 @@ def test_reference_testthat_cases_on_the_oracle(oracle, bundled, approx_analysis
     assert r1.deleterious_outliers[1, s]                                  # found by the discovery pass already
 
 
+def _readme_selection(bundled):
+    """README.md:55-66: mutate(is_significant = FDR < 0.01) -- 15 genes -- and the default 500 negative controls."""
+    genes = [str(g) for g in bundled["genes"]]
+    chk = [i for i in range(len(genes)) if bundled["FDR"][i] < 0.01]
+    assert len(chk) == 15
+    others = [i for i in range(len(genes)) if i not in set(chk)]
+    order = sorted(others, key=lambda i: bundled["PValue"][i])
+    controls = set(order[-500:])
+    sel = chk + [i for i in others if i in controls]
+    counts = bundled["value"][sel].astype(np.int32)
+    label = bundled["Label"]
+    X = np.stack([np.ones(len(label)), (label == sorted(set(label))[1]).astype(float)], axis=1)
+    return counts, X, [genes[i] for i in sel]
+
+
+def check_readme_calls(names, counts, samples, r2):
+    """The README's table (README.md:75-92): CYP1A1 and LYZ carry exactly one failed sample each, a deleterious outlier --
+    CYP1A1's in 11165PP (man/figures/unnamed-chunk-9-2.png). Returns the other genes called, which must be borderline:
+    at percent_false_positive_genes = 5 the test pass cuts each tail at 5 / 100 / 21 * 2 = 0.48 %, i.e. the reference's own
+    thresholds allow 0.05 x 15 = 0.75 false-positive genes per run, and its VB fit is unseeded (R/utilities.R:261), so the
+    README shows one draw of that; BASELINE.md section 5 holds the rate measured here over seeds."""
+    tot = r2.deleterious_outliers.sum(1)
+    failed = (~r2.ppc).sum(1)
+    for g, smp in (("CYP1A1", "11165PP"), ("LYZ", "11164PP")):
+        i = names.index(g)
+        assert tot[i] == 1 and failed[i] == 1, (g, tot[i], failed[i])
+        assert str(samples[int(np.flatnonzero(r2.deleterious_outliers[i])[0])]) == smp
+    extras = [names[g] for g in range(15) if tot[g] > 0 and names[g] not in ("CYP1A1", "LYZ")]
+    for g in extras:
+        i = names.index(g)
+        assert tot[i] == 1
+        s = int(np.flatnonzero(r2.deleterious_outliers[i])[0])
+        y, lo, up = float(counts[i, s]), float(r2.lower[i, s]), float(r2.upper[i, s])
+        assert (y > up and y < 2 * up) or (y < lo and 2 * y + 1 >= lo), (g, y, lo, up)      # just outside the interval
+    return extras
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_readme_case_on_the_oracle_in_the_readme_mode(oracle, bundled, seed):
+    """README.md:50-92 as written: the defaults -- ADVI inference and the approximated posterior analysis (R/methods.R:85-86)
+    -- with percent_false_positive_genes = 5 and 500 negative controls, through the oracle."""
+    counts, X, names = _readme_selection(bundled)
+    r1, r2 = _oracle_identify_outliers(oracle, counts, X, 15, pfp=5, vb=True, approx_analysis=True, cores=4, seed=seed)
+    extras = check_readme_calls(names, counts, bundled["samples"], r2)
+    assert len(extras) <= 2, extras                                         # 6 extra calls in 5 seeds on the oracle (BASELINE.md section 5)
+
+
 def test_readme_case_on_the_oracle_through_nuts(oracle, bundled):
     """README.md:50-92 (the reference runs it with its default, VB; here the oracle's NUTS): of the 15 genes with FDR < 0.01
     exactly CYP1A1 and LYZ fail the check, one deleterious outlier each."""
