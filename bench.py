@@ -43,8 +43,16 @@ def main():
     ap.add_argument("--mode", choices=["chains", "shards"], default="chains",
                     help="chains: BASELINE cfg3, chains partitioned over GPUs (default, weak scaling); shards: BASELINE cfg4 style, "
                          "genes partitioned over GPUs with an RCCL all-reduce of the partial sums every leapfrog (strong scaling)")
+    ap.add_argument("--exchange", choices=["direct", "rccl"], default="direct",
+                    help="shards mode: how the ranks' partial sums meet every leapfrog -- direct: peer-mapped buffers written by the "
+                         "state machines inside the merged launch of a pipelined round (no collective call); rccl: an RCCL "
+                         "all-reduce between the launches of the three-launch round")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-full-cfg2", action="store_true",
+                    help="also time ONE WHOLE fit of BASELINE cfg2 (5 000 x 50, 4 chains, 150 + 250) on the host's cores -- the "
+                         "optimised CPU comparator under the oracle's NUTS driver, same seed -- beside the same fit on the GPU "
+                         "(about a minute of CPU time; off by default)")
     ap.add_argument("--stream-groups", type=int, default=0,
                     help="chain groups on their own streams for the timed fits (0 = the library's default: 3 from eight chains on, 2 from four)")
     ap.add_argument("--single-stream-steps", type=int, default=1,
@@ -87,14 +95,23 @@ def main():
     if dist_on:
         arrays = D.broadcast_arrays(arrays, device=dev)
     K = int(arrays["K"][0])
-    comm = None
+    comm, xchg = None, None
     if args.mode == "shards":
-        # contiguous gene ranges; the communicator's id travels from rank 0 through torch.distributed
-        uid = [_lib.Comm.unique_id() if rank == 0 else None]
-        if dist_on:
-            import torch.distributed as dist
-            dist.broadcast_object_list(uid, src=0)
-        comm = _lib.Comm(world, rank, uid[0], device=dev_index)
+        # contiguous gene ranges
+        if args.exchange == "rccl":             # the communicator's id travels from rank 0 through torch.distributed
+            uid = [_lib.Comm.unique_id() if rank == 0 else None]
+            if dist_on:
+                import torch.distributed as dist
+                dist.broadcast_object_list(uid, src=0)
+            comm = _lib.Comm(world, rank, uid[0], device=dev_index)
+        else:                                   # direct exchange: every rank maps every rank's receive buffer (IPC handles)
+            xchg = _lib.Xchg(world, rank, args.chains_per_gpu, device=dev_index)
+            if dist_on:
+                import torch.distributed as dist
+                handles = [None] * world
+                dist.all_gather_object(handles, xchg.handle())
+                xchg.connect(handles)
+                dist.barrier()                  # nobody publishes before everybody has mapped everybody
         g0, g1 = G * rank // world, G * (rank + 1) // world
         model = _lib.Model(arrays["counts"][g0:g1], arrays["X"], arrays["exposure"], 0, device=dev_index,
                            shard=(G, K, g0, g1))
@@ -116,10 +133,14 @@ def main():
 
     if args.stream_groups > 0:
         model.set_rounds(stream_groups=args.stream_groups)
+    elif args.mode == "shards":
+        model.set_rounds(stream_groups=1)       # one in-order stream: the timed fits' launch timings are the roofline's sample
 
     def one_fit(step_seed):
         if comm is not None:                   # every rank runs the same chains on its genes
             return model.fit_nuts_comm(comm, chains=nch, iter=n_iter, warmup=args.nuts_warmup, seed=step_seed)
+        if xchg is not None:
+            return model.fit_nuts_xchg(xchg, chains=nch, iter=n_iter, warmup=args.nuts_warmup, seed=step_seed)
         return model.fit_nuts(chains=nch, iter=n_iter, warmup=args.nuts_warmup, seed=step_seed,
                               chain_id_offset=D.chain_id_offset(rank, nch))
 
@@ -131,6 +152,7 @@ def main():
     kA_ms, kA_n, kA_chains = 0.0, 0, 0.0
     ppc_obj, rounds_last, single_kt = None, 0, None
     ess_detail, depth_mean, div_total = None, [], 0
+    xchg_wait = (0.0, 0)
     for k in range(args.steps):
         barrier()
         t0 = time.perf_counter()
@@ -146,7 +168,7 @@ def main():
         kt = fit.kernel_times()
         lp = dg["lp"]
         ge = np.array([float(tm.grad_evals)])
-        if dist_on and comm is None:
+        if dist_on and args.mode == "chains":
             hyp = D.all_gather_chains(hyp, device=dev)
             lp = D.all_gather_chains(lp, device=dev)
             ge = D.all_gather_chains(ge, device=dev)
@@ -167,6 +189,9 @@ def main():
         depth_mean.append(float(dg["treedepth"].mean()))
         div_total += int(dg["divergent"][:, args.nuts_warmup:].sum())
         rounds_last = kt["launch_triples"]
+        if xchg is not None:
+            xw_us, xn = fit.xchg_timing()
+            xchg_wait = (xchg_wait[0] + xw_us * xn, xchg_wait[1] + xn)
         # the posterior-predictive kernel on this fit's draws (outside the timed region; rank 0, last step)
         if rank == 0 and k == args.steps - 1 and not args.no_ppc and args.mode == "chains":
             ppc_obj = ppc_object(fit, K, S, C)
@@ -275,10 +300,17 @@ def main():
                                            else "three launches: log-likelihood, close, step + update"),
                        "stream_groups": args.stream_groups if args.stream_groups > 0 else ("library default (3 from eight chains on, 2 from four)" if args.mode == "chains" else 1),
                        "rounds_last_step_all_groups": int(rounds_last),
-                       "us_per_grad_eval_per_chain": round(1e6 * tot_time * world * nch / max(tot_grad, 1), 2)},
+                       "us_per_grad_eval_per_chain": round(1e6 * tot_time * world * nch / max(tot_grad, 1), 2),
+                       **({"exchange": args.exchange,
+                           "exchange_us_per_round": (round(xchg_wait[0] / xchg_wait[1], 3) if xchg_wait[1] else (0.0 if world == 1 else None)),
+                           "exchange_note": "direct: mean time a chain's state machine waited for its peers' sums per round, measured in the kernel "
+                                            "(100 MHz wall clock), rank 0; it runs beside the log-likelihood workgroups of the same launch, so it is "
+                                            "not added to the round. One rank: no exchange takes place"} if args.mode == "shards" else {})},
             "roofline": roof, "ppc": ppc_obj, "cpu_baseline": cpu, "as_named_cfg3_one_chain_per_gpu": as_named, "single_stream": single,
             "concordance": None if (args.no_cpu_baseline or world > 1) else outlier_concordance(),
         }
+        if args.cpu_full_cfg2 and world == 1:
+            out["cpu_full_cfg2"] = cpu_full_cfg2(dev_index)
         print(json.dumps(out))
     model.close()
     if dist_on:
@@ -409,6 +441,56 @@ def outlier_concordance():
             "max_upper_ci_rel_diff": float(np.max(np.abs(g.upper - o.upper) / (1 + o.upper))),
             "median_upper_ci_rel_diff": float(np.median(np.abs(g.upper - o.upper) / (1 + o.upper))),
             "max_upper_ci_diff_in_mc_standard_errors": float(np.max(np.abs(g.upper - o.upper) / se_upper))}
+
+
+def cpu_full_cfg2(dev_index, seed=1):
+    """One WHOLE fit of BASELINE cfg2 (synthetic 5 000 genes x 50 samples, 4 chains, warm-up 150 + 250 kept draws) timed end to
+    end on the host's cores beside the same fit on the GPU -- same data, same sampler seed and chain ids (hence the same Philox
+    streams), same ESS estimator -- so that one CPU / GPU pair of this repository is measured, not extrapolated. The CPU side is
+    the oracle's NUTS driver (Stan-default sampler, oracle/ppc_oracle.c run_chain) on the optimised comparator's gradient
+    (oracle/cpu_fast.cpp), one host thread per chain as rstan runs chains on `cores` workers (R/utilities.R:1500-1501) and
+    cores / chains OpenMP threads over genes inside a gradient (map_rect shards, R/utilities.R:1383-1386,1479).
+    "CPU restatement of this repository, not rstan"."""
+    from oracle.oracle import CpuFast, Oracle
+    from ppcseq_amd import _lib
+    from ppcseq_amd.ess import ess_bulk
+    from ppcseq_amd.synth import synth
+    chains, warm, keep = 4, 150, 250
+    d = synth(5000, 50, seed=20252)
+    try:
+        cores = min(len(os.sched_getaffinity(0)), 16)
+    except AttributeError:
+        cores = min(os.cpu_count() or 1, 16)
+
+    def ess_of(draws, lp):
+        D = draws.shape[-1]
+        hy = draws[:, :, [0, 1, 2, D - 3, D - 2, D - 1]]
+        return float(np.nanmin([ess_bulk(hy[:, :, j]) for j in range(6)] + [ess_bulk(lp)]))
+
+    m = _lib.Model(d["counts"], d["X"], d["exposure"], d["K"], device=dev_index)
+    f = m.fit_nuts(chains=chains, iter=warm + keep, warmup=warm, seed=seed + 1000)     # untimed: first-launch costs
+    f.close()
+    t0 = time.perf_counter()
+    f = m.fit_nuts(chains=chains, iter=warm + keep, warmup=warm, seed=seed)
+    t_gpu = time.perf_counter() - t0
+    dg = f.diagnostics()
+    ess_gpu, grads_gpu = ess_of(f.draws(), dg["lp"]), int(dg["n_leapfrog"].sum())
+    f.close(); m.close()
+    O, F = Oracle(), CpuFast()
+    cfg = O.cfg(chains=chains, iter=warm + keep, warmup=warm, seed=seed)
+    tpc = max(1, cores // chains)
+    t0 = time.perf_counter()
+    r = F.nuts(O, d["counts"], d["X"], d["exposure"], d["K"], cfg, threads_per_chain=tpc)
+    t_cpu = time.perf_counter() - t0
+    ess_cpu, grads_cpu = ess_of(r.draws, r.lp), int(r.n_leapfrog.sum())
+    return {"workload": "BASELINE cfg2: synthetic 5000 genes x 50 samples (seed 20252), 4 chains, warm-up 150 + 250 kept draws, sampler seed %d" % seed,
+            "gpu": {"seconds": round(t_gpu, 3), "ess_min": round(ess_gpu, 1), "ess_per_s": round(ess_gpu / t_gpu, 2), "grad_evals": grads_gpu},
+            "cpu": {"seconds": round(t_cpu, 2), "ess_min": round(ess_cpu, 1), "ess_per_s": round(ess_cpu / t_cpu, 3), "grad_evals": grads_cpu,
+                    "cores": cores, "threads": chains * tpc, "chains_in_parallel": chains, "threads_per_chain": tpc,
+                    "kind": "port-optimised (oracle/cpu_fast.cpp under the oracle's NUTS driver); not rstan"},
+            "gpu_over_cpu_ess_per_s": round((ess_gpu / t_gpu) / (ess_cpu / t_cpu), 1),
+            "same_first_trees": bool(np.array_equal(dg["n_leapfrog"][:, :6], r.n_leapfrog[:, :6])),
+            "extrapolated": False}
 
 
 def cpu_baseline(arrays, K, gpu_ess, gpu_grad, args):

@@ -69,6 +69,10 @@ PPCX_API int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int
    n groups on their own streams. A chain's draws do not depend on stream_groups. The initial values come from the
    environment variables PPCX_PIPELINE / PPCX_STREAM_GROUPS, read once when the model is created. */
 PPCX_API int ppcx_model_set_rounds(ppcx_model* m, int pipelined, int stream_groups);
+/* what a fit of `nchains` chains of this model runs: pipelined = 1 (two launches per leapfrog: any model with X[,1] = 1 whose
+   slope columns are 0 / 1 indicators -- `~ 1`, `~ Label`, formulas of factors) or 0 (three launches: continuous covariates),
+   and the number of chain groups */
+PPCX_API int ppcx_model_get_rounds(const ppcx_model* m, int nchains, int* pipelined, int* stream_groups);
 /* diagnostic: the log-likelihood launch planned for `nchains` chains -- lanes per gene, workgroups per chain and the
    gene-order positions bounds[0 .. 4 * workgroups_per_chain] delimiting the wavefronts' ranges (NULL to skip) */
 PPCX_API int ppcx_model_get_plan(ppcx_model* m, int nchains, int* lanes_per_gene, int* workgroups_per_chain, int* bounds, int cap);
@@ -174,6 +178,26 @@ PPCX_API int ppcx_comm_unique_id(char* out128);               /* rank 0 creates 
 PPCX_API int ppcx_comm_create(int device, int nranks, int rank, const char* id128, ppcx_comm** out);
 PPCX_API void ppcx_comm_destroy(ppcx_comm* c);
 PPCX_API int ppcx_fit_nuts_comm(ppcx_model* shard, const ppcx_nuts_config* cfg, ppcx_comm* comm, ppcx_fit** out);
+
+/* --- gene shards with a DIRECT exchange (the default between GPUs): no collective library call per leapfrog. Every rank's
+ * receive buffer (uncached device memory) is mapped into every rank -- hipIpc handles between processes -- and the chains'
+ * state machines, which run inside the merged launch of a pipelined round beside the log-likelihood workgroups, store their
+ * <= 76 partial sums into the peers' buffers over xGMI, then a sequence number, and wait for the peers' (rank-order sum:
+ * identical bits, hence identical decisions, on every rank). A peer that leaves the fit or does not arrive within the timeout
+ * fails the fit with PPCX_ERR_STALL on every rank. Needs a model that runs pipelined rounds (ppcx_model_get_rounds); the RCCL
+ * path above serves the others.
+ *   rank r: ppcx_xchg_create -> ppcx_xchg_handle (64 bytes) -> [host layer all-gathers the handles] -> ppcx_xchg_connect
+ *           -> ppcx_fit_nuts_xchg (any number of fits, the same sequence on every rank) -> ppcx_xchg_destroy              */
+typedef struct ppcx_xchg ppcx_xchg;
+PPCX_API int ppcx_xchg_create(int device, int nranks, int rank, int max_chains, ppcx_xchg** out);
+PPCX_API int ppcx_xchg_handle(ppcx_xchg* x, char* out64);
+PPCX_API int ppcx_xchg_connect(ppcx_xchg* x, const char* handles /* nranks x 64 bytes, rank order */);
+PPCX_API int ppcx_xchg_connect_local(ppcx_xchg** group, int n);   /* all ranks in this process (a host thread each) */
+PPCX_API int ppcx_xchg_set_timeout(ppcx_xchg* x, double seconds); /* default 20 s */
+PPCX_API void ppcx_xchg_destroy(ppcx_xchg* x);
+PPCX_API int ppcx_fit_nuts_xchg(ppcx_model* shard, const ppcx_nuts_config* cfg, ppcx_xchg* x, ppcx_fit** out);
+/* mean time (us) a chain's state machine waited for its peers per exchange, and the number of exchanges of the fit */
+PPCX_API int ppcx_fit_get_xchg_timing(ppcx_fit* f, double* wait_us_per_exchange, long long* exchanges);
 
 /* What the ranks of a gene-sharded run conclude at a poll from the max-reduced vector
  * [rounds, -rounds, chains done, -chains done, -(error status)] and their own status: PPCX_OK, the peer's / own error

@@ -24,6 +24,7 @@ struct FastModel {
   std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, SX, ncell, Lg1, tab;
   std::vector<unsigned> low; std::vector<int> low_start, nhi; std::vector<unsigned short> low_m;
   std::vector<double> vecs, hv;
+  int threads = 1;                 // of ppcf_lp_callback
 };
 
 extern "C" __attribute__((visibility("default")))
@@ -35,8 +36,8 @@ void* ppcf_model_create(int G, int S, int C, int K, const int32_t* counts, const
   int x0 = 1;
   for (int s = 0; s < S; ++s) { m->E[s] = exp(expo[s]); if (X[s] != 1.0) x0 = 0; }
   m->d.x0_is_one = x0;
-  int x1b = (C == 2);
-  for (int s = 0; s < S && x1b; ++s) if (X[(size_t)S + s] != 0.0 && X[(size_t)S + s] != 1.0) x1b = 0;
+  int x1b = (C >= 2);
+  for (size_t i = (size_t)S; i < (size_t)S * C && x1b; ++i) if (X[i] != 0.0 && X[i] != 1.0) x1b = 0;
   m->d.x1_binary = x1b;
   m->Sy.assign(G, 0); m->SyE.assign(G, 0); m->SyX.assign((size_t)C * G, 0); m->SX.assign((size_t)C * G, 0); m->ncell.assign(G, 0); m->Lg1.assign(G, 0);
   m->low_start.assign(G + 1, 0); m->nhi.assign(G, 0); m->low_m.assign((size_t)G * 8, 0);
@@ -100,4 +101,13 @@ double ppcf_log_prob_grad(void* h, const double* u, double* grad, int threads) {
   if (m.CM == 2) return eval<2>(m, u, grad, threads);
   if (m.CM == 4) return eval<4>(m, u, grad, threads);
   return eval<8>(m, u, grad, threads);
+}
+
+// The same evaluation as a callback fn(ctx, u, grad) for the oracle's NUTS driver (ppco_nuts_chain_fn): ctx is the model,
+// whose scratch vectors make it single-caller -- one model per chain -- and ppcf_set_threads fixes its OpenMP threads.
+extern "C" __attribute__((visibility("default"))) void ppcf_set_threads(void* h, int threads) { ((FastModel*)h)->threads = threads < 1 ? 1 : threads; }
+extern "C" __attribute__((visibility("default")))
+double ppcf_lp_callback(const void* ctx, const double* u, double* grad) {
+  FastModel* m = (FastModel*)ctx;
+  return ppcf_log_prob_grad(m, u, grad, m->threads);
 }

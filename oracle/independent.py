@@ -123,3 +123,38 @@ def log_prob_grad_torch(u, counts, X, exposure, K, lambda_mu_mu=5.612671, excl=N
 
 
 from ppcseq_amd.synth import synth  # noqa: E402,F401  (the generator itself is product code)
+
+
+def factor_design(S, levels=(3,), seed=0):
+    """model.matrix of a formula of factors (R/utilities.R:887-900, treatment contrasts): an intercept column and, per factor
+    with n levels, n - 1 indicator columns. levels = (3,) is `~ a` with a three-level factor (C = 3, 3 distinct rows);
+    (2, 2) is `~ a + b` of two two-level factors (C = 3, 4 distinct rows); (4,) a four-level factor (C = 4)."""
+    rng = np.random.default_rng(seed)
+    cols = [np.ones(S)]
+    for n in levels:
+        lev = rng.permutation(np.arange(S) % n)
+        for k in range(1, n):
+            cols.append((lev == k).astype(float))
+    return np.stack(cols, axis=1)
+
+
+def synth_factor(G, S, K, levels=(3,), seed=0):
+    """synth() with a factor design: slopes of every indicator column for the checked genes."""
+    from scipy import stats
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = factor_design(S, levels, seed)
+    C = X.shape[1]
+    exposure = rng.normal(0, 0.2, S)
+    exposure -= exposure.mean()
+    intercept = stats.skewnorm.rvs(-1.0, loc=6.5, scale=1.8, size=G, random_state=rng)
+    sigma_raw = rng.normal(-0.3 * intercept, 0.4)
+    phi = np.exp(-sigma_raw)
+    alpha = np.zeros((C, G))
+    alpha[0] = intercept
+    alpha[1, :K] = rng.laplace(0, 1, K)
+    for c in range(2, C):
+        alpha[c, :K] = rng.normal(0, 0.7, K)
+    mu = np.exp((X @ alpha).T + exposure[None, :])
+    lam = rng.gamma(phi[:, None], mu / phi[:, None])
+    counts = np.minimum(rng.poisson(np.minimum(lam, 1e9)), 2**31 - 2).astype(np.int32)
+    return dict(counts=counts, X=X, exposure=exposure, K=K, truth=dict(intercept=intercept, sigma_raw=sigma_raw, alpha=alpha))

@@ -216,3 +216,36 @@ class CpuFast:
 
     def free(self, m):
         self.lib.ppcf_model_destroy(m)
+
+    def nuts(self, oracle: "Oracle", counts, X, exposure, K, cfg, threads_per_chain=1, chain_id_offset=0) -> NutsResult:
+        """A whole CPU fit: the oracle's NUTS driver (ppco_nuts_chain_fn: Stan-default sampler, same Philox streams as the GPU
+        fit) on this comparator's gradient, one host thread per chain (as rstan runs chains on `cores` workers,
+        R/utilities.R:1500-1501) and `threads_per_chain` OpenMP threads over genes inside a gradient (map_rect shards,
+        R/utilities.R:1383-1386,1479). Each chain owns a model: the evaluation keeps scratch vectors in it."""
+        import threading
+        L = oracle.lib
+        fn = C.cast(self.lib.ppcf_lp_callback, C.c_void_p)
+        L.ppco_nuts_chain_fn.restype = C.c_int
+        L.ppco_nuts_chain_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_Cfg), C.c_int] + [C.c_void_p] * 7
+        self.lib.ppcf_set_threads.argtypes = [C.c_void_p, C.c_int]
+        models = [self.model(counts, X, exposure, K) for _ in range(cfg.chains)]
+        D = int(self.lib.ppcf_dim(models[0]))
+        o = oracle._alloc(cfg, D)
+        done = np.zeros(cfg.chains, np.int32)
+
+        def run(c):
+            self.lib.ppcf_set_threads(models[c], int(threads_per_chain))
+            done[c] = L.ppco_nuts_chain_fn(fn, models[c], D, C.byref(cfg), int(chain_id_offset + c),
+                                           o["draws"][c].ctypes.data, o["lp"][c].ctypes.data, o["stepsize"][c].ctypes.data,
+                                           o["treedepth"][c].ctypes.data, o["n_leapfrog"][c].ctypes.data,
+                                           o["divergent"][c].ctypes.data, o["accept"][c].ctypes.data)
+        th = [threading.Thread(target=run, args=(c,)) for c in range(cfg.chains)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for m in models:
+            self.free(m)
+        if (done < 0).any():
+            raise RuntimeError("CPU NUTS: initialisation failed")
+        return NutsResult(metric=None, iters_done=done, **o)

@@ -624,6 +624,15 @@ PPCO_EXPORT int ppco_nuts_model(const ppco_model* m, const ppco_nuts_cfg* cfg, d
   }
   return rc;
 }
+/* One chain of the same sampler on a caller-supplied log density (fn(ctx, u, grad) returns lp and fills grad): bench.py's
+ * `--cpu-full-cfg2` leg drives the optimised CPU comparator (oracle/cpu_fast.cpp) through it, one chain per host thread, so
+ * that a whole CPU fit -- same seeds, chains, warm-up and iterations as the GPU fit -- is timed rather than extrapolated.
+ * chain_id is the chain's global id (its Philox stream). Returns the iterations completed, < 0 on init failure. */
+PPCO_EXPORT int ppco_nuts_chain_fn(ppco_lp_fn fn, const void* ctx, int D, const ppco_nuts_cfg* cfg, int chain_id,
+                                   double* draws, double* lp, double* stepsize, int* treedepth, int* n_leapfrog,
+                                   int* divergent, double* accept) {
+  return run_chain(fn, ctx, D, cfg, chain_id, draws, lp, stepsize, treedepth, n_leapfrog, divergent, accept, NULL);
+}
 PPCO_EXPORT int ppco_nuts_gauss(int D, const double* mean, const double* sd, const ppco_nuts_cfg* cfg,
                                 double* draws, double* lp, double* stepsize, int* treedepth,
                                 int* n_leapfrog, int* divergent, double* accept) {

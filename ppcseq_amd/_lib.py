@@ -18,10 +18,12 @@ EXPORTS = [
     "ppcx_version", "ppcx_device_count", "ppcx_last_error", "ppcx_model_create", "ppcx_model_set_exclusions",
     "ppcx_model_set_launch", "ppcx_model_get_launch", "ppcx_model_get_plan", "ppcx_model_dim", "ppcx_model_destroy", "ppcx_log_prob_grad",
     "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_from_draws", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
-    "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_model_set_rounds",
+    "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_model_set_rounds", "ppcx_model_get_rounds",
     "ppcx_model_create_shard", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
     "ppcx_fit_nuts_comm", "ppcx_advi_config_default", "ppcx_fit_advi", "ppcx_fit_advi_info", "ppcx_fit_advi_iterative",
     "ppcx_guard_decision", "ppcx_device_memory", "ppcx_fit_get_ppc_timing",
+    "ppcx_xchg_create", "ppcx_xchg_handle", "ppcx_xchg_connect", "ppcx_xchg_connect_local", "ppcx_xchg_set_timeout", "ppcx_xchg_destroy",
+    "ppcx_fit_nuts_xchg", "ppcx_fit_get_xchg_timing",
 ]
 ABI_VERSION = 300           # include/ppcx.h PPCX_VERSION this binding was written for
 
@@ -95,6 +97,16 @@ def load() -> C.CDLL:
     lib.ppcx_fit_ppc.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_ulonglong, C.c_int, C.c_int, dp, ip]
     lib.ppcx_fit_free.argtypes = [C.c_void_p]
     lib.ppcx_model_set_rounds.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.ppcx_xchg_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.ppcx_xchg_handle.argtypes = [C.c_void_p, C.c_char_p]
+    lib.ppcx_xchg_connect.argtypes = [C.c_void_p, C.c_char_p]
+    lib.ppcx_xchg_connect_local.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.ppcx_xchg_set_timeout.argtypes = [C.c_void_p, C.c_double]
+    lib.ppcx_xchg_destroy.argtypes = [C.c_void_p]
+    lib.ppcx_xchg_destroy.restype = None
+    lib.ppcx_fit_nuts_xchg.argtypes = [C.c_void_p, C.POINTER(NutsConfig), C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.ppcx_fit_get_xchg_timing.argtypes = [C.c_void_p, dp, C.POINTER(C.c_longlong)]
+    lib.ppcx_model_get_rounds.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     if hasattr(lib, "ppcx_testing_set"):         # the testing build (csrc/ppcx_testing.h)
         lib.ppcx_testing_set.argtypes = [C.c_char_p, C.c_longlong]
         lib.ppcx_testing_set_nccl_provider.argtypes = [C.c_char_p]
@@ -255,10 +267,23 @@ class Model:
         _check(load().ppcx_fit_nuts_comm(self._h, C.byref(cfg), comm._h, C.byref(h)))
         return Fit(self, h)
 
+    def fit_nuts_xchg(self, xchg: "Xchg", **kw) -> "Fit":
+        """This rank's gene shard of a multi-GPU fit; the ranks' partial sums are exchanged directly by the state machines."""
+        cfg = _make_cfg(**kw)
+        h = C.c_void_p()
+        _check(load().ppcx_fit_nuts_xchg(self._h, C.byref(cfg), xchg._h, C.byref(h)))
+        return Fit(self, h)
+
     def set_rounds(self, pipelined=-1, stream_groups=0):
         """Round structure of this model's NUTS fits: pipelined -1 = wherever the model allows it (default), 0 = the
         three-launch round; stream_groups 0 = by the number of chains, n = n chain groups on their own streams."""
         _check(load().ppcx_model_set_rounds(self._h, int(pipelined), int(stream_groups)))
+
+    def get_rounds(self, nchains=1):
+        """(pipelined, stream_groups) a fit of `nchains` chains would run with."""
+        a, b = C.c_int(), C.c_int()
+        _check(load().ppcx_model_get_rounds(self._h, int(nchains), C.byref(a), C.byref(b)))
+        return bool(a.value), b.value
 
     def bench_kernel(self, which=0, nchains=1, warm_rounds=40, reps=50, n_merge=1):
         """(ms per launch, command type) of one kernel of the three-launch round -- testing build only."""
@@ -317,6 +342,43 @@ class Comm:
             self._h = None
 
 
+class Xchg:
+    """Direct-exchange group of a gene-sharded fit (include/ppcx.h ppcx_xchg_*): one rank per process and GPU, connected
+    through IPC handles that the host layer all-gathers; or all ranks in this process (Xchg.local_group)."""
+
+    def __init__(self, nranks, rank, max_chains, device=0):
+        h = C.c_void_p()
+        _check(load().ppcx_xchg_create(int(device), int(nranks), int(rank), int(max_chains), C.byref(h)))
+        self._h, self.nranks, self.rank = h, int(nranks), int(rank)
+
+    def handle(self) -> bytes:
+        buf = C.create_string_buffer(64)
+        _check(load().ppcx_xchg_handle(self._h, buf))
+        return buf.raw
+
+    def connect(self, handles):
+        """handles: the ranks' 64-byte handles in rank order."""
+        blob = b"".join(handles)
+        if len(blob) != 64 * self.nranks:
+            raise ValueError("need one 64-byte handle per rank")
+        _check(load().ppcx_xchg_connect(self._h, blob))
+
+    @staticmethod
+    def local_group(n, max_chains, devices=None):
+        xs = [Xchg(n, k, max_chains, device=(devices[k] if devices else 0)) for k in range(n)]
+        arr = (C.c_void_p * n)(*[x._h for x in xs])
+        _check(load().ppcx_xchg_connect_local(arr, n))
+        return xs
+
+    def set_timeout(self, seconds):
+        _check(load().ppcx_xchg_set_timeout(self._h, float(seconds)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().ppcx_xchg_destroy(self._h)
+            self._h = None
+
+
 @dataclass
 class Timing:
     seconds: float
@@ -368,6 +430,12 @@ class Fit:
         el, et = C.c_double(), C.c_double()
         _check(load().ppcx_fit_advi_info(self._h, C.byref(it), C.byref(cv), C.byref(el), C.byref(et)))
         return dict(iterations=it.value, converged=bool(cv.value), elbo=el.value, eta=et.value)
+
+    def xchg_timing(self):
+        """(mean us a chain's state machine waited for its peers per exchange, exchanges) of a direct-exchange fit."""
+        us, n = C.c_double(), C.c_longlong()
+        _check(load().ppcx_fit_get_xchg_timing(self._h, C.byref(us), C.byref(n)))
+        return us.value, int(n.value)
 
     def ppc_timing(self):
         """(kernel ms, NB draws) of the last ppc() call on this fit."""

@@ -16,6 +16,14 @@ HEADERS = ["ppcx_math.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h", "ppcx_ke
            os.path.join("..", "..", "include", "ppcx.h")]
 
 
+# hipcc (ROCm 7.2, LLVM 20) miscompiles the scalar state machine of ppcx_step_kernel when AMDGPUCodeGenPrepare breaks the
+# <2 x i32> phis that the SLP vectoriser makes of adjacent Cmd fields into scalar phis: the IR stays correct, the ISA loses
+# a copy on one predecessor path (Cmd::rng_c3 = 0 on the halving / doubling path of the step-size search). Traced in round 4
+# (profiles/r04_miscompile/): of 15 builds with single passes switched off only this flag and
+# -fno-slp-vectorize give correct code; neither changes a kernel's time.
+CODEGEN_FLAGS = ["-mllvm", "-amdgpu-codegenprepare-break-large-phis=false"]
+
+
 def _stale(lib: str) -> bool:
     if not os.path.exists(lib):
         return True
@@ -30,7 +38,7 @@ def _compile(lib: str, extra, verbose: bool) -> None:
     for s in SOURCES:                            # the two translation units side by side
         o = lib + "." + s + ".o"
         objs.append(o)
-        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"] + extra + \
+        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"] + CODEGEN_FLAGS + extra + \
               ["-c", "-o", o, os.path.join(CSRC, s)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

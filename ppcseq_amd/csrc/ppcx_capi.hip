@@ -84,6 +84,7 @@ struct ppcx_fit {
   double kC_ms_mean = 0, kU_ms_mean = 0; long long launch_triples = 0;
   double advi_elbo = 0, advi_eta = 0; int advi_converged = 0;
   double ppc_ms = 0; long long ppc_draws = 0;  // last ppcx_fit_ppc: kernel time (HIP events) and NB draws generated
+  long long xchg_ticks = 0, xchg_count = 0;    // direct exchange: 100 MHz ticks the chains' state machines waited for peers, exchanges
 };
 
 extern "C" int ppcx_version(void) { return PPCX_VERSION; }
@@ -124,7 +125,7 @@ static double pass_cost(const ppcx_model* m, int L, int p, int n) {
   const bool ignore_tiers = false;
 #endif
   const double tail = (slope || ignore_tiers) ? 1.0 : (tier >= 2 ? 0.86 : (tier >= 1 ? 0.91 : 1.0));
-  const double sweep = (double)((S + L - 1) / L) * tail * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? 1.15 : 1.0));
+  const double sweep = (double)((S + L - 1) / L) * tail * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? (m->d.C > 2 ? 1.5 : 1.15) : 1.0));
   return 5.8 + sweep + 0.75 * (double)((lowmax + L - 1) / L);
 }
 // reserve: workgroups of the same launch that are not log-likelihood workgroups (the state machines of a pipelined
@@ -334,8 +335,8 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   int x0 = 1;
   for (int s = 0; s < S; ++s) if (X[s] != 1.0) x0 = 0;
   m->d.x0_is_one = x0;
-  int x1b = (C == 2);                          // two-group design: the second column is an indicator
-  for (int s = 0; s < S && x1b; ++s) if (X[(size_t)S + s] != 0.0 && X[(size_t)S + s] != 1.0) x1b = 0;
+  int x1b = (C >= 2);                          // factor design: every slope column is a 0 / 1 indicator (C == 2: two groups)
+  for (size_t i = (size_t)S; i < (size_t)S * C && x1b; ++i) if (X[i] != 0.0 && X[i] != 1.0) x1b = 0;
 #ifdef PPCX_TESTING
   if (g_test.force_generic) x1b = 0;
 #endif
@@ -399,6 +400,21 @@ extern "C" int ppcx_model_set_rounds(ppcx_model* m, int pipelined, int stream_gr
   m->opt_pipelined = pipelined; m->opt_stream_groups = stream_groups;
   return PPCX_OK;
 }
+static bool model_pipelines(const ppcx_model* m) {
+  // the pipelined round needs a model whose cells read the anticipated constants only: X[,1] = 1 and slopes only on
+  // indicator columns (no per-cell linear predictor)
+  return m->opt_pipelined != 0 && m->ls_wgs_per_cu >= 1 && m->d.x0_is_one && (m->d.C < 2 || m->d.K == 0 || m->d.x1_binary);
+}
+extern "C" int ppcx_model_get_rounds(const ppcx_model* m, int nchains, int* pipelined, int* stream_groups) {
+  if (!m || nchains < 1) return fail(PPCX_ERR_ARG, "bad arguments");
+  if (pipelined) *pipelined = model_pipelines(m) ? 1 : 0;
+  if (stream_groups) {
+    int g = default_stream_groups(nchains);
+    if (m->opt_stream_groups >= 1) g = m->opt_stream_groups < nchains ? m->opt_stream_groups : nchains;
+    *stream_groups = g;
+  }
+  return PPCX_OK;
+}
 extern "C" int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int* nblocks) {
   if (!m) return fail(PPCX_ERR_ARG, "model is NULL");
   if (lanes_per_gene) *lanes_per_gene = m->L;
@@ -453,6 +469,7 @@ struct Work {
   hipStream_t stream = nullptr; bool own_stream = false;
   bool pipelined = false;        // two launches per round (ppcx_ls_kernel + ppcx_gene_kernel) instead of three
   int *active = nullptr, *active_host = nullptr; int n_active = 0;   // chains still running (pump), 0 = all
+  const XchgArgs* xchg = nullptr; int xchg_chain0 = 0;   // gene shards with the direct exchange: the group's first chain in the buffers
   ~Work() {
     (void)hipFree(vecs); (void)hipFree(partials); (void)hipFree(done); (void)hipFree(sums); (void)hipFree(red);
     for (int i = 0; i < 2; ++i) { (void)hipFree(hyper_vecs[i]); (void)hipFree(t0[i]); (void)hipFree(cmds[i]); (void)hipFree(states[i]); }
@@ -529,6 +546,11 @@ static void step_args(ppcx_model* m, Work& w, const RunIO& io, int phases, bool 
   sa.out_lp = io.lp; sa.out_stepsize = io.stepsize; sa.out_treedepth = io.treedepth; sa.out_n_leapfrog = io.nleap;
   sa.out_divergent = io.div; sa.out_accept = io.accept; sa.done = w.done;
   sa.upd_vecs = nullptr; sa.upd_Dpad = 0; sa.upd_t0_out = nullptr; sa.upd_logtab = nullptr;
+  sa.x = XchgArgs();
+  if (w.xchg) {                                  // this group's chains start at xchg_chain0 of the exchange buffers
+    sa.x = *w.xchg;
+    sa.x.chain0 = w.xchg_chain0;
+  }
   if (with_update && (phases & STEP_ADVANCE)) { sa.upd_vecs = w.vecs; sa.upd_Dpad = w.Dpad; sa.upd_t0_out = w.t0[out]; sa.upd_logtab = m->d_logtab; }
 }
 static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int phases, bool with_update = false) {
@@ -771,7 +793,7 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
     }
 #ifdef PPCX_TESTING
     if (g_test.fail_at_round > 0 && pairs >= g_test.fail_at_round && local_rc == PPCX_OK &&
-        (g_test.fail_rank < 0 || !comm || g_test.fail_rank == comm->rank))      // fault injection for the guard's tests
+        (g_test.fail_rank < 0 || (!comm && !w0.xchg) || g_test.fail_rank == (comm ? comm->rank : w0.xchg->rank)))   // fault injection
       local_rc = fail(PPCX_ERR_HIP, "injected failure (ppcx_testing_set fail_at_round)");
 #endif
     int* flags = w0.done_host + (lookahead ? cur * nchains : 0);
@@ -800,6 +822,7 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       if (flags[c]) ++n_done;
       if (flags[c] == 2) rc = fail(PPCX_ERR_INIT, "no finite initial point after 100 attempts");
       if (flags[c] == 3) rc = fail(PPCX_ERR_STEPSIZE, "step-size heuristic diverged");
+      if (flags[c] == 5) rc = fail(PPCX_ERR_STALL, "gene-shard exchange: a peer rank left the fit or did not arrive within the timeout");
     }
     if (pairs > max_pairs && n_done < nchains && rc == PPCX_OK) rc = fail(PPCX_ERR_STALL, "launch budget exhausted before the chains finished");
     if (guarded) {
@@ -976,7 +999,109 @@ extern "C" void ppcx_fit_free(ppcx_fit* f) {
   if (--m->live_fits == 0 && m->destroy_requested) ppcx_model_destroy(m);
 }
 
-extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fit** out) {
+// ---- direct exchange between the ranks of a gene-sharded run (ppcx_kernels.h XchgArgs) ---------------------------------
+struct ppcx_xchg {
+  int device = 0, nranks = 1, rank = 0, max_chains = 0;
+  void* local = nullptr; size_t bytes = 0;       // this rank's receive buffer: sums, then sequence numbers and abort words
+  void* peer[kMaxRanks] = {};                    // every rank's buffer as this process sees it (peer[rank] = local)
+  bool opened[kMaxRanks] = {};                   // mapped through an IPC handle (to be closed)
+  bool connected = false;
+  unsigned epoch = 0;                            // fits run over this group
+  double timeout_s = 20.0;
+  std::mutex* mu = nullptr;
+};
+static size_t xchg_bytes(int nranks, int max_chains) { return sizeof(double) * xchg_recv_doubles(nranks, max_chains) + sizeof(unsigned long long) * xchg_flag_words(nranks, max_chains); }
+extern "C" int ppcx_xchg_create(int device, int nranks, int rank, int max_chains, ppcx_xchg** out) {
+  if (!out || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks || max_chains < 1 || max_chains > 1024)
+    return fail(PPCX_ERR_ARG, "need 1 <= nranks <= 16, 0 <= rank < nranks, 1 <= max_chains <= 1024");
+  *out = nullptr;
+  HIPCHK(hipSetDevice(device));
+  ppcx_xchg* x = new ppcx_xchg();
+  x->device = device; x->nranks = nranks; x->rank = rank; x->max_chains = max_chains; x->bytes = xchg_bytes(nranks, max_chains);
+  // uncached device memory: a peer's stores must be seen by loads of a kernel that is already running
+  hipError_t e = hipExtMallocWithFlags(&x->local, x->bytes, hipDeviceMallocUncached);
+  if (e == hipSuccess) e = hipMemset(x->local, 0, x->bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { (void)hipFree(x->local); delete x; return fail(PPCX_ERR_HIP, std::string("exchange buffer: ") + hipGetErrorString(e)); }
+  x->peer[rank] = x->local;
+  if (nranks == 1) x->connected = true;
+  *out = x;
+  return PPCX_OK;
+}
+extern "C" int ppcx_xchg_handle(ppcx_xchg* x, char* out64) {
+  if (!x || !out64) return fail(PPCX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(x->device));
+  hipIpcMemHandle_t h;
+  HIPCHK(hipIpcGetMemHandle(&h, x->local));
+  static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
+  memcpy(out64, &h, 64);
+  return PPCX_OK;
+}
+extern "C" int ppcx_xchg_connect(ppcx_xchg* x, const char* handles) {
+  if (!x || !handles) return fail(PPCX_ERR_ARG, "NULL argument");
+  if (x->connected) return fail(PPCX_ERR_ARG, "the exchange group is connected already");
+  HIPCHK(hipSetDevice(x->device));
+  for (int k = 0; k < x->nranks; ++k) {
+    if (k == x->rank) continue;
+    hipIpcMemHandle_t h; memcpy(&h, handles + (size_t)k * 64, 64);
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(PPCX_ERR_HIP, "hipIpcOpenMemHandle (rank " + std::to_string(k) + "): " + hipGetErrorString(e));
+    x->peer[k] = p; x->opened[k] = true;
+  }
+  x->connected = true;
+  return PPCX_OK;
+}
+// ranks that live in ONE process (host threads, a shard model each -- on one device or several): plain device pointers
+extern "C" int ppcx_xchg_connect_local(ppcx_xchg** group, int n) {
+  if (!group || n < 1 || n > kMaxRanks) return fail(PPCX_ERR_ARG, "bad group");
+  for (int k = 0; k < n; ++k) if (!group[k] || group[k]->nranks != n || group[k]->rank != k || group[k]->connected || group[k]->max_chains != group[0]->max_chains)
+    return fail(PPCX_ERR_ARG, "group[k] must be the unconnected rank k of n, all with the same max_chains");
+  for (int k = 0; k < n; ++k) {
+    for (int j = 0; j < n; ++j) {
+      if (group[k]->device != group[j]->device) {
+        (void)hipSetDevice(group[k]->device);
+        hipError_t e = hipDeviceEnablePeerAccess(group[j]->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(PPCX_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+      }
+      group[k]->peer[j] = group[j]->local;
+    }
+    group[k]->connected = true;
+  }
+  return PPCX_OK;
+}
+extern "C" int ppcx_xchg_set_timeout(ppcx_xchg* x, double seconds) {
+  if (!x || !(seconds > 0)) return fail(PPCX_ERR_ARG, "bad arguments");
+  x->timeout_s = seconds;
+  return PPCX_OK;
+}
+extern "C" void ppcx_xchg_destroy(ppcx_xchg* x) {
+  if (!x) return;
+  (void)hipSetDevice(x->device);
+  for (int k = 0; k < x->nranks; ++k) if (x->opened[k] && x->peer[k]) (void)hipIpcCloseMemHandle(x->peer[k]);
+  (void)hipFree(x->local);
+  delete x;
+}
+static void xchg_fill(const ppcx_xchg* x, XchgArgs* a) {
+  a->nranks = x->nranks; a->rank = x->rank; a->max_chains = x->max_chains; a->chain0 = 0; a->epoch = x->epoch;
+  a->timeout_ticks = (long long)(x->timeout_s * 1e8);
+  const size_t nd = xchg_recv_doubles(x->nranks, x->max_chains);
+  for (int k = 0; k < kMaxRanks; ++k) {
+    a->recv[k] = k < x->nranks ? (double*)x->peer[k] : nullptr;
+    a->flags[k] = k < x->nranks ? (unsigned long long*)((double*)x->peer[k] + nd) : nullptr;
+  }
+}
+
+static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* xg, ppcx_fit** out);
+extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fit** out) { return fit_nuts_impl(m, cfg, nullptr, out); }
+// One gene shard per rank, the ranks' sums added by the state machines themselves (direct exchange): the pipelined round of
+// ppcx_fit_nuts with one more step inside the merged launch. Every rank calls it with the same configuration.
+extern "C" int ppcx_fit_nuts_xchg(ppcx_model* shard, const ppcx_nuts_config* cfg, ppcx_xchg* xg, ppcx_fit** out) {
+  if (!xg) return fail(PPCX_ERR_ARG, "exchange group is NULL");
+  return fit_nuts_impl(shard, cfg, xg, out);
+}
+static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* xg, ppcx_fit** out) {
   if (!m || !cfg || !out) return fail(PPCX_ERR_ARG, "NULL argument");
   *out = nullptr;
   if (cfg->chains < 1 || cfg->chains > 1024 || cfg->iter < 1 || cfg->warmup < 0 || cfg->warmup > cfg->iter)
@@ -1015,8 +1140,17 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   // structures sum the kinetic energy of fresh momenta in different orders, and a chain's draws may not depend on its
   // company. (With more chains than the chip holds workgroups the state machines simply run ahead of the log-likelihood
   // workgroups instead of beside them.) ppcx_model_set_rounds(m, 0, ...) selects the three-launch round.
-  bool piped = m->ls_wgs_per_cu >= 1 && m->d.x0_is_one && (m->d.C < 2 || m->d.K == 0 || m->d.x1_binary);
-  if (m->opt_pipelined == 0) piped = false;
+  const bool piped = model_pipelines(m);
+  XchgArgs xa;
+  if (xg) {
+    if (!xg->connected) return fail(PPCX_ERR_ARG, "the exchange group is not connected");
+    if (xg->device != m->device) return fail(PPCX_ERR_ARG, "the exchange group lives on another device than the shard");
+    if (cfg->chains > xg->max_chains) return fail(PPCX_ERR_ARG, "more chains than the exchange group was created for");
+    if (!piped) return fail(PPCX_ERR_LIMIT, "the direct exchange runs inside pipelined rounds, which this model (a per-cell linear predictor) "
+                                             "or ppcx_model_set_rounds rules out: use ppcx_fit_nuts_comm");
+    xg->epoch += 1;                             // every rank counts the fits of the group: sequence numbers of earlier fits never match
+    xchg_fill(xg, &xa);
+  }
   // Chains can also be split into groups that run on their own streams from their own host threads
   // (ppcx_model_set_rounds): while one group sits in its memory-bound gene kernel another group's log-likelihood
   // workgroups have the CUs: measured at cfg3 / 8 chains, pipelined rounds (final kernels of round 3, mean of two fits):
@@ -1026,13 +1160,14 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
   // fit are only meaningful with one group (bench.py takes its roofline sample from a fit on one stream).
   int ngrp = default_stream_groups(nch);
   if (m->opt_stream_groups >= 1) ngrp = m->opt_stream_groups < nch ? m->opt_stream_groups : nch;
-  struct Group { int c0 = 0, n = 0; Work w; RunIO io; PumpStats ps; int rc = PPCX_OK; std::string err; long long leap = 0; };
+  struct Group { int c0 = 0, n = 0; Work w; RunIO io; PumpStats ps; int rc = PPCX_OK; std::string err; long long leap = 0, xticks = 0, xcount = 0; };
   std::vector<Group> grp(ngrp);
   const long long max_pairs = ((long long)iter * ((1LL << cfg->max_treedepth) + 8) + 100000) * (piped ? 2 : 1);
   for (int g = 0; g < ngrp; ++g) {
     Group& G = grp[g];
     G.w.pipelined = piped;
     G.c0 = (int)((long long)nch * g / ngrp); G.n = (int)((long long)nch * (g + 1) / ngrp) - G.c0;
+    if (xg && xg->nranks > 1) { G.w.xchg = &xa; G.w.xchg_chain0 = G.c0; }
     if (g > 0) { FHIP(hipStreamCreateWithFlags(&G.w.stream, hipStreamNonBlocking)); G.w.own_stream = true; }
     int rc = work_alloc(G.w, m, G.n);
     if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }
@@ -1058,7 +1193,7 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
     if (hipMemcpy(states.data(), current_states(G->w), sizeof(ChainState) * G->n, hipMemcpyDeviceToHost) != hipSuccess) {
       G->rc = PPCX_ERR_HIP; G->err = "reading back the chain states failed"; return;
     }
-    for (int c = 0; c < G->n; ++c) G->leap += states[c].sc.total_leapfrogs;
+    for (int c = 0; c < G->n; ++c) { G->leap += states[c].sc.total_leapfrogs; G->xticks += states[c].sc.xticks; G->xcount += states[c].sc.xcount; }
   };
   {
     std::vector<std::thread> th;
@@ -1067,12 +1202,20 @@ extern "C" int ppcx_fit_nuts(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_fi
     for (auto& t : th) t.join();
   }
   const auto t1 = std::chrono::steady_clock::now();
-  for (int g = 0; g < ngrp; ++g) if (grp[g].rc != PPCX_OK) { const int rc = grp[g].rc; const std::string e = grp[g].err; ppcx_fit_free(f); return fail(rc, e); }
+  for (int g = 0; g < ngrp; ++g) if (grp[g].rc != PPCX_OK) {
+    const int rc = grp[g].rc; const std::string e = grp[g].err;
+    if (xg && xg->nranks > 1) {                  // the peers' state machines wait for this rank: tell them it has left
+      (void)launch_xchg_abort_kernel(xa, m->stream);
+      (void)hipStreamSynchronize(m->stream);
+    }
+    ppcx_fit_free(f);
+    return fail(rc, e);
+  }
   f->seconds = std::chrono::duration<double>(t1 - t0).count();
   f->grad_evals = 0;
   PumpStats ps;
   for (int g = 0; g < ngrp; ++g) {
-    f->grad_evals += grp[g].leap;
+    f->grad_evals += grp[g].leap; f->xchg_ticks += grp[g].xticks; f->xchg_count += grp[g].xcount;
     ps.kA_ms_sum += grp[g].ps.kA_ms_sum; ps.kC_ms_sum += grp[g].ps.kC_ms_sum; ps.kU_ms_sum += grp[g].ps.kU_ms_sum;
     ps.kA_samples += grp[g].ps.kA_samples; ps.chain_launches += grp[g].ps.chain_launches; ps.pairs += grp[g].ps.pairs;
   }
@@ -1479,6 +1622,12 @@ extern "C" int ppcx_fit_get_kernel_times(ppcx_fit* f, double* loglik_ms, double*
   if (close_ms) *close_ms = f->kC_ms_mean;
   if (update_ms) *update_ms = f->kU_ms_mean;
   if (launch_triples) *launch_triples = f->launch_triples;
+  return PPCX_OK;
+}
+extern "C" int ppcx_fit_get_xchg_timing(ppcx_fit* f, double* wait_us_per_exchange, long long* exchanges) {
+  if (!f) return fail(PPCX_ERR_ARG, "fit is NULL");
+  if (wait_us_per_exchange) *wait_us_per_exchange = f->xchg_count > 0 ? (double)f->xchg_ticks / 100.0 / (double)f->xchg_count : 0.0;
+  if (exchanges) *exchanges = f->xchg_count;
   return PPCX_OK;
 }
 extern "C" int ppcx_fit_get_ppc_timing(ppcx_fit* f, double* kernel_ms, long long* nb_draws) {

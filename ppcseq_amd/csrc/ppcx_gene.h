@@ -80,7 +80,8 @@ PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, Gene
 //       immediate offsets and a trip costs one address update;
 //   (2) the gene's low-count list (0 <= y <= 7; entries (y << 16) | s, built by the host in sample order): cell_eval_low;
 //   (3) the count part of the list cells, low_terms, term k by lane k (mod L).
-// Genes with slopes in a two-group design take the same route with e^t = E_s A or E_s A1 by the sample's group; any
+// Genes with slopes in a two-group design take the same route with e^t = E_s A or E_s A1 by the sample's group; with more
+// indicator columns (factor designs, C > 2) e^t = E_s A prod exp(slope_c) over the sample's columns (indicator_cells); any
 // other gene with slopes, and every gene when X[,1] != 1, forms eta per cell (generic_cells: an exp per cell).
 // `counts` must be readable 4 L entries past the end of the matrix, `sE` / `sX` (LDS) 4 L entries past S, `low` L past
 // its end: the host and the kernel pad them.
@@ -180,6 +181,30 @@ PPCX_HD void generic_cells(const Dims& d, const Cmd& c, const VecRef& v, int g, 
   }
 }
 
+// a gene with slopes in a design whose slope columns are all 0 / 1 indicators (model.matrix of factors: a multi-level factor,
+// `~ a + b` of factors; R/utilities.R:887-900) and C > 2: e^t still factorises -- E_s A_g times the product of exp(slope_c)
+// over the columns set for the sample -- from the per-coordinate constants exp(q), no exp per cell. One loop over the row
+// (5 % of the genes take it: the checked ones), the list cells evaluated in place.
+template <int CM, int L>
+PPCX_HD void indicator_cells(const Dims& d, const int* row, const double* sE, const double* sX, int sub, double A,
+                             const double* ec /* exp(slope_c), c = 1 .. C - 1 */, const GeneParams<CM>& gp, const double* tab,
+                             CellAcc<CM>& acc) {
+  const int S = d.S, C = d.C;
+  int it = 0;
+  for (int s = sub; s < S; s += L) {
+    const int y = row[s];
+    if (y >= 0) {
+      double a = A;
+#pragma unroll
+      for (int cc = 1; cc < CM; ++cc) if (cc < C) a = sX[cc * S + s] != 0.0 ? a * ec[cc] : a;
+      const double rho = y >= kLowCount ? cell_eval<CM>(y, sE[s], a, gp, tab, acc) : cell_eval_low<CM>(y, sE[s], a, gp, tab, acc);
+#pragma unroll
+      for (int cc = 1; cc < CM; ++cc) if (cc < C) acc.Tx[cc] = fma(sX[cc * S + s], rho, acc.Tx[cc]);
+    }
+    if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
+  }
+}
+
 // one lane's share of gene g: the hand-over sums before the L-lane reduction
 // GEN = false: a model in which every gene factorises (X[,1] == 1 and slopes only in a two-group design) -- the
 // per-cell-eta path is not compiled in, which leaves the registers to the sweep
@@ -209,7 +234,18 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   }
   if (!GEN || PPCX_WAVE_ANY(!generic)) {
     if (!generic) {
-      if (PPCX_WAVE_ANY(two)) {                            // e^t = E_s A or E_s A1 by the sample's group (X[,2] is 0 or 1)
+      if (CM > 2 && d.C > 2 && PPCX_WAVE_ANY(two)) {       // indicator columns, C > 2: genes with slopes first (host order),
+        if (two) {                                         // so a pass rarely mixes the two kinds
+          double ec[CM];
+          ec[0] = 1.0;
+#pragma unroll
+          for (int cc = 1; cc < CM; ++cc) ec[cc] = cc < d.C ? v.at(V_C0, coef_index(d, cc, g)) : 1.0;
+          indicator_cells<CM, L>(d, row, sE, sX, sub, A, ec, gp, tab, acc);
+        } else {
+          sweep_cells<CM, L, false>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+          low_cells<CM, L, false>(m.low + lo, low_n, sE, sX, sub, A, A, gp, tab, acc);
+        }
+      } else if (PPCX_WAVE_ANY(two)) {                     // e^t = E_s A or E_s A1 by the sample's group (X[,2] is 0 or 1)
         const double A1 = two ? A * v.at(V_C0, coef_index(d, 1, g)) : A;
         sweep_cells<CM, L, true>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc);
         low_cells<CM, L, true>(m.low + lo, low_n, sE, sX + S, sub, A, A1, gp, tab, acc);

@@ -48,6 +48,27 @@ struct GeneArgs {
   int spec;                     // anticipate the next leaf's position (models whose cell paths read the constants only)
 };
 
+// Direct exchange of a gene-sharded run (one shard per rank; the reference's map_rect over gene shards,
+// inst/stan/negBinomial_MPI.stan:226-240): every rank's state machine adds the ranks' partial sums itself. Rank k's receive
+// buffer is mapped into every rank (peer-mapped device memory: hipIpc handles between processes, plain pointers inside one);
+// a state machine stores its PT_COUNT sums into every rank's buffer, then a sequence number, and waits until the sequence
+// numbers of all ranks have arrived in its own buffer. No collective library call, no kernel boundary: the exchange happens
+// inside the merged launch of a pipelined round, beside the log-likelihood workgroups.
+constexpr int kMaxRanks = 16;
+struct XchgArgs {
+  int nranks = 1, rank = 0, max_chains = 0;
+  int chain0 = 0;                              // first chain of the launch's chain group in the buffers
+  unsigned epoch = 0;                          // of this fit: stale sequence numbers of earlier fits never match
+  long long timeout_ticks = 0;                 // of the 100 MHz wall clock: a peer that does not arrive fails the chain
+  double* recv[kMaxRanks];                     // [2 slots][nranks][max_chains][PT_COUNT]
+  unsigned long long* flags[kMaxRanks];        // [2 slots][nranks][max_chains] sequence numbers, then [nranks] abort epochs
+};
+PPCX_HD long xchg_recv_index(const XchgArgs& x, int slot, int src, int chain) { return (((long)slot * x.nranks + src) * x.max_chains + x.chain0 + chain) * PT_COUNT; }
+PPCX_HD long xchg_flag_index(const XchgArgs& x, int slot, int src, int chain) { return ((long)slot * x.nranks + src) * x.max_chains + x.chain0 + chain; }
+PPCX_HD long xchg_abort_index(const XchgArgs& x, int src) { return 2L * x.nranks * x.max_chains + src; }
+PPCX_HD size_t xchg_recv_doubles(int nranks, int max_chains) { return (size_t)2 * nranks * max_chains * PT_COUNT; }
+PPCX_HD size_t xchg_flag_words(int nranks, int max_chains) { return (size_t)2 * nranks * max_chains + nranks; }
+
 enum StepPhase : int { STEP_REDUCE = 1, STEP_ADVANCE = 2 };
 struct StepArgs {
   Dims d;
@@ -66,6 +87,7 @@ struct StepArgs {
   // the per-coordinate work of the new command in the same launch (null upd_vecs: a separate ppcx_update_kernel does
   // it): grid.x workgroups per chain, each runs the step redundantly and updates its share of the coordinates
   double* upd_vecs; long upd_Dpad; double* upd_t0_out; const double* upd_logtab;
+  XchgArgs x;                   // nranks > 1: the sums are exchanged with the other ranks' state machines (pipelined rounds)
 };
 
 constexpr int kMaxShards = 16;
@@ -126,5 +148,6 @@ hipError_t launch_advi_elbo_kernel(const AdviElboArgs& a, hipStream_t st);
 hipError_t launch_ppc_kernel(const PpcArgs& a, int nblocks, hipStream_t st);
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st);
 hipError_t launch_fill_kernel(double* p, long n, double val, hipStream_t st);
+hipError_t launch_xchg_abort_kernel(const XchgArgs& x, hipStream_t st);      // tells every peer that this rank has left the fit
 
 }  // namespace ppcx

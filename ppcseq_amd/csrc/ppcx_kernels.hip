@@ -123,7 +123,7 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
   if (evenS) { if (tid < S / 2) f_e = reinterpret_cast<const dpair_t*>(a.sampleE)[tid]; }
   else if (tid < S) f_e.x = a.sampleE[tid];
   double f_x = 0.0;
-  if (!GEN && any_generic && tid < S) f_x = a.X[S + tid];      // the two-group path reads the group column only
+  if (!GEN && any_generic && tid < S) f_x = a.X[S + tid];      // the two-group path reads the group column only (C > 2: below)
   const int chain = a.active ? a.active[col] : col;
   const Cmd& c = a.cmds[chain];
   if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
@@ -156,6 +156,7 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
     } else {
       if (tid < S) sX[S + tid] = f_x;
       for (int i = tid + 256; i < S; i += 256) sX[S + i] = a.X[S + i];
+      for (int i = 2 * S + tid; i < S * C; i += 256) sX[i] = a.X[i];      // further indicator columns (factor designs)
     }
   }
   __syncthreads();
@@ -492,7 +493,54 @@ struct StepShared {
   Cmd ex, nc;
   ChainState st;
   Reduced rd;
+  int x_ok[kMaxRanks]; long long x_wait;       // direct exchange: has rank k's contribution arrived; ticks waited
 };
+// system-scope accesses to the peer-mapped exchange buffers (uncached memory: nothing may be served from a cache line that a
+// peer has rewritten since)
+__device__ __forceinline__ void sys_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned long long sys_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// Adds the ranks' partial sums in red[0 .. PT_COUNT) (LDS), in rank order on every rank -- identical bits everywhere, so the
+// replicated state machines take identical decisions. Called by all 256 threads of a chain's state-machine workgroup, red
+// complete and visible. Two slots by the parity of the sequence number: a rank can be one exchange ahead of a peer (it has
+// published exchange n + 1 while the peer still reads exchange n), never two, because exchange n + 2 needs the peer's n + 1.
+// Returns false when a peer has aborted or does not arrive within the timeout.
+__device__ __forceinline__ bool xchg_sums(const XchgArgs& x, int chain, unsigned count, StepShared& s) {
+  const int tid = threadIdx.x;
+  const unsigned long long seq = ((unsigned long long)x.epoch << 32) | (unsigned long long)count;
+  const int slot = (int)(count & 1u);
+  if (tid < PT_COUNT) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(s.red[tid]);
+    for (int k = 0; k < x.nranks; ++k)
+      sys_store(reinterpret_cast<unsigned long long*>(x.recv[k] + xchg_recv_index(x, slot, x.rank, chain)) + tid, bits);
+  }
+  __threadfence_system();                      // the sums are in the peers' memory before the sequence number is
+  __syncthreads();
+  if (tid < x.nranks) {
+    __hip_atomic_store(x.flags[tid] + xchg_flag_index(x, slot, x.rank, chain), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long* mine = x.flags[x.rank];
+    const long long t0 = (long long)wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(mine + xchg_flag_index(x, slot, tid, chain), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      bool gone = (long long)wall_clock64() - t0 > x.timeout_ticks;
+      for (int k = 0; k < x.nranks && !gone; ++k) gone = (unsigned)sys_load(mine + xchg_abort_index(x, k)) == x.epoch;
+      if (gone) { ok = 0; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    s.x_ok[tid] = ok;
+    if (tid == 0) s.x_wait = (long long)wall_clock64() - t0;
+  }
+  __syncthreads();
+  bool ok = true;
+  for (int k = 0; k < x.nranks; ++k) ok = ok && s.x_ok[k] != 0;
+  if (ok && tid < PT_COUNT) {
+    double t = 0.0;
+    for (int k = 0; k < x.nranks; ++k)
+      t += __longlong_as_double((long long)sys_load(reinterpret_cast<const unsigned long long*>(x.recv[x.rank] + xchg_recv_index(x, slot, k, chain)) + tid));
+    s.red[tid] = t;
+  }
+  __syncthreads();
+  return ok;
+}
 __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain, StepShared& s, bool spec) {
   constexpr int NST = (int)(sizeof(ChainState) / sizeof(int)), NCMD = (int)(sizeof(Cmd) / sizeof(int)), NHV = V_COUNT * 8;
   static_assert(NST <= 4 * 256 && NCMD <= 256 && NHV <= 3 * 256 && PT_COUNT <= 96, "step role staging sizes");
@@ -551,8 +599,21 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
     for (int k = 0; k < 3; ++k) if (tid + 256 * k < NHV) s.hv[tid + 256 * k] = r_hv[k];
   }
   __syncthreads();
+  // gene shards, one per rank: the other ranks' sums. Every rank's copy of this chain reaches this point the same number of times.
+  bool x_ok = true;
+  const bool x_on = a.x.nranks > 1;
+  if (x_on) x_ok = xchg_sums(a.x, chain, s.st.sc.xcount + 1u, s);
   if (tid < 8) {
     ChainScalars st = s.st.sc;
+    if (x_on) { st.xcount += 1u; st.xticks += s.x_wait; }
+    if (!x_ok) {                               // a peer has left the fit or did not arrive: this chain ends with an error
+      if (tid == 0) {
+        st.error = 4; st.phase = PH_DONE;
+        s.st.sc = st;
+        s.nc = s.ex; s.nc.type = CMD_DONE;
+        a.done[chain] = 1 + st.error;
+      }
+    } else {
     ChainIO io;
     io.draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
     io.out.lp = a.out_lp ? a.out_lp + (long)chain * a.n_keep : nullptr;
@@ -567,6 +628,7 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
       s.st.sc = st;
       s.nc = nc;
       if (st.phase == PH_DONE) a.done[chain] = 1 + st.error;
+    }
     }
   }
   __syncthreads();
@@ -1011,6 +1073,13 @@ __global__ void ppcx_gather_kernel(const double* draws, long n_rows, int D, cons
   out[i] = draws[r * D + cols[cidx]];
 }
 
+// a rank that leaves a gene-sharded fit early (a local failure) says so to every peer: their state machines stop waiting for it
+__global__ void ppcx_xchg_abort_kernel(XchgArgs x) {
+  const int k = threadIdx.x;
+  if (k < x.nranks) sys_store(x.flags[k] + xchg_abort_index(x, x.rank), (unsigned long long)x.epoch);
+  __threadfence_system();
+}
+
 __global__ void ppcx_fill_kernel(double* p, long n, double val) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = val;
@@ -1119,6 +1188,10 @@ hipError_t launch_ppc_kernel(const PpcArgs& a, int nblocks, hipStream_t st) {
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st) {
   const long n = n_rows * n_cols;
   hipLaunchKernelGGL(ppcx_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, draws, n_rows, D, cols, n_cols, out);
+  return hipGetLastError();
+}
+hipError_t launch_xchg_abort_kernel(const XchgArgs& x, hipStream_t st) {
+  hipLaunchKernelGGL(ppcx_xchg_abort_kernel, dim3(1), dim3(64), 0, st, x);
   return hipGetLastError();
 }
 hipError_t launch_fill_kernel(double* p, long n, double val, hipStream_t st) {

@@ -37,8 +37,9 @@ struct Dims {
   int G, S, C, K, D;
   int off_intercept, off_alpha1, off_alpha2, off_sigma_raw, off_tail;  // Stan declaration order (.stan:183-197)
   int x0_is_one;                // X[,1] == 1 (model.matrix intercept column, R/utilities.R:887-900)
-  int x1_binary;                // C == 2 and X[,2] in {0, 1} (a two-group design, `~ Label`): e^t of a gene with a slope is
-                                // E_s A_g or E_s A1_g by the sample's group -- no per-cell exp for the checked genes either
+  int x1_binary;                // C >= 2 and every slope column of X in {0, 1} (model.matrix of factors: `~ Label`, a multi-level
+                                // factor, `~ a + b`): e^t of a gene with slopes is E_s A_g times exp(slope_c) of the sample's
+                                // columns -- no per-cell exp for the checked genes either (C == 2: A_g or A1_g by the group)
   int Gt, Kt, g0, k0;           // gene shard: totals of the whole problem and this shard's first gene / checked gene
   double lambda_mu_mu;
 };

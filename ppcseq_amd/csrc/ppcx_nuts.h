@@ -291,6 +291,9 @@ struct ChainScalars {
   int win_next, win_size, win_counter, wn;
   double lp_eval;                // CMD_EVAL result
   long long total_leapfrogs;
+  // gene shards with the direct exchange (ppcx_kernels.hip xchg_sums): exchanges this chain has taken part in -- the sequence
+  // number its ranks stamp their contributions with -- and the wall-clock ticks (100 MHz) its state machine has waited for peers
+  unsigned xcount; unsigned pad_; long long xticks;
 };
 
 // per-level log weights / potentials of the parked left subtrees (indexed at run time: kept in LDS)
@@ -332,7 +335,7 @@ PPCX_HD void state_init(ChainState& cs, const NutsConfig& cfg, int local_chain, 
   st.H0 = 0; st.lsw_tree = 0; st.sum_metro = 0; st.V_sample = 0; st.T0h = 0; st.T0g = 0; st.T0g_held = 0;
   st.mu = 0; st.s_bar = 0; st.x_bar = 0; st.da_counter = 0;
   st.win_next = st.init_buffer + st.window - 1; st.win_size = st.window; st.win_counter = 0; st.wn = 0;
-  st.lp_eval = 0; st.total_leapfrogs = 0;
+  st.lp_eval = 0; st.total_leapfrogs = 0; st.xcount = 0; st.pad_ = 0; st.xticks = 0;
   for (int d = 0; d <= kLev; ++d) { cs.ta.Llsw[d] = 0; cs.ta.LV[d] = 0; }
 }
 
@@ -357,13 +360,12 @@ PPCX_HD bool cmd_evaluates(const Cmd& c) { return c.type == CMD_EVAL || c.type =
 // ----- helpers that fill in the next command ---------------------------------------------------------
 PPCX_HD void issue_eps_try(ChainScalars& st, Cmd& nc) {
   nc.type = CMD_EPS_TRY; nc.pre_flags |= PRE_EPS_TRY; nc.dir = 1; nc.eps = st.eps;
-  // Opaque on purpose. Without it hipcc (ROCm 7.2, -O3) emits 0 here on the halving / doubling path of PH_EPS in
-  // ppcx_step_kernel (not in the other kernels built from this header, nor on the host): every trial after the second then
-  // drew the momenta of trial 0. Found in round 3 by running the two round structures side by side
-  // (tests/test_gpu_parity.py::test_round_structures_agree_with_the_oracle).
-  unsigned attempt = (unsigned)st.eps_attempt;
-  PPCX_OPAQUE(attempt);
-  nc.rng_c1 = (unsigned)st.eps_call; nc.rng_c3 = attempt;
+  // (Round 3 had an opaque asm barrier on st.eps_attempt here: hipcc ROCm 7.2 emitted 0 for rng_c3 on the halving / doubling
+  // path of PH_EPS in ppcx_step_kernel. Round 4 traced it: the optimised LLVM IR is correct, the AMDGPU backend drops the
+  // copy on one of the two predecessor paths after AMDGPUCodeGenPrepare has broken the SLP-made <2 x i32> phi of
+  // (rng_c1, rng_c3) into scalars; the library is built with that transform off -- ppcseq_amd/build.py, DESIGN.md section 3,
+  // profiles/r04_miscompile/.)
+  nc.rng_c1 = (unsigned)st.eps_call; nc.rng_c3 = (unsigned)st.eps_attempt;
   st.eps_attempt++;
   st.phase = PH_EPS;
 }

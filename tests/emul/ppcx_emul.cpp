@@ -28,8 +28,8 @@ static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, c
   int x0 = 1;
   for (int s = 0; s < S; ++s) { m.E[s] = exp(expo[s]); if (X[s] != 1.0) x0 = 0; }
   m.d.x0_is_one = x0;
-  int x1b = (C == 2);
-  for (int s = 0; s < S && x1b; ++s) if (X[(size_t)S + s] != 0.0 && X[(size_t)S + s] != 1.0) x1b = 0;
+  int x1b = (C >= 2);
+  for (size_t i = (size_t)S; i < (size_t)S * C && x1b; ++i) if (X[i] != 0.0 && X[i] != 1.0) x1b = 0;
   m.d.x1_binary = x1b;
   m.Sy.assign(G, 0); m.SyE.assign(G, 0); m.SyX.assign((size_t)C * G, 0); m.SX.assign((size_t)C * G, 0); m.ncell.assign(G, 0); m.Lg1.assign(G, 0);
   m.low_start.assign(G + 1, 0); m.nhi.assign(G, 0); m.low_m.assign((size_t)G * 8, 0);

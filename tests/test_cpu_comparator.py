@@ -32,3 +32,18 @@ def test_optimised_comparator_agrees_with_the_port(G, S, K, seed):
                 assert np.max(np.abs(g_f - g_o) / (1 + np.abs(g_o))) <= 1e-10, (k, threads)
     finally:
         F.free(mf)
+
+
+def test_whole_cpu_fit_on_the_comparator_follows_the_port():
+    """bench.py --cpu-full-cfg2 times a WHOLE CPU fit: the oracle's NUTS driver on the comparator's gradient, one host
+    thread per chain (CpuFast.nuts). With gradients that agree to 1e-12 it must take the port's decisions for the first
+    iterations (tree sizes, step sizes) before rounding separates the two, whatever the threads per chain."""
+    d = ind.synth(40, 12, K=5, seed=3)
+    O, F = Oracle(), CpuFast()
+    cfg = O.cfg(chains=3, iter=30, warmup=20, seed=4)
+    ref = O.nuts_model(O.model(d["counts"], d["X"], d["exposure"], 5), cfg)
+    for threads in (1, 2):
+        r = F.nuts(O, d["counts"], d["X"], d["exposure"], 5, cfg, threads_per_chain=threads)
+        assert np.array_equal(r.n_leapfrog[:, :8], ref.n_leapfrog[:, :8]), threads
+        assert np.allclose(r.stepsize[:, :8], ref.stepsize[:, :8], rtol=1e-8, atol=0)
+        assert (r.iters_done == 30).all() and np.isfinite(r.draws).all()

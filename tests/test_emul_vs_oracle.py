@@ -27,6 +27,26 @@ def test_density_and_gradient(oracle, emul, G, S, C, K, seed):
     assert np.max(np.abs(g - g2) / (1 + np.abs(g))) < 1e-10
 
 
+@pytest.mark.parametrize("levels,G,S,K,seed", [((3,), 30, 14, 6, 1), ((2, 2), 24, 11, 24, 2), ((4,), 18, 9, 5, 3), ((3, 2), 20, 13, 7, 4)])
+def test_factor_designs_take_the_factorised_cells(oracle, emul, levels, G, S, K, seed):
+    """Designs whose slope columns are all 0 / 1 indicators -- a multi-level factor, `~ a + b` of factors (model.matrix,
+    R/utilities.R:887-900) -- with C = 3, 3 and 4, 4: e^t = E_s A_g prod exp(slope_c), no exp per cell (ppcx_gene.h
+    indicator_cells). Low counts and excluded cells included."""
+    d = ind.synth_factor(G, S, K, levels, seed)
+    counts = d["counts"].copy()
+    counts[1, :] //= 50; counts[2, ::2] = 0                              # list cells (y <= 7) in genes with slopes
+    C = d["X"].shape[1]
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(-1, 1, oracle.dim(G, C, K))
+    u[3:3 + G] += 5
+    excl = np.array(sorted({1, S + 2, 2 * S, (G - 1) * S + 1}), dtype=np.int32) if seed % 2 == 0 else None
+    m = oracle.model(counts, d["X"], d["exposure"], K, excl=excl)
+    lp, g = oracle.log_prob_grad(m, u)
+    lp2, g2 = emul_lp(emul, counts, d["X"], d["exposure"], K, u, excl)
+    assert abs(lp2 - lp) <= 1e-11 * max(1.0, abs(lp))
+    assert np.max(np.abs(g - g2) / (1 + np.abs(g))) < 1e-10
+
+
 def _low_count_case(seed):
     """Counts 0..40 around the regime boundaries of the cell loop (y + phi < 8: exact recurrences; < 32: 7-term tails;
     else 4-term) with phi from 0.01 to 100, some rows all zero, some cells excluded."""

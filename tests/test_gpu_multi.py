@@ -267,3 +267,143 @@ def test_collectives_over_rccl_with_one_rank():
     p.join(120)
     assert status == "ok" and p.exitcode == 0, status
     assert np.array_equal(lower, one.lower) and np.array_equal(upper, one.upper) and np.array_equal(flags, one.deleterious_outliers)
+
+
+# ---- gene shards with the DIRECT exchange (include/ppcx.h ppcx_xchg_*): the ranks' state machines add their partial sums
+# ---- themselves through peer-mapped buffers, inside the merged launch of a pipelined round ------------------------------
+XG, XK, XS = 80, 6, 10
+XKW = dict(chains=2, iter=40, warmup=25, seed=6)
+
+
+def _xchg_reference():
+    """The unsharded fit and the in-process shards over the three-launch round, for the decisions of the first iterations."""
+    from ppcseq_amd import _lib as L
+    d = ind.synth(XG, XS, K=XK, seed=4)
+    whole = L.Model(d["counts"], d["X"], d["exposure"], XK)
+    shards = [L.Model(d["counts"][g0:g1], d["X"], d["exposure"], 0, shard=(XG, XK, g0, g1)) for g0, g1 in ((0, 40), (40, 80))]
+    try:
+        fw = whole.fit_nuts(**XKW)
+        nl_w, ss_w, hy_w = fw.diagnostics()["n_leapfrog"].copy(), fw.diagnostics()["stepsize"].copy(), fw.draws()[..., :3].copy()
+        fw.close()
+        fits = L.fit_nuts_shards(shards, **XKW)
+        nl_s = fits[0].diagnostics()["n_leapfrog"].copy()
+        for f in fits:
+            f.close()
+    finally:
+        for m in shards + [whole]:
+            m.close()
+    return d, nl_w, ss_w, hy_w, nl_s
+
+
+def _check_ranks(res, nl_w, ss_w, hy_w, nl_s):
+    (nl0, ss0, dr0), (nl1, ss1, dr1) = res
+    assert np.array_equal(nl0, nl1) and np.array_equal(ss0, ss1)                 # replicated state machines: identical decisions
+    assert np.array_equal(dr0[..., :3], dr1[..., :3]) and np.array_equal(dr0[..., -3:], dr1[..., -3:])   # hyper draws, bit for bit
+    assert np.array_equal(nl0[:, :12], nl_w[:, :12]) and np.array_equal(nl0[:, :12], nl_s[:, :12])       # = unsharded = three-launch shards
+    assert np.max(np.abs(ss0[:, :12] - ss_w[:, :12])) < 1e-9
+    assert np.max(np.abs(dr0[:, :3, :3] - hy_w[:, :3])) < 1e-6
+
+
+def test_direct_exchange_between_two_ranks_in_one_process():
+    """Two shard models, two host threads, one exchange group wired with plain device pointers (ppcx_xchg_connect_local)."""
+    import threading
+    from ppcseq_amd import _lib as L
+    d, nl_w, ss_w, hy_w, nl_s = _xchg_reference()
+    shards = [L.Model(d["counts"][g0:g1], d["X"], d["exposure"], 0, shard=(XG, XK, g0, g1)) for g0, g1 in ((0, 40), (40, 80))]
+    xs = L.Xchg.local_group(2, XKW["chains"])
+    res, err = [None, None], [None, None]
+
+    def run(k):
+        try:
+            xs[k].set_timeout(30)
+            f = shards[k].fit_nuts_xchg(xs[k], **XKW)
+            dg = f.diagnostics()
+            res[k] = (dg["n_leapfrog"], dg["stepsize"], f.draws())
+            err[k] = f.xchg_timing()
+            f.close()
+        except Exception as e:                   # noqa: BLE001
+            err[k] = e
+    try:
+        th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert all(r is not None for r in res), err
+        _check_ranks(res, nl_w, ss_w, hy_w, nl_s)
+        assert err[0][1] > 0 and err[0][1] == err[1][1]                          # both ranks took part in the same exchanges
+    finally:
+        for x in xs:
+            x.close()
+        for m in shards:
+            m.close()
+
+
+def _xchg_worker(rank, conn, q, hooks):
+    """One rank = one process, both on device 0; the 64-byte IPC handles travel over a pipe."""
+    from ppcseq_amd import _lib as L
+    try:
+        if hooks:
+            from ppcseq_amd import build
+            L.use_library(build.build_testing())
+            for k, v in hooks.items():
+                L.testing_set(k, v)
+        d = ind.synth(XG, XS, K=XK, seed=4)
+        g0, g1 = XG * rank // 2, XG * (rank + 1) // 2
+        m = L.Model(d["counts"][g0:g1], d["X"], d["exposure"], 0, device=0, shard=(XG, XK, g0, g1))
+        x = L.Xchg(2, rank, XKW["chains"], device=0)
+        x.set_timeout(30)
+        mine = x.handle()
+        conn.send(mine)
+        theirs = conn.recv()
+        x.connect([mine, theirs] if rank == 0 else [theirs, mine])
+        conn.send(b"connected"); conn.recv()          # nobody publishes before both have mapped the other's buffer
+        try:
+            kw = dict(XKW, iter=200, warmup=100) if hooks else XKW
+            f = m.fit_nuts_xchg(x, **kw)
+            dg = f.diagnostics()
+            q.put((rank, "ok", (dg["n_leapfrog"], dg["stepsize"], f.draws()), f.xchg_timing()))
+            f.close()
+        except L.PpcxError as e:
+            q.put((rank, "error", str(e), None))
+        m.close(); x.close()
+    except Exception as e:                       # noqa: BLE001
+        q.put((rank, "crash", repr(e), None))
+
+
+def _run_xchg_ranks(hooks=None):
+    if hooks:
+        from ppcseq_amd import build
+        build.build_testing()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    a, b = ctx.Pipe()
+    procs = [ctx.Process(target=_xchg_worker, args=(r, (a, b)[r], q, hooks)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_direct_exchange_between_two_processes_over_ipc_handles():
+    """ppcx_fit_nuts_xchg with one rank per PROCESS (the reference's map_rect over gene shards, .stan:226-240, one shard per
+    GPU): the receive buffers are mapped through hipIpc handles -- which also works between two processes on ONE device, so
+    the real exchange path runs on a one-GPU box. Same decisions and hyper draws on both ranks, those of the unsharded fit."""
+    d, nl_w, ss_w, hy_w, nl_s = _xchg_reference()
+    res = _run_xchg_ranks()
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    _check_ranks([r[2] for r in res], nl_w, ss_w, hy_w, nl_s)
+    assert res[0][3][1] > 0 and res[0][3][1] == res[1][3][1]
+
+
+@pytest.mark.parametrize("failing_rank", [0, 1])
+def test_a_rank_that_fails_takes_its_peer_out_of_the_direct_exchange(failing_rank):
+    """Fault injection (testing build): one rank fails after round 64. It tells its peer (abort word in the peer's buffer);
+    the peer's state machines stop waiting and its fit ends with PPCX_ERR_STALL -- neither rank hangs."""
+    res = _run_xchg_ranks({"fail_at_round": 64, "fail_rank": failing_rank})
+    assert [r[1] for r in res] == ["error", "error"], res
+    assert "injected failure" in res[failing_rank][2]
+    assert "ppcx error -5" in res[1 - failing_rank][2] and "peer rank left" in res[1 - failing_rank][2], res

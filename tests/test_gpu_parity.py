@@ -90,6 +90,51 @@ def test_continuous_covariate_and_two_group_designs(L, oracle):
         assert np.max(np.abs(res[0] - res[1]) / np.abs(res[0])) < 1e-13
 
 
+@pytest.mark.parametrize("levels,G,S,K,seed", [((3,), 70, 19, 9, 1), ((2, 2), 40, 21, 40, 2), ((4,), 33, 200, 6, 3), ((3, 2), 300, 50, 15, 4)])
+def test_factor_designs_factorise_and_pipeline(L, oracle, levels, G, S, K, seed):
+    """Designs beyond two groups whose slope columns are all indicators -- model.matrix of a multi-level factor or of
+    `~ a + b` (R/utilities.R:887-900): C = 3 and 4. The checked genes' cells use E_s A_g prod exp(slope_c) (no exp per cell:
+    ppcx_gene.h indicator_cells), the model runs pipelined rounds, and both round structures follow the oracle's sampler."""
+    d = ind.synth_factor(G, S, K, levels, seed)
+    counts = d["counts"].copy()
+    counts[1, :] //= 50; counts[2, ::2] = 0
+    C = d["X"].shape[1]
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(-1, 1, (2, oracle.dim(G, C, K)))
+    u[:, 3:3 + G] += 5
+    excl = np.array(sorted({1, S + 2, 2 * S, (G - 1) * S + 1}), dtype=np.int32) if seed % 2 == 0 else None
+    mo = oracle.model(counts, d["X"], d["exposure"], K, excl=excl)
+    ref = [oracle.log_prob_grad(mo, u[i]) for i in range(2)]
+    m = L.Model(counts, d["X"], d["exposure"], K, excl=excl)
+    try:
+        assert m.get_rounds(3)[0] is True                                 # pipelined
+        for lanes in (0, 4, 64):
+            m.set_launch(lanes, 0)
+            lp, g = m.log_prob_grad(u)
+            for i in range(2):
+                assert abs(lp[i] - ref[i][0]) <= 1e-11 * abs(ref[i][0]), (lanes, i)
+                assert np.max(np.abs(g[i] - ref[i][1]) / (1 + np.abs(ref[i][1]))) < 1e-10, (lanes, i)
+        if G <= 70:
+            m.set_launch(0, 0)
+            r = oracle.nuts_model(mo, oracle.cfg(chains=2, iter=14, warmup=10, seed=5))
+            for pipe in (-1, 0):
+                m.set_rounds(pipelined=pipe)
+                f = m.fit_nuts(chains=2, iter=14, warmup=10, seed=5)
+                dg = f.diagnostics()
+                f.close()
+                assert np.array_equal(dg["n_leapfrog"][:, :6], r.n_leapfrog[:, :6]), pipe
+                assert np.allclose(dg["stepsize"][:, :6], r.stepsize[:, :6], rtol=1e-9, atol=0), pipe
+    finally:
+        m.close()
+    Xc = d["X"].copy()
+    Xc[:, -1] = np.linspace(-1, 1, S)                                      # a continuous covariate: per-cell exp, three launches
+    m = L.Model(counts, Xc, d["exposure"], K)
+    try:
+        assert m.get_rounds(3)[0] is False
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_low_counts_across_the_lgamma_regimes(L, oracle, seed):
     """Counts around the regime boundaries of the cell loop (y + phi < 8 / < 32 / >= 32), phi from 0.01 to 100,
@@ -395,13 +440,8 @@ def test_full_size_properties_20k_by_200(L):
         m.close()
 
 
-def test_reference_readme_example(L, bundled):
-    """Second known answer held by the reference: README.md:50-92 -- genes with FDR < 0.01 (15 genes) checked
-    against 500 negative controls, `~ Label`, percent_false_positive_genes = 5: only CYP1A1 and LYZ have one
-    failed sample, which is a deleterious outlier (README shows the reference's default VB path; the NUTS path
-    must reach the same calls)."""
+def _readme_frame(bundled):
     import pandas as pd
-    from ppcseq_amd.methods import identify_outliers
     genes = [str(g) for g in bundled["genes"]]
     samples = [str(s) for s in bundled["samples"]]
     G, S = len(genes), len(samples)
@@ -410,26 +450,51 @@ def test_reference_readme_example(L, bundled):
         "PValue": np.repeat(bundled["PValue"], S), "FDR": np.repeat(bundled["FDR"], S),
         "Label": np.tile(bundled["Label"].astype(str), G)})
     df["is_significant"] = df["FDR"] < 0.01
-    res = identify_outliers(df, formula="~ Label", sample="sample", transcript="symbol", abundance="value",
-                            significance="PValue", do_check="is_significant", percent_false_positive_genes=5,
-                            cores=4, seed=7, approximate_posterior_inference=False, approximate_posterior_analysis=False)
+    return df
+
+
+def _check_readme_result(res):
+    """README.md:75-92: 15 checked genes; CYP1A1 and LYZ carry exactly one failed sample each, a deleterious outlier, on the
+    samples of the reference's figure. Any other call must be a single borderline cell (just outside its interval): at
+    percent_false_positive_genes = 5 the reference's own thresholds allow 0.05 x 15 = 0.75 false-positive genes per run, its VB
+    fit is unseeded (R/utilities.R:261), and the README shows one draw of that. Measured here over 12 seeds
+    (profiles/r04_readme_case_rates.json): CYP1A1 and LYZ exactly as in the README in 12 of 12 runs in
+    both modes; other calls 0.83 per run in the README's mode (MMP8 5 x, CCNA1 5 x), 1.42 per run through NUTS (MMP8 11 x,
+    CCNA1 6 x), never more than two in a run."""
     assert len(res) == 15
-    flagged = res[res["tot_deleterious_outliers"] > 0]["symbol"].tolist()
     by = res.set_index("symbol")
-    # the two robust calls of the README, on the samples the reference's figure shows
-    assert {"CYP1A1", "LYZ"} <= set(flagged)
     for g, smp in [("CYP1A1", "11165PP"), ("LYZ", "11164PP")]:
         sw = by.loc[g, "sample_wise_data"]
         assert sw[sw["deleterious_outliers"]]["sample"].tolist() == [smp]
-        assert by.loc[g, "ppc_samples_failed"] == 1
-    # pfp = 5 % tolerates false-positive genes and the 0.24 % tail quantile rests on ~5 of 2100 draws, so other
-    # calls may appear, but only borderline ones (count within 2x of the interval end), and few
-    extras = [g for g in flagged if g not in ("CYP1A1", "LYZ")]
-    assert len(extras) <= 3
+        assert by.loc[g, "ppc_samples_failed"] == 1 and by.loc[g, "tot_deleterious_outliers"] == 1
+    extras = [g for g in res[res["tot_deleterious_outliers"] > 0]["symbol"].tolist() if g not in ("CYP1A1", "LYZ")]
+    assert len(extras) <= 2 and set(extras) <= {"MMP8", "CCNA1", "SUSD4"}, extras
     for g in extras:
         sw = by.loc[g, "sample_wise_data"]
         bad = sw[sw["deleterious_outliers"]]
-        assert len(bad) == 1 and float(bad["value"].iloc[0]) < 2.0 * float(bad[".upper"].iloc[0]) + 10
+        assert len(bad) == 1
+        y, lo, up = float(bad["value"].iloc[0]), float(bad[".lower"].iloc[0]), float(bad[".upper"].iloc[0])
+        assert (y > up and y < 2 * up) or (y < lo and 2 * y + 1 >= lo), (g, y, lo, up)
+    return extras
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_reference_readme_example_in_the_readme_mode(L, bundled, seed):
+    """README.md:50-92 AS WRITTEN: identify_outliers with its defaults -- ADVI inference and the approximated posterior
+    analysis (R/methods.R:85-86) -- percent_false_positive_genes = 5, the default 500 negative controls."""
+    from ppcseq_amd.methods import identify_outliers
+    res = identify_outliers(_readme_frame(bundled), formula="~ Label", sample="sample", transcript="symbol", abundance="value",
+                            significance="PValue", do_check="is_significant", percent_false_positive_genes=5, cores=4, seed=seed)
+    _check_readme_result(res)
+
+
+def test_reference_readme_example(L, bundled):
+    """The same known answer through NUTS with the full posterior analysis (this engine's headline path)."""
+    from ppcseq_amd.methods import identify_outliers
+    res = identify_outliers(_readme_frame(bundled), formula="~ Label", sample="sample", transcript="symbol", abundance="value",
+                            significance="PValue", do_check="is_significant", percent_false_positive_genes=5,
+                            cores=4, seed=7, approximate_posterior_inference=False, approximate_posterior_analysis=False)
+    _check_readme_result(res)
 
 
 def _shard_models(L, d, K, bounds):
