@@ -652,7 +652,8 @@ PPCO_EXPORT int ppco_nuts_gauss(int D, const double* mean, const double* sd, con
 
 /* ----------------------------------------------------------------------------------- */
 /* generated quantities: neg_binomial_2_log_rng (.stan:259-266), gamma-Poisson mixture  */
-/* Stream addressing: key = (seed32, 0x50504331), counter = (blk, cell, draw, 4)        */
+/* Stream addressing: key = (seed32, 0x50504331), counter = (blk, cell, draw, 4) for the  */
+/* gamma variate and (blk, cell, draw, 8) for the Poisson variate                        */
 /* ----------------------------------------------------------------------------------- */
 static double gamma_rng(double a, ppco_stream* st) {     /* Marsaglia-Tsang 2000, unit scale */
   double boost = 1.0;
@@ -693,7 +694,8 @@ PPCO_EXPORT int32_t ppco_nb2_log_rng(double eta, double phi, uint64_t seed, uint
   ppco_stream st; ppco_stream_init(&st, seed32(seed), 0x50504331u, cell, draw, 4u);
   double lam = gamma_rng(phi, &st) * (exp(eta) / phi);
   if (!(lam < 1073741824.0)) return 1073741823;          /* Stan errors above 2^30; we saturate */
-  int64_t k = poisson_rng(lam, &st);
+  ppco_stream sp; ppco_stream_init(&sp, seed32(seed), 0x50504331u, cell, draw, 8u);
+  int64_t k = poisson_rng(lam, &sp);
   return k > 2147483647LL ? 2147483647 : (int32_t)k;
 }
 

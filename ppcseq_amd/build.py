@@ -16,12 +16,14 @@ HEADERS = ["ppcx_math.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h", "ppcx_ke
            os.path.join("..", "..", "include", "ppcx.h")]
 
 
-# hipcc (ROCm 7.2, LLVM 20) miscompiles the scalar state machine of ppcx_step_kernel when AMDGPUCodeGenPrepare breaks the
-# <2 x i32> phis that the SLP vectoriser makes of adjacent Cmd fields into scalar phis: the IR stays correct, the ISA loses
-# a copy on one predecessor path (Cmd::rng_c3 = 0 on the halving / doubling path of the step-size search). Traced in round 4
-# (profiles/r04_miscompile/): of 15 builds with single passes switched off only this flag and
-# -fno-slp-vectorize give correct code; neither changes a kernel's time.
-CODEGEN_FLAGS = ["-mllvm", "-amdgpu-codegenprepare-break-large-phis=false"]
+# hipcc (ROCm 7.2) miscompiles the scalar state machine of ppcx_step_kernel when the SLP vectoriser has made <2 x i32> phis of
+# adjacent Cmd fields and AMDGPUCodeGenPrepare breaks them up again: the IR stays correct, the ISA loses a copy on one
+# predecessor path (Cmd::rng_c3 = 0 on the halving / doubling path of the step-size search). Traced in round 4 (DESIGN.md
+# section 3, profiles/r04_miscompile/): of 15 builds with single passes switched off only -fno-slp-vectorize and
+# -mllvm -amdgpu-codegenprepare-break-large-phis=false give correct code. Neither changes a fit's time; the second costs
+# ppcx_step_kernel nine vector registers and with them its third workgroup per CU (169 instead of 160; 158 without SLP),
+# so the library is built without SLP vectorisation (scalar fp64 kernels: there is nothing for it to vectorise usefully).
+CODEGEN_FLAGS = ["-fno-slp-vectorize"]
 
 
 def _stale(lib: str) -> bool:

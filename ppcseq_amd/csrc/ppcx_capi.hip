@@ -125,7 +125,7 @@ static double pass_cost(const ppcx_model* m, int L, int p, int n) {
   const bool ignore_tiers = false;
 #endif
   const double tail = (slope || ignore_tiers) ? 1.0 : (tier >= 2 ? 0.86 : (tier >= 1 ? 0.91 : 1.0));
-  const double sweep = (double)((S + L - 1) / L) * tail * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? (m->d.C > 2 ? 1.5 : 1.15) : 1.0));
+  const double sweep = (double)((S + L - 1) / L) * tail * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? (m->d.C > 2 ? 2.0 : 1.15) : 1.0));
   return 5.8 + sweep + 0.75 * (double)((lowmax + L - 1) / L);
 }
 // reserve: workgroups of the same launch that are not log-likelihood workgroups (the state machines of a pipelined
@@ -1193,7 +1193,7 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
     if (hipMemcpy(states.data(), current_states(G->w), sizeof(ChainState) * G->n, hipMemcpyDeviceToHost) != hipSuccess) {
       G->rc = PPCX_ERR_HIP; G->err = "reading back the chain states failed"; return;
     }
-    for (int c = 0; c < G->n; ++c) { G->leap += states[c].sc.total_leapfrogs; G->xticks += states[c].sc.xticks; G->xcount += states[c].sc.xcount; }
+    for (int c = 0; c < G->n; ++c) { G->leap += states[c].sc.total_leapfrogs; G->xticks += states[c].xc.ticks; G->xcount += states[c].xc.count; }
   };
   {
     std::vector<std::thread> th;
@@ -1665,14 +1665,22 @@ extern "C" int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double 
   // 1024 workgroups share the cells and keep the current cell's draws in their slice of a global scratch buffer
   const int kLdsDraws = 39680;
   int nblocks = n_cells;
-  if (n_gen > kLdsDraws) {
+  const bool wave_kernel = n_gen <= ppc_wave_max_draws();      // one wavefront per cell (else one workgroup per cell)
+  double* d_T = nullptr;                                       // the checked genes' parameters, transposed: [K][C + 1][draws]
+  {
+    hipError_t e = hipMalloc(&d_T, sizeof(double) * (size_t)m->d.K * (m->d.C + 1) * (size_t)n_draws);
+    if (e != hipSuccess) { (void)hipFree(d_ci); return fail(PPCX_ERR_HIP, hipGetErrorString(e)); }
+  }
+  if (wave_kernel) {
+    nblocks = (n_cells + 3) / 4; if (nblocks > 4096) nblocks = 4096;
+  } else if (n_gen > kLdsDraws) {
     nblocks = n_cells < 1024 ? n_cells : 1024;
     hipError_t e = hipMalloc(&d_scratch, sizeof(int) * (size_t)nblocks * n_gen);
-    if (e != hipSuccess) { (void)hipFree(d_ci); return fail(PPCX_ERR_HIP, hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(d_ci); (void)hipFree(d_T); return fail(PPCX_ERR_HIP, hipGetErrorString(e)); }
   }
   if (counts_rng) {
     hipError_t e = hipMalloc(&d_rng, sizeof(int) * (size_t)n_gen * n_cells);
-    if (e != hipSuccess) { (void)hipFree(d_ci); (void)hipFree(d_scratch); return fail(PPCX_ERR_HIP, hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(d_ci); (void)hipFree(d_scratch); (void)hipFree(d_T); return fail(PPCX_ERR_HIP, hipGetErrorString(e)); }
   }
   PpcArgs pa;
   pa.d = m->d; pa.draws = f->d_draws; pa.n_draws = n_draws; pa.exposure = m->d_expo; pa.X = m->d_X;
@@ -1681,7 +1689,9 @@ extern "C" int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
   if (ev0) (void)hipEventRecord(ev0, m->stream);
-  hipError_t e = launch_ppc_kernel(pa, nblocks, m->stream);
+  hipError_t e = hipSuccess;
+  e = launch_ppc_table_kernel(f->d_draws, n_draws, m->d, truncation_compensation, d_T, m->stream);
+  if (e == hipSuccess) e = wave_kernel ? launch_ppc_wave_kernel(pa, d_T, nblocks, m->stream) : launch_ppc_kernel(pa, d_T, nblocks, m->stream);
   if (ev1) (void)hipEventRecord(ev1, m->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
   if (e == hipSuccess && ev0 && ev1) { float ms = 0; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { f->ppc_ms = ms; f->ppc_draws = (long long)n_gen * n_cells; } }
@@ -1689,7 +1699,7 @@ extern "C" int ppcx_fit_ppc(ppcx_fit* f, double truncation_compensation, double 
   if (ev1) (void)hipEventDestroy(ev1);
   if (e == hipSuccess) e = hipMemcpy(ci, d_ci, sizeof(double) * (size_t)n_cells * 4, hipMemcpyDeviceToHost);
   if (e == hipSuccess && counts_rng) e = hipMemcpy(counts_rng, d_rng, sizeof(int) * (size_t)n_gen * n_cells, hipMemcpyDeviceToHost);
-  (void)hipFree(d_ci); (void)hipFree(d_rng); (void)hipFree(d_scratch);
+  (void)hipFree(d_ci); (void)hipFree(d_rng); (void)hipFree(d_scratch); (void)hipFree(d_T);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, hipGetErrorString(e));
   return PPCX_OK;
 }

@@ -81,7 +81,8 @@ PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, Gene
 //   (2) the gene's low-count list (0 <= y <= 7; entries (y << 16) | s, built by the host in sample order): cell_eval_low;
 //   (3) the count part of the list cells, low_terms, term k by lane k (mod L).
 // Genes with slopes in a two-group design take the same route with e^t = E_s A or E_s A1 by the sample's group; with more
-// indicator columns (factor designs, C > 2) e^t = E_s A prod exp(slope_c) over the sample's columns (indicator_cells); any
+// indicator columns (factor designs, C > 2; model.matrix of a multi-level factor or of `~ a + b`, R/utilities.R:887-900)
+// e^t = E_s A prod exp(slope_c) over the sample's columns, from the per-coordinate constants exp(q) -- no exp per cell; any
 // other gene with slopes, and every gene when X[,1] != 1, forms eta per cell (generic_cells: an exp per cell).
 // `counts` must be readable 4 L entries past the end of the matrix, `sE` / `sX` (LDS) 4 L entries past S, `low` L past
 // its end: the host and the kernel pad them.
@@ -96,9 +97,12 @@ struct CellData {                // the chain-independent inputs of the log-like
   const unsigned short* low_m;   // [G][8] entry k < 7: number of list cells with count > k
 };
 
-template <int CM, int L, bool TWO, int TAIL = 4>
+// MODE 0: plain gene (e^t = E_s A); 1: two-group design (A or A1 by the sample's group, sX1 = the group column);
+// 2: more indicator columns (C > 2; sX1 = column 1 of X in LDS, column c at sX1 + (c - 1) S; ec[c] = exp(slope_c)):
+// A times the ec of the sample's columns
+template <int CM, int L, int MODE, int TAIL = 4>
 PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* sX1, int sub, double A, double A1,
-                         const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& acc) {
+                         const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& acc, const double* ec = nullptr, int C = 2) {
   const int nmin = S / L;                                  // cells every lane of the gene has
   const int nlane = nmin + (sub < S - nmin * L ? 1 : 0);
   const int* p = row + sub;
@@ -106,22 +110,29 @@ PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* 
   const double* qx = sX1 + sub;
   int y0 = p[0], y1 = p[L], y2 = p[2 * L], y3 = p[3 * L];
   int k = 0;
-#define PPCX_SWEEP_CELL(Y, E, XB, COND)                                                         \
+#define PPCX_SWEEP_CELL(Y, E, XB, OFF, COND)                                                    \
   if ((COND) && (TAIL < 4 || (Y) >= kLowCount)) {      /* tiers 1, 2: every cell of the gene is a row-sweep cell */ \
-    if (TWO) { const double rho_ = cell_eval<CM, TAIL>(Y, E, (XB) != 0.0 ? A1 : A, gp, tab, acc); \
-               acc.Tx[1] = fma(XB, rho_, acc.Tx[1]); }                                          \
+    if (MODE == 1) { const double rho_ = cell_eval<CM, TAIL>(Y, E, (XB) != 0.0 ? A1 : A, gp, tab, acc); \
+                     acc.Tx[1] = fma(XB, rho_, acc.Tx[1]); }                                    \
+    else if (MODE == 2) {                                                                       \
+      double a_ = (XB) != 0.0 ? A1 : A; double xk_[CM];                                         \
+      _Pragma("unroll") for (int cc = 2; cc < CM; ++cc) { xk_[cc] = cc < C ? qx[(cc - 1) * S + (OFF)] : 0.0; a_ = xk_[cc] != 0.0 ? a_ * ec[cc] : a_; } \
+      const double rho_ = cell_eval<CM, TAIL>(Y, E, a_, gp, tab, acc);                          \
+      acc.Tx[1] = fma(XB, rho_, acc.Tx[1]);                                                     \
+      _Pragma("unroll") for (int cc = 2; cc < CM; ++cc) acc.Tx[cc] = fma(xk_[cc], rho_, acc.Tx[cc]); \
+    }                                                                                           \
     else (void)cell_eval<CM, TAIL>(Y, E, A, gp, tab, acc);                                      \
   }
   for (; k + 4 <= nmin; k += 4) {
     const double e0 = q[0], e1 = q[L], e2 = q[2 * L], e3 = q[3 * L];
     double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
-    if (TWO) { x0 = qx[0]; x1 = qx[L]; x2 = qx[2 * L]; x3 = qx[3 * L]; }
+    if (MODE != 0) { x0 = qx[0]; x1 = qx[L]; x2 = qx[2 * L]; x3 = qx[3 * L]; }
     p += 4 * L; q += 4 * L; qx += 4 * L;
     const int n0 = p[0], n1 = p[L], n2 = p[2 * L], n3 = p[3 * L];
-    PPCX_SWEEP_CELL(y0, e0, x0, true)
-    PPCX_SWEEP_CELL(y1, e1, x1, true)
-    PPCX_SWEEP_CELL(y2, e2, x2, true)
-    PPCX_SWEEP_CELL(y3, e3, x3, true)
+    PPCX_SWEEP_CELL(y0, e0, x0, -4 * L, true)              // (MODE 2 reads its further columns behind the advanced pointer)
+    PPCX_SWEEP_CELL(y1, e1, x1, -3 * L, true)
+    PPCX_SWEEP_CELL(y2, e2, x2, -2 * L, true)
+    PPCX_SWEEP_CELL(y3, e3, x3, -L, true)
     PPCX_KEEP_BRANCH();
     acc.renorm();
     y0 = n0; y1 = n1; y2 = n2; y3 = n3;
@@ -129,29 +140,38 @@ PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* 
   if (k < nlane) {                                         // the last, partial trip
     const double e0 = q[0], e1 = q[L], e2 = q[2 * L], e3 = q[3 * L];
     double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
-    if (TWO) { x0 = qx[0]; x1 = qx[L]; x2 = qx[2 * L]; x3 = qx[3 * L]; }
-    PPCX_SWEEP_CELL(y0, e0, x0, true)
-    PPCX_SWEEP_CELL(y1, e1, x1, k + 1 < nlane)
-    PPCX_SWEEP_CELL(y2, e2, x2, k + 2 < nlane)
-    PPCX_SWEEP_CELL(y3, e3, x3, k + 3 < nlane)
+    if (MODE != 0) { x0 = qx[0]; x1 = qx[L]; x2 = qx[2 * L]; x3 = qx[3 * L]; }
+    PPCX_SWEEP_CELL(y0, e0, x0, 0, true)
+    PPCX_SWEEP_CELL(y1, e1, x1, L, k + 1 < nlane)
+    PPCX_SWEEP_CELL(y2, e2, x2, 2 * L, k + 2 < nlane)
+    PPCX_SWEEP_CELL(y3, e3, x3, 3 * L, k + 3 < nlane)
     acc.renorm();
   }
 #undef PPCX_SWEEP_CELL
 }
 
-template <int CM, int L, bool TWO>
+template <int CM, int L, int MODE>
 PPCX_HD void low_cells(const unsigned* low, int low_n, const double* sE, const double* sX1, int sub, double A, double A1,
-                       const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& acc) {
+                       const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& acc, const double* ec = nullptr, int C = 2, int S = 0) {
   unsigned en = low[sub];
   for (int i = sub; i < low_n; i += L) {
-    const unsigned ec = en;
+    const unsigned ec_ = en;
     en = low[i + L];
-    const int sl = (int)(ec & 0xffffu);
-    if (TWO) {
+    const int sl = (int)(ec_ & 0xffffu);
+    if (MODE == 1) {
       const double xb = sX1[sl];
-      const double rho = cell_eval_low<CM>((int)(ec >> 16), sE[sl], xb != 0.0 ? A1 : A, gp, tab, acc);
+      const double rho = cell_eval_low<CM>((int)(ec_ >> 16), sE[sl], xb != 0.0 ? A1 : A, gp, tab, acc);
       acc.Tx[1] = fma(xb, rho, acc.Tx[1]);
-    } else (void)cell_eval_low<CM>((int)(ec >> 16), sE[sl], A, gp, tab, acc);
+    } else if (MODE == 2) {
+      const double xb = sX1[sl];
+      double a_ = xb != 0.0 ? A1 : A; double xk_[CM];
+#pragma unroll
+      for (int cc = 2; cc < CM; ++cc) { xk_[cc] = cc < C ? sX1[(cc - 1) * S + sl] : 0.0; a_ = xk_[cc] != 0.0 ? a_ * ec[cc] : a_; }
+      const double rho = cell_eval_low<CM>((int)(ec_ >> 16), sE[sl], a_, gp, tab, acc);
+      acc.Tx[1] = fma(xb, rho, acc.Tx[1]);
+#pragma unroll
+      for (int cc = 2; cc < CM; ++cc) acc.Tx[cc] = fma(xk_[cc], rho, acc.Tx[cc]);
+    } else (void)cell_eval_low<CM>((int)(ec_ >> 16), sE[sl], A, gp, tab, acc);
   }
 }
 
@@ -176,30 +196,6 @@ PPCX_HD void generic_cells(const Dims& d, const Cmd& c, const VecRef& v, int g, 
       const double rho = y >= kLowCount ? cell_eval<CM>(y, u, 1.0, gp, tab, acc) : cell_eval_low<CM>(y, u, 1.0, gp, tab, acc);
 #pragma unroll
       for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.Tx[cc] = fma(sX[cc * S + s], rho, acc.Tx[cc]);
-    }
-    if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
-  }
-}
-
-// a gene with slopes in a design whose slope columns are all 0 / 1 indicators (model.matrix of factors: a multi-level factor,
-// `~ a + b` of factors; R/utilities.R:887-900) and C > 2: e^t still factorises -- E_s A_g times the product of exp(slope_c)
-// over the columns set for the sample -- from the per-coordinate constants exp(q), no exp per cell. One loop over the row
-// (5 % of the genes take it: the checked ones), the list cells evaluated in place.
-template <int CM, int L>
-PPCX_HD void indicator_cells(const Dims& d, const int* row, const double* sE, const double* sX, int sub, double A,
-                             const double* ec /* exp(slope_c), c = 1 .. C - 1 */, const GeneParams<CM>& gp, const double* tab,
-                             CellAcc<CM>& acc) {
-  const int S = d.S, C = d.C;
-  int it = 0;
-  for (int s = sub; s < S; s += L) {
-    const int y = row[s];
-    if (y >= 0) {
-      double a = A;
-#pragma unroll
-      for (int cc = 1; cc < CM; ++cc) if (cc < C) a = sX[cc * S + s] != 0.0 ? a * ec[cc] : a;
-      const double rho = y >= kLowCount ? cell_eval<CM>(y, sE[s], a, gp, tab, acc) : cell_eval_low<CM>(y, sE[s], a, gp, tab, acc);
-#pragma unroll
-      for (int cc = 1; cc < CM; ++cc) if (cc < C) acc.Tx[cc] = fma(sX[cc * S + s], rho, acc.Tx[cc]);
     }
     if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
   }
@@ -234,30 +230,27 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   }
   if (!GEN || PPCX_WAVE_ANY(!generic)) {
     if (!generic) {
-      if (CM > 2 && d.C > 2 && PPCX_WAVE_ANY(two)) {       // indicator columns, C > 2: genes with slopes first (host order),
-        if (two) {                                         // so a pass rarely mixes the two kinds
-          double ec[CM];
-          ec[0] = 1.0;
+      if (CM > 2 && d.C > 2 && PPCX_WAVE_ANY(two)) {       // indicator columns, C > 2 (factor designs): e^t = E_s A times the
+        double ec[CM];                                     // exp(slope_c) of the sample's columns; a plain gene of the same
+        ec[0] = 1.0;                                       // pass (the host puts genes with slopes first) runs it with ec = 1
 #pragma unroll
-          for (int cc = 1; cc < CM; ++cc) ec[cc] = cc < d.C ? v.at(V_C0, coef_index(d, cc, g)) : 1.0;
-          indicator_cells<CM, L>(d, row, sE, sX, sub, A, ec, gp, tab, acc);
-        } else {
-          sweep_cells<CM, L, false>(S, row, sE, sX, sub, A, A, gp, tab, acc);
-          low_cells<CM, L, false>(m.low + lo, low_n, sE, sX, sub, A, A, gp, tab, acc);
-        }
+        for (int cc = 1; cc < CM; ++cc) ec[cc] = (two && cc < d.C) ? v.at(V_C0, coef_index(d, cc, g)) : 1.0;
+        const double A1 = A * ec[1];
+        sweep_cells<CM, L, 2>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc, ec, d.C);
+        low_cells<CM, L, 2>(m.low + lo, low_n, sE, sX + S, sub, A, A1, gp, tab, acc, ec, d.C, S);
       } else if (PPCX_WAVE_ANY(two)) {                     // e^t = E_s A or E_s A1 by the sample's group (X[,2] is 0 or 1)
         const double A1 = two ? A * v.at(V_C0, coef_index(d, 1, g)) : A;
-        sweep_cells<CM, L, true>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc);
-        low_cells<CM, L, true>(m.low + lo, low_n, sE, sX + S, sub, A, A1, gp, tab, acc);
+        sweep_cells<CM, L, 1>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc);
+        low_cells<CM, L, 1>(m.low + lo, low_n, sE, sX + S, sub, A, A1, gp, tab, acc);
       } else {
 #ifdef PPCX_FORCE_TAIL          // development aid (timing only, wrong results): every pass with one tail length
-        (void)tier; sweep_cells<CM, L, false, PPCX_FORCE_TAIL>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+        (void)tier; sweep_cells<CM, L, 0, PPCX_FORCE_TAIL>(S, row, sE, sX, sub, A, A, gp, tab, acc);
 #else
-        if (PPCX_WAVE_ALL(tier >= 2)) sweep_cells<CM, L, false, 1>(S, row, sE, sX, sub, A, A, gp, tab, acc);
-        else if (PPCX_WAVE_ALL(tier >= 1)) sweep_cells<CM, L, false, 2>(S, row, sE, sX, sub, A, A, gp, tab, acc);
-        else sweep_cells<CM, L, false>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+        if (PPCX_WAVE_ALL(tier >= 2)) sweep_cells<CM, L, 0, 1>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+        else if (PPCX_WAVE_ALL(tier >= 1)) sweep_cells<CM, L, 0, 2>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+        else sweep_cells<CM, L, 0>(S, row, sE, sX, sub, A, A, gp, tab, acc);
 #endif
-        low_cells<CM, L, false>(m.low + lo, low_n, sE, sX, sub, A, A, gp, tab, acc);
+        low_cells<CM, L, 0>(m.low + lo, low_n, sE, sX, sub, A, A, gp, tab, acc);
       }
     }
   }

@@ -145,7 +145,12 @@ hipError_t launch_sum_shards_kernel(const ShardSumArgs& a, hipStream_t st);
 hipError_t launch_update_kernel(const UpdateArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_advi_kernel(const AdviArgs& a, int nblocks, hipStream_t st);
 hipError_t launch_advi_elbo_kernel(const AdviElboArgs& a, hipStream_t st);
-hipError_t launch_ppc_kernel(const PpcArgs& a, int nblocks, hipStream_t st);
+hipError_t launch_ppc_kernel(const PpcArgs& a, const double* T, int nblocks, hipStream_t st);   // one workgroup per cell
+// one wavefront per cell (n_gen <= ppc_wave_max_draws()): the parameter table T[K][C + 1][n_draws], then the draws
+size_t ppc_wave_lds_bytes(int n_gen);
+int ppc_wave_max_draws();
+hipError_t launch_ppc_table_kernel(const double* draws, long n_draws, const Dims& d, double tc, double* T, hipStream_t st);
+hipError_t launch_ppc_wave_kernel(const PpcArgs& a, const double* T, int nblocks, hipStream_t st);
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st);
 hipError_t launch_fill_kernel(double* p, long n, double val, hipStream_t st);
 hipError_t launch_xchg_abort_kernel(const XchgArgs& x, hipStream_t st);      // tells every peer that this rank has left the fit

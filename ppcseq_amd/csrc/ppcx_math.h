@@ -281,53 +281,148 @@ struct Stream {
   }
 };
 
-// Gamma(shape a, scale 1): Marsaglia & Tsang, "A simple method for generating gamma variables" (2000)
-PPCX_HD double gamma_rng(double a, Stream& st) {
-  double boost = 1.0;
-  if (a < 1.0) { boost = pow(st.uniform(), 1.0 / a); a += 1.0; }
-  const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
-  for (int it = 0; it < 4096; ++it) {          // bounded: every wave must be able to leave the loop
-    const double x = st.normal();
-    double v = 1.0 + c * x;
-    if (v <= 0.0) continue;
-    v = v * v * v;
-    const double u = st.uniform();
-    const double x2 = x * x;
-    if (u < 1.0 - 0.0331 * x2 * x2) return d * v * boost;
-    if (log(u) < 0.5 * x2 + d * (1.0 - v + log(v))) return d * v * boost;
-  }
-  return d * boost;                            // unreachable for finite a > 0 (acceptance > 95 %)
+// The transcendental functions of the posterior-predictive draws. On the device the lean versions above (fast_log, fast_exp:
+// < 1 ulp) and a sine / cosine of 2 pi u reduced on u itself; on the host libm. The integers drawn agree with the oracle's
+// (libm) unless an accept / reject comparison or a floor() is decided by the last bits: ~1e-13 per draw.
+#if defined(__HIP_DEVICE_COMPILE__)
+PPCX_HD double rng_log(double x) { return fast_log(x); }
+PPCX_HD double rng_exp(double x) { return (x > -700.0 && x < 700.0) ? fast_exp(x) : exp(x); }
+PPCX_HD double rng_div(double a, double b) { return a * fast_rcp(b); }      // v_rcp_f64 + Newton instead of the ~30-instruction division
+// sin(2 pi u), cos(2 pi u), u in (0, 1): the quadrant and the reduced argument are exact in u; kernel polynomials of
+// Sun's fdlibm k_sin.c / k_cos.c (public domain algorithm) on [0, pi/4]
+PPCX_HD void sincos_2pi(double u, double* sn, double* cs) {
+  const double q4 = floor(u * 4.0);
+  double r = u - q4 * 0.25;                              // [0, 1/4), exact
+  const bool flip = r > 0.125;
+  r = flip ? 0.25 - r : r;                               // [0, 1/8], exact
+  const double t = r * 6.283185307179586476925, z = t * t;
+  const double ps = z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+  const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double s0 = fma(t, ps, t), c0 = fma(z, pc, fma(-0.5, z, 1.0));
+  const double sq = flip ? c0 : s0, cq = flip ? s0 : c0;  // of the angle inside the quadrant
+  const int q = (int)q4 & 3;
+  *sn = q == 0 ? sq : (q == 1 ? cq : (q == 2 ? -sq : -cq));
+  *cs = q == 0 ? cq : (q == 1 ? -sq : (q == 2 ? -cq : sq));
 }
-// Poisson(lam): Knuth multiplication below 10, Hoermann's PTRS (1993) above
-PPCX_HD long long poisson_rng(double lam, Stream& st) {
-  if (lam < 10.0) {
-    const double L = exp(-lam);
-    double p = st.uniform();
-    long long k = 0;
-    while (p > L && k < 4096) { ++k; p *= st.uniform(); }
-    return k;
+// lgamma(k + 1) for an integer k >= 0 held in a double: a table of ln k! below 8, Stirling with the tail polynomial above
+PPCX_HD double lgamma_int1(double kf) {
+  if (kf < 8.0) {
+    const int k = (int)kf;
+    return k < 2 ? 0.0 : (k == 2 ? 6.93147180559945286e-01 : (k == 3 ? 1.79175946922805496e+00 : (k == 4 ? 3.17805383034794575e+00 :
+           (k == 5 ? 4.78749174278204581e+00 : (k == 6 ? 6.57925121201010121e+00 : 8.52516136106541467e+00)))));
   }
-  const double slam = sqrt(lam), loglam = log(lam);
-  const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
-  const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
-  for (int it = 0; it < 4096; ++it) {
-    const double U = st.uniform() - 0.5, V = st.uniform();
-    const double us = 0.5 - fabs(U);
-    const double kf = floor((2.0 * a / us + b) * U + lam + 0.43);
-    if (us >= 0.07 && V <= vr) return (long long)kf;
-    if (kf < 0 || (us < 0.013 && V > us)) continue;
-    if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + kf * loglam - lgamma(kf + 1.0)) return (long long)kf;
-  }
-  return (long long)lam;                       // unreachable for finite lam (acceptance > 85 %)
+  const double x = kf + 1.0, rx = fast_rcp(x);
+  double lgt, dgt;
+  stirling_tails(rx, &lgt, &dgt);
+  return (x - 0.5) * fast_log(x) - x + 9.18938533204672742e-01 + lgt;
 }
-// neg_binomial_2_log_rng(eta, phi) as a gamma-Poisson mixture (inst/stan/negBinomial_MPI.stan:264);
-// stream = (seed, 'PPC1') x (cell, draw). Stan raises above 2^30; we saturate.
+#else
+PPCX_HD double rng_log(double x) { return log(x); }
+PPCX_HD double rng_exp(double x) { return exp(x); }
+PPCX_HD double rng_div(double a, double b) { return a / b; }
+PPCX_HD void sincos_2pi(double u, double* sn, double* cs) { const double t = 6.283185307179586476925 * u; *sn = sin(t); *cs = cos(t); }
+PPCX_HD double lgamma_int1(double kf) { return lgamma(kf + 1.0); }
+#endif
+
+// sequential stream of the posterior-predictive draws: as Stream, with the lean functions
+struct RngStream {
+  uint32_t k0, k1, c1, c2, c3, blk;
+  int have; double b0, b1;
+  int have_n; double spare;
+  PPCX_HD void init(uint32_t k0_, uint32_t k1_, uint32_t c1_, uint32_t c2_, uint32_t c3_) {
+    k0 = k0_; k1 = k1_; c1 = c1_; c2 = c2_; c3 = c3_; blk = 0; have = 0; have_n = 0; b0 = b1 = spare = 0.0;
+  }
+  PPCX_HD double uniform() {
+    if (have == 0) {
+      const u4 r = philox4x32_10(blk++, c1, c2, c3, k0, k1);
+      b1 = u01(r.x, r.y); b0 = u01(r.z, r.w); have = 2;
+    }
+    --have;
+    return have == 1 ? b1 : b0;
+  }
+  PPCX_HD double normal() {                      // Box-Muller; the sine branch is the spare
+    if (have_n) { have_n = 0; return spare; }
+    const double u1 = uniform(), u2 = uniform();
+    const double rad = sqrt(-2.0 * rng_log(u1));
+    double sn, cs;
+    sincos_2pi(u2, &sn, &cs);
+    spare = rad * sn; have_n = 1;
+    return rad * cs;
+  }
+};
+
+// Gamma(shape a, scale 1): Marsaglia & Tsang, "A simple method for generating gamma variables" (2000), as begin + attempts:
+// the posterior-predictive kernel runs the attempts of a wavefront's lanes in ONE loop in which a lane that has accepted
+// goes on to its next draw at once, instead of every draw waiting for the slowest lane's rejections.
+// Stream: key (seed32, 'PPC1'), counter (block, cell, draw, 4).
+struct GammaDraw { RngStream st; double d, c, boost; };
+PPCX_HD void gamma_begin(GammaDraw& g, double a, uint32_t k0, uint32_t cell, uint32_t draw) {
+  g.st.init(k0, 0x50504331u, cell, draw, 4u);
+  g.boost = 1.0;
+  if (a < 1.0) { g.boost = pow(g.st.uniform(), 1.0 / a); a += 1.0; }
+  g.d = a - 1.0 / 3.0; g.c = rng_div(1.0, sqrt(9.0 * g.d));
+}
+PPCX_HD bool gamma_attempt(GammaDraw& g, double* out) {
+  const double x = g.st.normal();
+  double v = 1.0 + g.c * x;
+  if (v <= 0.0) return false;
+  v = v * v * v;
+  const double u = g.st.uniform();
+  const double x2 = x * x;
+  if (u < 1.0 - 0.0331 * x2 * x2 || rng_log(u) < 0.5 * x2 + g.d * (1.0 - v + rng_log(v))) { *out = g.d * v * g.boost; return true; }
+  return false;
+}
+// Poisson(lam): Knuth multiplication below 10, Hoermann's PTRS (1993) above; begin + attempts likewise.
+// Stream: key (seed32, 'PPC1'), counter (block, cell, draw, 8) -- its own stream (round 4), so that the gamma part's stream
+// state need not travel with the draw from the gamma loop to the Poisson loop.
+struct PoissonDraw {
+  RngStream st; double lam;
+  double L, p; long long k;                     // Knuth
+  double loglam, b, a, invalpha, vr;            // PTRS
+  int n_att;
+};
+PPCX_HD void poisson_begin(PoissonDraw& q, double lam, uint32_t k0, uint32_t cell, uint32_t draw) {
+  q.st.init(k0, 0x50504331u, cell, draw, 8u);
+  q.lam = lam; q.n_att = 0; q.k = 0; q.L = 0.0; q.p = 0.0; q.loglam = 0.0; q.b = 0.0; q.a = 0.0; q.invalpha = 0.0; q.vr = 0.0;
+  if (lam < 10.0) { q.L = rng_exp(-lam); q.p = q.st.uniform(); }
+  else {
+    const double slam = sqrt(lam);
+    q.loglam = rng_log(lam);
+    q.b = 0.931 + 2.53 * slam; q.a = -0.059 + 0.02483 * q.b;
+    q.invalpha = 1.1239 + rng_div(1.1328, q.b - 3.4); q.vr = 0.9277 - rng_div(3.6224, q.b - 2.0);
+  }
+}
+PPCX_HD bool poisson_attempt(PoissonDraw& q, long long* out) {
+  if (q.lam < 10.0) {
+    if (!(q.p > q.L) || q.k >= 4096) { *out = q.k; return true; }
+    ++q.k; q.p *= q.st.uniform();
+    return false;
+  }
+  if (++q.n_att > 4096) { *out = (long long)q.lam; return true; }     // unreachable for finite lam (acceptance > 85 %)
+  const double U = q.st.uniform() - 0.5, V = q.st.uniform();
+  const double us = 0.5 - fabs(U);
+  const double kf = floor((rng_div(2.0 * q.a, us) + q.b) * U + q.lam + 0.43);
+  if (us >= 0.07 && V <= q.vr) { *out = (long long)kf; return true; }
+  if (kf < 0 || (us < 0.013 && V > us)) return false;
+  if (rng_log(V) + rng_log(q.invalpha) - rng_log(rng_div(q.a, us * us) + q.b) <= -q.lam + kf * q.loglam - lgamma_int1(kf)) { *out = (long long)kf; return true; }
+  return false;
+}
+// neg_binomial_2_log_rng(eta, phi) as a gamma-Poisson mixture (inst/stan/negBinomial_MPI.stan:264); Stan raises above 2^30,
+// we saturate. lam_of_gamma: the Poisson mean from the gamma variate.
+PPCX_HD bool nb2_invalid(double eta, double phi) { return !(phi > 0.0) || !isfinite(phi) || !isfinite(eta); }
 PPCX_HD int32_t nb2_log_rng(double eta, double phi, uint32_t k0, uint32_t cell, uint32_t draw) {
-  if (!(phi > 0.0) || !isfinite(phi) || !isfinite(eta)) return 2147483647;   // invalid draw: sorts last
-  Stream st; st.init(k0, 0x50504331u, cell, draw, 4u);
-  const double lam = gamma_rng(phi, st) * (exp(eta) / phi);
+  if (nb2_invalid(eta, phi)) return 2147483647;                       // invalid draw: sorts last
+  GammaDraw g; gamma_begin(g, phi, k0, cell, draw);
+  double gam = 0.0;
+  int it = 0;
+  while (!gamma_attempt(g, &gam)) if (++it >= 4096) { gam = g.d * g.boost; break; }   // bounded: every wave must be able to leave the loop
+  const double lam = gam * rng_div(rng_exp(eta), phi);
   if (!(lam < 1073741824.0)) return 1073741823;
-  const long long k = poisson_rng(lam, st);
+  PoissonDraw q; poisson_begin(q, lam, k0, cell, draw);
+  long long k = 0;
+  while (!poisson_attempt(q, &k)) {}
   return k > 2147483647LL ? 2147483647 : (int32_t)k;
 }
 

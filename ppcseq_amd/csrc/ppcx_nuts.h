@@ -291,14 +291,15 @@ struct ChainScalars {
   int win_next, win_size, win_counter, wn;
   double lp_eval;                // CMD_EVAL result
   long long total_leapfrogs;
-  // gene shards with the direct exchange (ppcx_kernels.hip xchg_sums): exchanges this chain has taken part in -- the sequence
-  // number its ranks stamp their contributions with -- and the wall-clock ticks (100 MHz) its state machine has waited for peers
-  unsigned xcount; unsigned pad_; long long xticks;
 };
+// gene shards with the direct exchange (ppcx_kernels.hip xchg_sums): exchanges this chain has taken part in -- the sequence
+// number its ranks stamp their contributions with -- and the wall-clock ticks (100 MHz) its state machine has waited for peers.
+// Kept apart from ChainScalars: those live in registers while a state machine runs, and ppcx_step_kernel has none to spare.
+struct XchgCount { unsigned count; unsigned pad_; long long ticks; };
 
 // per-level log weights / potentials of the parked left subtrees (indexed at run time: kept in LDS)
 struct TreeArrays { double Llsw[kLev + 1], LV[kLev + 1]; };
-struct ChainState { ChainScalars sc; TreeArrays ta; };
+struct ChainState { ChainScalars sc; TreeArrays ta; XchgCount xc; };
 
 struct Reduced {
   double lp_genes, hsum[6], T0, T1, nonfinite;
@@ -335,7 +336,8 @@ PPCX_HD void state_init(ChainState& cs, const NutsConfig& cfg, int local_chain, 
   st.H0 = 0; st.lsw_tree = 0; st.sum_metro = 0; st.V_sample = 0; st.T0h = 0; st.T0g = 0; st.T0g_held = 0;
   st.mu = 0; st.s_bar = 0; st.x_bar = 0; st.da_counter = 0;
   st.win_next = st.init_buffer + st.window - 1; st.win_size = st.window; st.win_counter = 0; st.wn = 0;
-  st.lp_eval = 0; st.total_leapfrogs = 0; st.xcount = 0; st.pad_ = 0; st.xticks = 0;
+  st.lp_eval = 0; st.total_leapfrogs = 0;
+  cs.xc.count = 0; cs.xc.pad_ = 0; cs.xc.ticks = 0;
   for (int d = 0; d <= kLev; ++d) { cs.ta.Llsw[d] = 0; cs.ta.LV[d] = 0; }
 }
 
@@ -363,8 +365,8 @@ PPCX_HD void issue_eps_try(ChainScalars& st, Cmd& nc) {
   // (Round 3 had an opaque asm barrier on st.eps_attempt here: hipcc ROCm 7.2 emitted 0 for rng_c3 on the halving / doubling
   // path of PH_EPS in ppcx_step_kernel. Round 4 traced it: the optimised LLVM IR is correct, the AMDGPU backend drops the
   // copy on one of the two predecessor paths after AMDGPUCodeGenPrepare has broken the SLP-made <2 x i32> phi of
-  // (rng_c1, rng_c3) into scalars; the library is built with that transform off -- ppcseq_amd/build.py, DESIGN.md section 3,
-  // profiles/r04_miscompile/.)
+  // (rng_c1, rng_c3) into scalars; the library is built without SLP vectorisation -- ppcseq_amd/build.py, DESIGN.md
+  // section 3, profiles/r04_miscompile/.)
   nc.rng_c1 = (unsigned)st.eps_call; nc.rng_c3 = (unsigned)st.eps_attempt;
   st.eps_attempt++;
   st.phase = PH_EPS;

@@ -141,3 +141,99 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_
     raise_if_any_rank_failed(err, device=coll_device, what="pooled summary")
     dist.broadcast_object_list(res, src=0)
     return res[0]
+
+
+def do_inference_shards(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_device="cpu", chains=None, cores=None,
+                        approximate_posterior_analysis=False, lambda_mu_mu=5.612671, adj_prob_theshold=0.05,
+                        how_many_posterior_draws=1000, to_exclude=None, truncation_compensation=1.0, seed=1):
+    """One inference pass with the GENES partitioned over the ranks (the reference's map_rect over gene shards,
+    inst/stan/negBinomial_MPI.stan:226-240; BASELINE cfg4): every rank holds a contiguous gene range and runs ALL the chains on
+    it, the six hyper-parameters and the chains' state machines are replicated, and the ranks' partial sums meet every leapfrog
+    through the direct exchange (include/ppcx.h ppcx_xchg_*: peer-mapped buffers, no collective call). The checked genes' draws
+    are then gathered on rank 0, which computes the credible intervals from them exactly as the chains path does
+    (pooled_summary), and the result is broadcast. Needs a design that runs pipelined rounds (factor designs, `~ 1`)."""
+    import math
+    from . import _lib
+    from .inference import _to_cell_ids, find_optimal_number_of_chains, pooled_summary
+    dist = _dist()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    counts = np.asarray(counts)
+    G, S = counts.shape
+    K = int(how_many_to_check)
+    X = np.asarray(X, dtype=np.float64).reshape(S, -1)
+    C = X.shape[1]
+    n2 = max(C - 2, 0)
+    practical = 1000 if approximate_posterior_analysis else how_many_posterior_draws
+    if chains is None:
+        chains = max(3, min(int(cores) if cores else 8, find_optimal_number_of_chains(practical)))
+    n_iter = int(math.ceil(practical / chains)) + 150
+    n_keep = n_iter - 150
+    g0, g1 = G * rank // world, G * (rank + 1) // world
+    excl = _to_cell_ids(to_exclude, S)
+    if excl is not None and len(excl):
+        excl = np.asarray(excl, np.int64)
+        excl = (excl[(excl // S >= g0) & (excl // S < g1)] - g0 * S).astype(np.int32)
+    part, err = None, None
+    m = xg = None
+    try:
+        m = _lib.Model(counts[g0:g1], X, exposure_rate, 0, lambda_mu_mu=lambda_mu_mu, excl=excl, device=device, shard=(G, K, g0, g1))
+        xg = _lib.Xchg(world, rank, chains, device=device)
+        handle = xg.handle()
+    except Exception as e:                          # noqa: BLE001
+        err, handle = e, b""
+    raise_if_any_rank_failed(err, device=coll_device, what="gene shards (set-up)")
+    handles = [None] * world
+    dist.all_gather_object(handles, handle)
+    try:
+        if world > 1:
+            xg.connect(handles)
+    except Exception as e:                          # noqa: BLE001
+        err = e
+    raise_if_any_rank_failed(err, device=coll_device, what="gene shards (exchange)")      # also the barrier before anybody publishes
+    try:
+        f = m.fit_nuts_xchg(xg, chains=chains, iter=n_iter, warmup=150, seed=seed)
+        try:
+            Gl, Kl = g1 - g0, m.K                   # this shard's genes and checked genes (local unconstrained vector, Stan order)
+            a1, a2 = 3 + Gl, 3 + Gl + Kl
+            sr = a2 + n2 * Kl
+            cols = np.concatenate([np.arange(3), 3 + np.arange(Kl), a1 + np.arange(Kl), a2 + np.arange(n2 * Kl),
+                                   sr + np.arange(Kl), sr + Gl + np.arange(3)]).astype(np.int32)
+            part = (Kl, f.columns(cols))
+        finally:
+            f.close()
+    except Exception as e:                          # noqa: BLE001
+        err = e
+    finally:
+        if m is not None:
+            m.close()
+        if xg is not None:
+            xg.close()
+    raise_if_any_rank_failed(err, device=coll_device, what="gene shards (fit)")
+    parts = [None] * world
+    dist.all_gather_object(parts, part)
+    res, err = [None], None
+    if rank == 0:
+        try:
+            pooled = np.zeros((chains, n_keep, 3 + K * (2 + max(C - 1, 1)) + 3))
+            pooled[..., :3] = parts[0][1][..., :3]                           # hyper-parameters: replicated, rank 0's copy
+            pooled[..., -3:] = parts[0][1][..., -3:]
+            k0 = 0
+            for Kl, dr in parts:                                             # the shards' checked genes, in gene order
+                if Kl:
+                    pooled[..., 3 + k0:3 + k0 + Kl] = dr[..., 3:3 + Kl]
+                    pooled[..., 3 + K + k0:3 + K + k0 + Kl] = dr[..., 3 + Kl:3 + 2 * Kl]
+                    for c in range(n2):                                      # alpha_2: (C - 2) entries per checked gene, gene-major
+                        pooled[..., 3 + 2 * K + n2 * k0 + c:3 + 2 * K + n2 * (k0 + Kl):n2] = dr[..., 3 + 2 * Kl + c:3 + 2 * Kl + n2 * Kl:n2]
+                    pooled[..., 3 + (2 + n2) * K + k0:3 + (2 + n2) * K + k0 + Kl] = dr[..., 3 + (2 + n2) * Kl:3 + (3 + n2) * Kl]
+                k0 += Kl
+            r = pooled_summary(counts, X, exposure_rate, K, pooled, lambda_mu_mu=lambda_mu_mu,
+                               approximate_posterior_analysis=approximate_posterior_analysis, adj_prob_theshold=adj_prob_theshold,
+                               how_many_posterior_draws=how_many_posterior_draws, truncation_compensation=truncation_compensation,
+                               seed=seed, device=device)
+            r.chains, r.iter = chains, n_iter
+            res[0] = r
+        except Exception as e:                      # noqa: BLE001
+            err = e
+    raise_if_any_rank_failed(err, device=coll_device, what="pooled summary")
+    dist.broadcast_object_list(res, src=0)
+    return res[0]

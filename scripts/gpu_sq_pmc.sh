@@ -1,6 +1,7 @@
 #!/bin/bash
-# development aid: SQ counters of the loglik kernel (kernel-level bench, scripts/gpu_kbench.py; G, S, LANES from the env)
-# usage: scripts/gpu_sq_pmc.sh <tag> [passes: 1 2 3]
+# development aid: SQ counters of one kernel. Default: the loglik kernel under the kernel-level bench (scripts/gpu_kbench.py; G, S,
+# LANES from the env). SCRIPT=scripts/gpu_ppc_bench.py KERNEL=ppc_wave: the posterior-predictive kernel at the bench's workload.
+# usage: [SCRIPT=...] [KERNEL=...] scripts/gpu_sq_pmc.sh <tag> [passes: 1 2 3]
 export TMPDIR=/tmp
 TAG=${1:-run}; shift
 PASSES=${@:-1 2 3}
@@ -9,7 +10,7 @@ P[1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU S
 P[2]="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD"
 P[3]="GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_IFETCH SQ_ACTIVE_INST_FLAT SQ_VALU_MFMA_BUSY_CYCLES"
 for i in $PASSES; do
-  rocprofv3 --pmc ${P[$i]} --kernel-trace --output-format csv -d $OUT/p$i -- python3 scripts/gpu_kbench.py > $OUT/p$i.log 2> $OUT/p$i.err || echo "pass $i failed"
+  rocprofv3 --pmc ${P[$i]} --kernel-trace --output-format csv -d $OUT/p$i -- python3 ${SCRIPT:-scripts/gpu_kbench.py} > $OUT/p$i.log 2> $OUT/p$i.err || echo "pass $i failed"
 done
 python3 - $OUT <<'PY'
 import csv, glob, collections, sys, os

@@ -407,3 +407,46 @@ def test_a_rank_that_fails_takes_its_peer_out_of_the_direct_exchange(failing_ran
     assert [r[1] for r in res] == ["error", "error"], res
     assert "injected failure" in res[failing_rank][2]
     assert "ppcx error -5" in res[1 - failing_rank][2] and "peer rank left" in res[1 - failing_rank][2], res
+
+
+def _shards_rank_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from ppcseq_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = ind.synth_factor(90, 12, 7, (3,), 5)
+        r = D.do_inference_shards(d["counts"], d["X"], d["exposure"], 7, device=0, coll_device="cpu", chains=4,
+                                  to_exclude=np.array([3, 14], np.int32), **KW)
+        q.put((rank, "ok", r.lower, r.upper, r.slope, r.deleterious_outliers))
+    except Exception as e:                      # noqa: BLE001
+        q.put((rank, "crash: " + repr(e), None, None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_do_inference_with_the_genes_sharded_over_two_ranks():
+    """distributed.do_inference_shards: genes over the ranks (here two gloo ranks on the one GPU, a three-level factor design:
+    C = 3), all chains on every rank, the direct exchange every leapfrog, the checked genes' draws gathered on rank 0 for the
+    posterior-predictive pass. Against the same pass on one rank with all the genes: identical decisions for as long as rounding
+    lets the chains coincide, so the intervals agree within Monte-Carlo error and the slopes closely."""
+    from ppcseq_amd.inference import do_inference
+    d = ind.synth_factor(90, 12, 7, (3,), 5)
+    one = do_inference(d["counts"], d["X"], d["exposure"], 7, chains=4, to_exclude=np.array([3, 14], np.int32), **KW)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shards_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == ["ok", "ok"], [r[1] for r in res]
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][5], res[1][5])          # broadcast: the same on every rank
+    lower, upper, slope = res[0][2], res[0][3], res[0][4]
+    assert np.max(np.abs(slope - one.slope)) < 0.25
+    assert np.median(np.abs(upper - one.upper) / (1 + one.upper)) < 0.06 and np.max(np.abs(upper - one.upper) / (1 + one.upper)) < 0.5
+    assert np.median(np.abs(lower - one.lower) / (1 + one.lower)) < 0.1
