@@ -69,6 +69,13 @@ PPCX_API int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int
    n groups on their own streams. A chain's draws do not depend on stream_groups. The initial values come from the
    environment variables PPCX_PIPELINE / PPCX_STREAM_GROUPS, read once when the model is created. */
 PPCX_API int ppcx_model_set_rounds(ppcx_model* m, int pipelined, int stream_groups);
+/* Progress of a running NUTS fit (rstan prints the chains' iterations; a fit of minutes need not be silent, and a chain that left
+   the reference's 150 warm-up iterations with a very small step size -- every transition at the maximum tree depth, DESIGN.md
+   section 4 -- shows up here as one chain still running long after the others): fn(user, first_chain_of_the_group,
+   chains_in_the_group, chains_done, leapfrog_rounds_issued, seconds) is called from the thread that pumps the group's launches,
+   at most every `every_seconds` and once when the group is done. NULL switches it off (default). */
+typedef void (*ppcx_progress_fn)(void* user, int first_chain, int chains, int chains_done, long long rounds, double seconds);
+PPCX_API int ppcx_model_set_progress(ppcx_model* m, ppcx_progress_fn fn, void* user, double every_seconds);
 /* what a fit of `nchains` chains of this model runs: pipelined = 1 (two launches per leapfrog: any model with X[,1] = 1 whose
    slope columns are 0 / 1 indicators -- `~ 1`, `~ Label`, formulas of factors) or 0 (three launches: continuous covariates),
    and the number of chain groups */

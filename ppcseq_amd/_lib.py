@@ -18,7 +18,7 @@ EXPORTS = [
     "ppcx_version", "ppcx_device_count", "ppcx_last_error", "ppcx_model_create", "ppcx_model_set_exclusions",
     "ppcx_model_set_launch", "ppcx_model_get_launch", "ppcx_model_get_plan", "ppcx_model_dim", "ppcx_model_destroy", "ppcx_log_prob_grad",
     "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_from_draws", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
-    "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_model_set_rounds", "ppcx_model_get_rounds",
+    "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_model_set_rounds", "ppcx_model_get_rounds", "ppcx_model_set_progress",
     "ppcx_model_create_shard", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
     "ppcx_fit_nuts_comm", "ppcx_advi_config_default", "ppcx_fit_advi", "ppcx_fit_advi_info", "ppcx_fit_advi_iterative",
     "ppcx_guard_decision", "ppcx_device_memory", "ppcx_fit_get_ppc_timing",
@@ -45,6 +45,7 @@ class AdviConfig(C.Structure):
                 ("init_radius", C.c_double)]
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_double)
 _lib = None
 
 
@@ -107,6 +108,7 @@ def load() -> C.CDLL:
     lib.ppcx_fit_nuts_xchg.argtypes = [C.c_void_p, C.POINTER(NutsConfig), C.c_void_p, C.POINTER(C.c_void_p)]
     lib.ppcx_fit_get_xchg_timing.argtypes = [C.c_void_p, dp, C.POINTER(C.c_longlong)]
     lib.ppcx_model_get_rounds.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.ppcx_model_set_progress.argtypes = [C.c_void_p, PROGRESS_FN, C.c_void_p, C.c_double]
     if hasattr(lib, "ppcx_testing_set"):         # the testing build (csrc/ppcx_testing.h)
         lib.ppcx_testing_set.argtypes = [C.c_char_p, C.c_longlong]
         lib.ppcx_testing_set_nccl_provider.argtypes = [C.c_char_p]
@@ -278,6 +280,11 @@ class Model:
         """Round structure of this model's NUTS fits: pipelined -1 = wherever the model allows it (default), 0 = the
         three-launch round; stream_groups 0 = by the number of chains, n = n chain groups on their own streams."""
         _check(load().ppcx_model_set_rounds(self._h, int(pipelined), int(stream_groups)))
+
+    def set_progress(self, fn=None, every_seconds=1.0):
+        """fn(first_chain, chains, chains_done, rounds, seconds) during a NUTS fit of this model (None: off)."""
+        self._progress_cb = PROGRESS_FN((lambda user, c0, n, done, rounds, sec: fn(c0, n, done, rounds, sec)) if fn else 0)
+        _check(load().ppcx_model_set_progress(self._h, self._progress_cb, None, float(every_seconds)))
 
     def get_rounds(self, nchains=1):
         """(pipelined, stream_groups) a fit of `nchains` chains would run with."""

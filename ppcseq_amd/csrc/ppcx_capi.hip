@@ -36,6 +36,7 @@ struct TestHooks {
   long long fail_at_round = 0; int fail_rank = -1;   // fault injection into the pump of a gene-sharded run
   int force_generic = 0;                             // every gene with slopes takes the per-cell-eta path
   int no_tail_tiers = 0, plan_ignore_tiers = 0;      // timing experiments on the Stirling-tail tiers
+  int slope_cost_permille = 0;                       // plan: cost of a pass with slope genes relative to a plain one (0: built-in)
   std::string rccl_lib;                              // another provider of the nccl* entry points (tests/loopback)
 };
 static TestHooks g_test;
@@ -52,6 +53,8 @@ struct ppcx_model {
   // round structure of a NUTS fit (ppcx_model_set_rounds; initial values from PPCX_PIPELINE / PPCX_STREAM_GROUPS, read
   // once when the model is created): pipelined -1 = where it applies, 0 = never; stream_groups 0 = by the number of chains
   int opt_pipelined = -1, opt_stream_groups = 0;
+  // progress reports of a running fit (ppcx_model_set_progress): the pump calls it at a poll, at most every progress_every s
+  ppcx_progress_fn progress = nullptr; void* progress_user = nullptr; double progress_every = 1.0;
   // gene order of the log-likelihood launch (upload_counts): per position, the length of the gene's low-count list
   // and whether it has slopes -- what a pass of a wavefront costs (plan_launch)
   std::vector<int> pos_low; std::vector<char> pos_slope, pos_tier;
@@ -125,7 +128,16 @@ static double pass_cost(const ppcx_model* m, int L, int p, int n) {
   const bool ignore_tiers = false;
 #endif
   const double tail = (slope || ignore_tiers) ? 1.0 : (tier >= 2 ? 0.86 : (tier >= 1 ? 0.91 : 1.0));
-  const double sweep = (double)((S + L - 1) / L) * tail * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? (m->d.C > 2 ? 2.0 : 1.15) : 1.0));
+  // a pass of genes with slopes: 1.15 x a plain one in a two-group design. With more indicator columns it costs 1.43 x (C = 3, all
+  // genes with slopes against none: 83.9 vs 58.4 us per launch) -- but weighting it so makes the launch SLOWER (K = 1000 of 20 000
+  // genes: weight 1.0 -> 63.4 us, 1.45 -> 67.5, 2.0 -> 72.8; scripts/gpu_factor_k.py): the four wavefronts of a SIMD come from four
+  // workgroups and share its fp64 unit, so what counts is the SIMD's total, and a wavefront with fewer, dearer passes does not
+  // relieve the three it shares the SIMD with, while the passes it gives up push the others over their share
+  double slope_w = m->d.C > 2 ? 1.0 : 1.15;
+#ifdef PPCX_TESTING
+  if (g_test.slope_cost_permille > 0) slope_w = 1e-3 * g_test.slope_cost_permille;
+#endif
+  const double sweep = (double)((S + L - 1) / L) * tail * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? slope_w : 1.0));
   return 5.8 + sweep + 0.75 * (double)((lowmax + L - 1) / L);
 }
 // reserve: workgroups of the same launch that are not log-likelihood workgroups (the state machines of a pipelined
@@ -404,6 +416,11 @@ static bool model_pipelines(const ppcx_model* m) {
   // the pipelined round needs a model whose cells read the anticipated constants only: X[,1] = 1 and slopes only on
   // indicator columns (no per-cell linear predictor)
   return m->opt_pipelined != 0 && m->ls_wgs_per_cu >= 1 && m->d.x0_is_one && (m->d.C < 2 || m->d.K == 0 || m->d.x1_binary);
+}
+extern "C" int ppcx_model_set_progress(ppcx_model* m, ppcx_progress_fn fn, void* user, double every_seconds) {
+  if (!m || !(every_seconds >= 0)) return fail(PPCX_ERR_ARG, "bad arguments");
+  m->progress = fn; m->progress_user = user; m->progress_every = every_seconds;
+  return PPCX_OK;
 }
 extern "C" int ppcx_model_get_rounds(const ppcx_model* m, int nchains, int* pipelined, int* stream_groups) {
   if (!m || nchains < 1) return fail(PPCX_ERR_ARG, "bad arguments");
@@ -755,6 +772,7 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
   bool lookahead = piped && !guarded;
   if (lookahead) for (int i = 4; i < 6; ++i) if (hipEventCreateWithFlags(&evs.e[i], hipEventDisableTiming) != hipSuccess) { evs.e[i] = nullptr; lookahead = false; }
   long long pairs = 0; int n_done = 0, n_done_applied = 0;
+  const auto t_start = std::chrono::steady_clock::now(); auto t_report = t_start;
   Work& w0 = *sh[0].w;
   int cur = 0; bool have_prev = false, sampled_prev = false;
   while (true) {
@@ -831,6 +849,13 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       if (grc != PPCX_OK) return grc;
       if (all_rc != PPCX_OK) { rc = all_rc; break; }
     } else if (rc != PPCX_OK) break;
+    if (sh[0].m->progress && local_rc == PPCX_OK) {   // a blocking call of minutes need not be silent: rounds issued, chains done
+      const auto now = std::chrono::steady_clock::now();
+      if (std::chrono::duration<double>(now - t_report).count() >= sh[0].m->progress_every || n_done == nchains) {
+        t_report = now;
+        sh[0].m->progress(sh[0].m->progress_user, sh[0].w->xchg_chain0, nchains, n_done, pairs, std::chrono::duration<double>(now - t_start).count());
+      }
+    }
     if (n_done == nchains) break;
     // fewer chains in the launch: the others get their wavefronts (the list is rewritten on an idle stream: with the poll one
     // batch behind the queued batch is waited for first, and its newer flags are the ones applied)
@@ -919,6 +944,7 @@ extern "C" int ppcx_testing_set(const char* key, long long value) {
   else if (k == "force_generic") g_test.force_generic = (int)value;
   else if (k == "no_tail_tiers") g_test.no_tail_tiers = (int)value;
   else if (k == "plan_ignore_tiers") g_test.plan_ignore_tiers = (int)value;
+  else if (k == "slope_cost_permille") g_test.slope_cost_permille = (int)value;
   else return fail(PPCX_ERR_ARG, "unknown test hook " + k);
   return PPCX_OK;
 }
@@ -1167,7 +1193,8 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
     Group& G = grp[g];
     G.w.pipelined = piped;
     G.c0 = (int)((long long)nch * g / ngrp); G.n = (int)((long long)nch * (g + 1) / ngrp) - G.c0;
-    if (xg && xg->nranks > 1) { G.w.xchg = &xa; G.w.xchg_chain0 = G.c0; }
+    G.w.xchg_chain0 = G.c0;                    // also what a progress report names the group by
+    if (xg && xg->nranks > 1) G.w.xchg = &xa;
     if (g > 0) { FHIP(hipStreamCreateWithFlags(&G.w.stream, hipStreamNonBlocking)); G.w.own_stream = true; }
     int rc = work_alloc(G.w, m, G.n);
     if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }

@@ -74,6 +74,19 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
     const int g = g_next;
     const int pn = p + GPW + gl;
     if (p + GPW < p1) g_next = a.order[pn < p1 ? pn : p1 - 1];
+    if (CM > 2 && d.x0_is_one && !PPCX_WAVE_ANY(g < d.K)) {
+      // a pass of plain genes in a model with more than two design columns: the two-column instantiation of the gene's work
+      // (its accumulators carry two slope sums, not CM: the registers the wider one needs cost the row sweep spills), and
+      // the three sums of a plain gene
+      GeneSumsV<2> o2;
+      lane_gene_sums<2, L, false>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, o2);
+#pragma unroll
+      for (int msk = 1; msk < L; msk <<= 1) {
+        o2.lik = wave_xor_add_rt(o2.lik, msk); o2.dph = wave_xor_add_rt(o2.dph, msk); o2.Sr = wave_xor_add_rt(o2.Sr, msk);
+      }
+      if (act && sub == 0) { const long G = d.G; sums[0 * G + g] = o2.lik; sums[1 * G + g] = o2.dph; sums[2 * G + g] = o2.Sr; }
+      continue;
+    }
     GeneSumsV<CM> o;
     lane_gene_sums<CM, L, GEN>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, o);
     // sum X_sc rho is needed of genes with slopes only (and of every gene when X[,1] != 1): a pass without such genes

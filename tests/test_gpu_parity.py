@@ -294,6 +294,30 @@ def test_round_structures_agree_with_the_oracle(L, oracle, monkeypatch):
     assert not bad, bad
 
 
+def test_progress_reports_of_a_running_fit(L):
+    """ppcx_model_set_progress: the pump reports rounds issued and chains done while the (blocking) fit runs -- how a caller
+    learns early that one chain is still running long after the others."""
+    d = ind.synth(300, 12, K=10, seed=3)
+    m = L.Model(d["counts"], d["X"], d["exposure"], 10)
+    seen = []
+    try:
+        m.set_progress(lambda c0, n, done, rounds, sec: seen.append((c0, n, done, rounds, sec)), every_seconds=0.0)
+        f = m.fit_nuts(chains=4, iter=60, warmup=40, seed=2)
+        f.close()
+        m.set_progress(None)
+        n_before = len(seen)
+        f = m.fit_nuts(chains=2, iter=20, warmup=10, seed=2)
+        f.close()
+        assert len(seen) == n_before                                     # switched off
+    finally:
+        m.close()
+    groups = {c0: n for c0, n, *_ in seen}
+    assert sum(groups.values()) == 4                                      # the chain groups of the fit (two from four chains on)
+    for c0, n in groups.items():
+        mine = [r for r in seen if r[0] == c0]
+        assert mine[-1][2] == n and all(a[3] <= b[3] and a[4] <= b[4] for a, b in zip(mine, mine[1:]))   # ends with all done; monotone
+
+
 def test_nuts_draws_follow_oracle_without_adaptation(L, oracle):
     d = ind.synth(16, 5, K=3, seed=9, C=2)
     mo = oracle.model(d["counts"], d["X"], d["exposure"], 3)
