@@ -264,7 +264,7 @@ def main():
             if args.mode == "shards":
                 b_grad = b_grad / world              # each rank streams its share of the genes
             achieved = b_grad * chains_per_launch / (ms * 1e-3) / 1e9
-            piped = os.environ.get("PPCX_PIPELINE", "1") != "0" and args.mode == "chains"
+            piped = model.get_rounds(nch)[0] and comm is None
             roof = {"bound": "hbm", "kernel": "ppcx_ls_kernel" if piped else "ppcx_loglik_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(chains_per_launch), "fp64_issue": issue_profile(),
                     "algorithmic_bytes_per_launch": b_grad * chains_per_launch, "avg_launch_ms": round(ms, 5),
@@ -296,7 +296,7 @@ def main():
                        "ess_median_intercept_sigma_raw_rank0_chains": round(ess_gene_median, 1),
                        "grad_evals": tot_grad, "mean_treedepth": round(float(np.mean(depth_mean)), 2),
                        "divergent_after_warmup": div_total,
-                       "round_structure": ("pipelined: merged log-likelihood / state-machine launch + gene kernel" if os.environ.get("PPCX_PIPELINE", "1") != "0" and args.mode == "chains"
+                       "round_structure": ("pipelined: merged log-likelihood / state-machine launch + gene kernel" if (model.get_rounds(nch)[0] and comm is None)
                                            else "three launches: log-likelihood, close, step + update"),
                        "stream_groups": args.stream_groups if args.stream_groups > 0 else ("library default (3 from eight chains on, 2 from four)" if args.mode == "chains" else 1),
                        "rounds_last_step_all_groups": int(rounds_last),
@@ -384,14 +384,16 @@ def ppc_object(fit, K, S, C):
     nb = fit.ppc_timing()[1]
     b_draw = 4.0 * S * K + 8.0 * (S + K * (C + 1))
     achieved = b_draw * n_draws / t / 1e9
-    return {"kernel": "ppcx_ppc_kernel", "workload": f"{K} checked genes x {S} samples x {n_draws} kept draws of the timed fit",
+    return {"kernel": "ppcx_ppc_table_kernel + " + ("ppcx_ppc_wave_kernel" if n_draws <= 4096 else "ppcx_ppc_kernel"),
+            "workload": f"{K} checked genes x {S} samples x {n_draws} kept draws of the timed fit",
             "nb_draws": int(nb), "kernel_ms": round(1e3 * t, 3), "nb_draws_per_s": round(nb / t, 1),
             "algorithmic_bytes_per_posterior_draw": b_draw, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 6), "bound": "alu",
-            "note": "not memory bound: a negative-binomial draw is a Philox block, a Marsaglia-Tsang gamma and a Knuth / PTRS Poisson "
-                    "(rejection loops, log / exp / sqrt / lgamma) -- a few hundred fp64 instructions against 4 bytes; the draws never "
-                    "leave LDS unless save_generated_quantities asks for them, so the 4 S K bytes of the reference's counts_rng are "
-                    "not written at all (profiles/ README: instruction and traffic counters of this kernel)"}
+            "note": "not memory bound: a negative-binomial draw is 5-7 Philox blocks (quarter-rate 32 x 32 multiplies), a "
+                    "Marsaglia-Tsang gamma and a Knuth / PTRS Poisson -- ~1500 vector-instruction slots per wavefront-draw against 4 "
+                    "bytes (profiles/ README: SQ counters of this kernel). One wavefront per cell, parameters from a transposed "
+                    "table, one loop of sampler attempts per wavefront; the draws never leave LDS unless save_generated_quantities "
+                    "asks for them, so the 4 S K bytes of the reference's counts_rng are not written at all"}
 
 
 def outlier_concordance():
