@@ -216,14 +216,15 @@ def test_approximated_analysis_matches_its_oracle_restatement(L, oracle):
 
 def test_more_predictive_draws_than_fit_in_lds(L, oracle):
     """how_many_posterior_draws = draws_after_tail / threshold reaches 100 000 at the reference's defaults with 200
-    samples (R/methods.R:166-167): beyond 39 680 draws per cell the kernel keeps them in a global scratch buffer."""
+    samples (R/methods.R:166-167): beyond 39 680 draws per cell the kernel keeps them in a global scratch buffer. Also the
+    hand-over from the wavefront-per-cell kernel (up to 4096 draws per cell) to the workgroup-per-cell kernel."""
     d = ind.synth(12, 5, K=2, seed=5)
     mo = oracle.model(d["counts"], d["X"], d["exposure"], 2, n_threads=8)
     m = L.Model(d["counts"], d["X"], d["exposure"], 2)
     try:
         f = m.fit_nuts(chains=3, iter=250, warmup=150, seed=4)
         dr = f.draws().reshape(-1, f.D)
-        for n_gen in (39680, 39681, 100000):
+        for n_gen in (4095, 4096, 4097, 39680, 39681, 100000):
             ci, rng = f.ppc(0.7352941, 0.0005, 0.9995, seed=6, n_gen=n_gen, resample=True, return_counts_rng=True)
             gq = oracle.generated_quantities_approx(mo, dr, n_gen, 0.7352941, seed=6)
             assert np.array_equal(gq, rng), n_gen
