@@ -628,10 +628,10 @@ static int launch_ls(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
   return PPCX_OK;
 }
 // pipelined round, second launch: the command the state machines just wrote, gene by gene
-static int launch_gene_round(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
+static int launch_gene_round(ppcx_model* m, Work& w, int nchains, const RunIO& io, int spec = 1) {
   GeneArgs ga;
   close_args(m, w, &ga.c);
-  ga.draws = io.draws; ga.draws_chain_stride = io.draws_stride; ga.logtab = m->d_logtab; ga.spec = 1;
+  ga.draws = io.draws; ga.draws_chain_stride = io.draws_stride; ga.logtab = m->d_logtab; ga.spec = spec;
   hipError_t e = launch_gene_kernel(m->CM, ga, w.nb_close, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("gene kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
@@ -958,7 +958,7 @@ extern "C" int ppcx_testing_set_nccl_provider(const char* path) {
 // tree position of that command (number of subtree merges the leaf closes), so every variant is timed on the same work.
 extern "C" int ppcx_testing_bench_kernel(ppcx_model* m, int which, int nchains, int warm_rounds, int reps, int n_merge,
                                          double* ms_per_launch, int* cmd_type) {
-  if (!m || nchains < 1 || reps < 1 || !ms_per_launch || which < 0 || which > PPCX_BENCH_STEP_UPDATE) return fail(PPCX_ERR_ARG, "bad arguments");
+  if (!m || nchains < 1 || reps < 1 || !ms_per_launch || which < 0 || which > PPCX_BENCH_GENE_NEW_TRANSITION) return fail(PPCX_ERR_ARG, "bad arguments");
   HIPCHK(hipSetDevice(m->device));
   choose_launch(m, nchains);
   Work w;
@@ -984,9 +984,22 @@ extern "C" int ppcx_testing_bench_kernel(ppcx_model* m, int which, int nchains, 
   std::vector<Cmd> cmds(nchains);
   HIPCHK(hipMemcpy(cmds.data(), dcmds, sizeof(Cmd) * nchains, hipMemcpyDeviceToHost));
   if (cmd_type) *cmd_type = cmds[0].type;
-  if (n_merge >= 0) for (int c = 0; c < nchains; ++c) if (cmds[c].type == CMD_LEAF) {
+  if (n_merge >= 0) for (int c = 0; c < nchains; ++c) {
+    // a chain still searching its step size after the warm rounds is timed on a leaf as well (the gene kernel's variants:
+    // with step-size trials among the chains the launch takes as long as their fresh momenta, whatever the others do)
+    if (which >= PPCX_BENCH_GENE && cmds[c].type == CMD_EPS_TRY) { cmds[c].type = CMD_LEAF; cmds[c].pre_dir = cmds[c].dir; cmds[c].next_dir = cmds[c].dir; cmds[c].leaf_n = 1; }
+    if (cmds[c].type != CMD_LEAF) continue;
     cmds[c].n_merge = n_merge; cmds[c].subtree_complete = 0;
     cmds[c].eps *= 1e-3;                         // keep the repeated second half kicks on a bounded trajectory
+  }
+  if (which >= PPCX_BENCH_GENE) for (int c = 0; c < nchains; ++c) {   // the gene kernel of a pipelined round: apply + close + anticipate
+    cmds[c].evaluated = 1; cmds[c].updated = 0;
+    // a plain leaf inside a subtree: the proposal copy is its only pre-operation (the command left by the warm rounds may be a
+    // transition's first leaf, whose fresh momenta -- Philox, Box-Muller -- are a thirtieth of a fit's rounds, not the typical one)
+    if (cmds[c].type == CMD_LEAF) { cmds[c].pre_flags = PRE_PROP; cmds[c].prop_slot = n_merge >= 0 ? n_merge : 0; cmds[c].prop_src = -1; }
+    if (which == PPCX_BENCH_GENE_NEW_TRANSITION && cmds[c].type == CMD_LEAF) { cmds[c].pre_flags = PRE_NEW_TRANSITION | PRE_SAVE_NEAR; cmds[c].rng_c1 = 7; }
+    if (which == PPCX_BENCH_GENE_NO_PROP) cmds[c].pre_flags &= ~PRE_PROP;   // what the kernel would cost without the proposal copies
+    if (which == PPCX_BENCH_GENE_UPDATE_ONLY) cmds[c].evaluated = 0;        // apply the command only (no close, its own constants)
   }
   HIPCHK(hipMemcpy(dcmds, cmds.data(), sizeof(Cmd) * nchains, hipMemcpyHostToDevice));
   auto one = [&]() -> int {
@@ -998,6 +1011,9 @@ extern "C" int ppcx_testing_bench_kernel(ppcx_model* m, int which, int nchains, 
       case PPCX_BENCH_STEP_REDUCE: return launch_step(m, w, nchains, io, STEP_REDUCE);
       case PPCX_BENCH_STEP_ADVANCE: return launch_step(m, w, nchains, io, STEP_ADVANCE);
       case PPCX_BENCH_STEP_UPDATE: return launch_step(m, w, nchains, io, STEP_REDUCE | STEP_ADVANCE, true);
+      case PPCX_BENCH_GENE: case PPCX_BENCH_GENE_NO_PROP: case PPCX_BENCH_GENE_UPDATE_ONLY: case PPCX_BENCH_GENE_NEW_TRANSITION:
+        return launch_gene_round(m, w, nchains, io);
+      case PPCX_BENCH_GENE_NO_SPEC: return launch_gene_round(m, w, nchains, io, 0);
       default: return launch_loglik(m, w, nchains);
     }
   };

@@ -352,11 +352,33 @@ PPCX_HD void coord_update(const Dims& d, const Cmd& nc, const VecRef& v, int i, 
 // positions (commands whose position the log-likelihood kernel has not evaluated ahead of time).
 // cache: the coordinates' end states requested ahead (coord_prefetch_for) or null; p_out / minv_out: momentum after the
 // first half kick and the metric, for a close that follows in the same thread (null: not wanted).
+// A command with pre-operations other than a leaf's inside a transition (kPreCommon: proposal / sample copies, the saved
+// near end) -- the first leaf of a transition, a step-size trial, the initial point: one command in thirty of a fit -- has ALL
+// its pre-operations done here, in a pass of its own in front of everything else the thread does, through memory; the
+// loop below then runs as for a command without pre-operations and reads what this pass stored. With the rare paths inside
+// the loop the compiler moves what its unrolled iterations share of them -- the Philox key schedule, the metric's two
+// divisions, every field of the command they read, ~70 scalars spilled to vector lanes -- in front of the loop, where every
+// command pays for it: 130 of a wavefront's 920 vector instructions and 0.6 us of the launch (round 4,
+// profiles/r04_sq_counters_gene.txt); a second copy of the loop for such commands costs the kernel its registers instead.
+// Returns the pre-operations left for the loop (coord_pre's fmask). Must run before the coordinates are prefetched.
+template <int CM>
+PPCX_HD int gene_rare_pre(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, double* draws, double* T0) {
+  if ((c.pre_flags & ~kPreCommon) == 0) return ~0;
+  constexpr int NCM = CM + 1;
+#pragma unroll
+  for (int j = 0; j < NCM; ++j) {
+    if (j < x.ncoord) { const int i = x.idx[j]; (void)coord_pre<~0>(c, v, i, i, global_flat(d, i), true, draws, d.D, c.k0, c.k1, T0); }
+  }
+  return 0;
+}
+// fmask: what gene_rare_pre returned when the caller ran it (it has to, ahead of its prefetch, when it passes a cache);
+// -1 = not run yet.
 template <int CM, bool CACHED = false>
 PPCX_HD void gene_coord_update(const Dims& d, const Cmd& c, const VecRef& v, GeneCtx<CM>& x, double* draws, double* T0,
                                const double* tab, bool consts, const CoordCache* cache = nullptr, double* p_out = nullptr,
-                               double* minv_out = nullptr, bool store_p = true) {
+                               double* minv_out = nullptr, bool store_p = true, int fmask = -1) {
   constexpr int NCM = CM + 1;
+  if (!CACHED && fmask == -1) fmask = gene_rare_pre<CM>(d, c, v, x, draws, T0);
 #pragma unroll
   for (int j = 0; j < NCM; ++j) {
     x.q[j] = 0.0;
@@ -364,8 +386,8 @@ PPCX_HD void gene_coord_update(const Dims& d, const Cmd& c, const VecRef& v, Gen
     if (j < x.ncoord) {
       const int i = x.idx[j];
       CoordVals cv;
-      if (CACHED) { const CoordCache cj = cache[j]; cv = coord_pre(c, v, i, i, global_flat(d, i), true, draws, d.D, c.k0, c.k1, T0, &cj); }
-      else cv = coord_pre(c, v, i, i, global_flat(d, i), true, draws, d.D, c.k0, c.k1, T0);
+      if (CACHED) { const CoordCache cj = cache[j]; cv = coord_pre<kPreCommon>(c, v, i, i, global_flat(d, i), true, draws, d.D, c.k0, c.k1, T0, &cj, fmask); }
+      else cv = coord_pre<kPreCommon>(c, v, i, i, global_flat(d, i), true, draws, d.D, c.k0, c.k1, T0, nullptr, fmask);
       double qn = cv.q, ph = cv.p;
       if (c.type != CMD_FLUSH) {
         if (c.eps != 0.0) {

@@ -228,6 +228,37 @@ __device__ __forceinline__ void block_accumulate(double* vals, double* wacc, int
   }
 }
 
+// Sums of up to 16 quantities over the 64 lanes of a wavefront THROUGH LDS: row k = quantity k, one column per lane, rows padded
+// to 77 doubles, a row's four runs of 16 columns to 20; lane 4 k + part adds columns 16 part .. 16 part + 15 of row k, the four parts meet by two cross-lane
+// moves, and the lanes 4 k .. 4 k + 3 end with the total of quantity k. About 25 vector instructions and 32 LDS accesses for 16 sums,
+// against 18 vector instructions PER sum of the cross-lane scan (wave_sum_to_lane63): the gene kernel spent a quarter of its 1100
+// vector instructions per wavefront in those scans (profiles/r04_sq_counters_gene.txt). Fixed order, the scan's own (below): the same bits as before.
+constexpr int kRowStride = 77, kPartStride = 20, kRowsPerWave = 16;     // 16 lanes of one access: 16 different pairs of banks
+template <int N>
+__device__ __forceinline__ void wave_sums_lds(const double* vals, double* rows, double* out /* wacc + offset */, int lane) {
+  static_assert(N >= 1 && N <= kRowsPerWave, "one batch");
+#pragma unroll
+  for (int k = 0; k < N; ++k) rows[k * kRowStride + lane + (kPartStride - 16) * (lane >> 4)] = vals[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int k = lane >> 2, part = lane & 3;
+  double t = 0.0;
+  if (k < N) {
+    // the sixteen columns in the order of the cross-lane scan this replaces (wave_sum_to_lane63: neighbours, pairs of pairs,
+    // ... -- a balanced tree), so that the sums, and with them every fit, keep the bits they had
+    const double* r = rows + k * kRowStride + kPartStride * part;
+    double b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = r[2 * j + 1] + r[2 * j];
+    t = ((b[7] + b[6]) + (b[5] + b[4])) + ((b[3] + b[2]) + (b[1] + b[0]));
+  }
+  t += dpp_take<0xB1, 0xf>(t);                 // quad_perm [1,0,3,2]: parts 0 + 1, 2 + 3
+  t += dpp_take<0x4E, 0xf>(t);                 // quad_perm [2,3,0,1]: the quad's total
+  if (k < N && part == 0) out[k] = t;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();             // the rows are free again
+}
+
 template <int CM>
 __global__ __launch_bounds__(256) void ppcx_close_kernel(CloseArgs a) {
   constexpr int NCM = CM + 1;
@@ -683,7 +714,7 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC_FAST) void ppcx_ls_kernel(Logl
 // command through a flag -- and measured: 90 us per launch against 63 + 20 for the two launches)
 template <int CM>
 __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c, int chain, int g,
-                                               double* wacc, const double* s_tab, int wave, int lane, bool do_update, bool do_close) {
+                                               double* wacc, double* rows, const double* s_tab, int wave, int lane, bool do_update, bool do_close) {
   constexpr int NCM = CM + 1;
   constexpr int NS = GeneSums<CM>::N;
   const CloseArgs& a = ga.c;
@@ -693,6 +724,10 @@ __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c,
   const bool any_generic = !d.x0_is_one || (d.C >= 2 && d.K > 0);
   GeneCtx<CM> x;
   gene_index<CM>(d, g, x);
+  // ---- a command with rare pre-operations: those first, through memory (gene_rare_pre)
+  double T0 = 0.0;
+  double* draws = ga.draws ? ga.draws + (long)chain * ga.draws_chain_stride : nullptr;
+  const int fmask = do_update ? gene_rare_pre<CM>(d, c, v, x, draws, &T0) : ~0;
   // ---- everything this lane reads is requested here, in one round trip, before anything is stored
   CoordCache cache[NCM];
   double p_cur[NCM], minv[NCM];
@@ -738,12 +773,10 @@ __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c,
     }
   }
   // ---- the command's work on the gene's coordinates
-  double T0 = 0.0;
-  double* draws = ga.draws ? ga.draws + (long)chain * ga.draws_chain_stride : nullptr;
-  if (do_update) gene_coord_update<CM, true>(d, c, v, x, draws, &T0, s_tab, !do_close, cache, p_cur, minv, !do_close);
+  if (do_update) gene_coord_update<CM, true>(d, c, v, x, draws, &T0, s_tab, !do_close, cache, p_cur, minv, !do_close, fmask);
   if (!do_close) {                             // the command's position has not been evaluated yet: nothing to close
     double t0v[1] = {T0};
-    block_accumulate<1>(t0v, wacc, wave, lane);
+    wave_sums_lds<1>(t0v, rows, wacc + wave * PT_COUNT, lane);
     return;
   }
   // ---- close the evaluated position
@@ -752,28 +785,43 @@ __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c,
   for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < d.C) ? x.q[cc + 1] : 0.0;
   x.gp.sigma_raw = x.q[1];
   x.gp.phi = phi; x.gp.invphi = 0.0; x.gp.dlt = 0.0; x.gp.dps = 0.0; x.gp.A = 0.0; x.gp.A1 = 0.0;
-  double pn[NCM], gn[NCM], part[10];
+  double pn[NCM], gn[NCM], part[16];
   gene_finish_vals<CM>(d, c, v, x, acc, gd, p_cur, minv, part, pn, gn);
   part[PT_T0] = T0;
-  block_accumulate<10>(part, wacc, wave, lane);
-  if (c.type == CMD_LEAF) {
+  double* wrow = wacc + wave * PT_COUNT;
+  if (c.type != CMD_LEAF) { wave_sums_lds<10>(part, rows, wrow, lane); return; }
+  {
     NodeVals nv[NCM];
 #pragma unroll
     for (int j = 0; j < NCM; ++j) nv[j] = NodeVals{pn[j], pn[j]};
+    // the ten sums of the leaf travel with the six U-turn products of the first level it closes (one batch of 16), the
+    // second and third level with the top-level criteria
 #pragma unroll
-    for (int lev = 0; lev < kPreLev; ++lev) {
-      if (lev < n_pre) {
-        double dots[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 6; ++k) part[10 + k] = 0.0;
+    if (n_pre > 0) {
 #pragma unroll
-        for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots_vals(pre[lev][j][0], pre[lev][j][1], pre[lev][j][2], pn[j], minv[j], &nv[j], dots);
-        block_accumulate<6>(dots, wacc + PT_DOTS + 6 * lev, wave, lane);
+      for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots_vals(pre[0][j][0], pre[0][j][1], pre[0][j][2], pn[j], minv[j], &nv[j], part + 10);
+    }
+    wave_sums_lds<16>(part, rows, wrow, lane);   // wrow[0 .. 9] the leaf, wrow[PT_DOTS .. PT_DOTS + 5] level 0 (PT_DOTS = 10)
+    static_assert(PT_DOTS == 10, "the first level's products follow the leaf's ten sums");
+    if (n_pre > 1) {
+      double two[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) two[k] = 0.0;
+#pragma unroll
+      for (int lev = 1; lev < kPreLev; ++lev) {
+        if (lev < n_pre) {
+#pragma unroll
+          for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots_vals(pre[lev][j][0], pre[lev][j][1], pre[lev][j][2], pn[j], minv[j], &nv[j], two + 6 * (lev - 1));
+        }
       }
+      wave_sums_lds<12>(two, rows, wrow + PT_DOTS + 6, lane);
     }
     for (int lev = kPreLev; lev < c.n_merge; ++lev) {
       double dots[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots(v, x.idx[j], lev, pn[j], minv[j], &nv[j], dots);
-      block_accumulate<6>(dots, wacc + PT_DOTS + 6 * lev, wave, lane);
+      wave_sums_lds<6>(dots, rows, wrow + PT_DOTS + 6 * lev, lane);
     }
     if (!c.subtree_complete) {
 #pragma unroll
@@ -782,7 +830,7 @@ __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c,
       double top[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_top_dots(v, x.idx[j], c.dir, pn[j], minv[j], nv[j], top);
-      block_accumulate<6>(top, wacc + PT_TOP, wave, lane);
+      wave_sums_lds<6>(top, rows, wrow + PT_TOP, lane);
     }
     // ahead of the state machine: the constants of the position the next leaf evaluates if the tree goes on
     if (ga.spec) gene_spec_consts<CM>(d, c, v, x, pn, gn, minv, s_tab);
@@ -806,6 +854,7 @@ template <int CM>
 __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gene_kernel(GeneArgs ga) {
   __shared__ double wacc[4 * PT_COUNT];
   __shared__ __attribute__((aligned(16))) double s_tab[2 * kLogTabSize];
+  __shared__ double s_rows[4 * kRowsPerWave * kRowStride];      // wave_sums_lds: 9.9 KB per wavefront
   const CloseArgs& a = ga.c;
   const int chain = blockIdx.y;
   // the chain's command, copied into registers HERE: read through the reference its fields would be requested where they are
@@ -818,7 +867,7 @@ __global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gen
   static_assert(2 * kLogTabSize == 512, "two table entries per thread");
   reinterpret_cast<dpair_t*>(s_tab)[tid] = reinterpret_cast<const dpair_t*>(ga.logtab)[tid];     // one 16-byte request per thread
   __syncthreads();
-  gene_wave_part<CM>(ga, c, chain, blockIdx.x * 256 + tid, wacc, s_tab, wave, lane, do_update, do_close);
+  gene_wave_part<CM>(ga, c, chain, blockIdx.x * 256 + tid, wacc, s_rows + wave * kRowsPerWave * kRowStride, s_tab, wave, lane, do_update, do_close);
   __syncthreads();
   gene_block_finish(c, do_update, do_close, wacc, a.partials + ((long)chain * gridDim.x + blockIdx.x) * PT_COUNT, tid);
 }

@@ -126,9 +126,13 @@ PPCX_HD CoordCache coord_prefetch_for(const Cmd& c, const VecRef& v, int i) {
 // `i` indexes the vectors, `flat` is the coordinate's column in this (shard's) unconstrained vector = draws column,
 // `rid` its index in the whole problem's vector = Philox stream id. i != flat only for kernel B's LDS copy of
 // the hyper coordinates; rid != flat only for gene shards.
+// MASK: the pre-operations this instantiation knows (the others are compiled out); fmask: those still to do (0 after
+// gene_rare_pre has done all of them in a pass of its own) -- see gene_coord_update.
+constexpr int kPreCommon = PRE_PROP | PRE_SAMPLE | PRE_SAVE_NEAR;      // what a leaf inside a transition can carry
+template <int MASK = ~0>
 PPCX_HD CoordVals coord_pre(const Cmd& c, const VecRef& v, int i, int flat, int rid, bool writer, double* draws, int D,
-                            uint32_t k0, uint32_t k1, double* T0, const CoordCache* cc = nullptr) {
-  const int f = c.pre_flags;
+                            uint32_t k0, uint32_t k1, double* T0, const CoordCache* cc = nullptr, int fmask = ~0) {
+  const int f = c.pre_flags & MASK & fmask;
   if (f & PRE_PROP) {
     double q_, g_;
     if (c.prop_src < 0) { q_ = cc ? cc->qe(c.pre_dir) : v.at(V_Q0 + 3 * c.pre_dir, i); g_ = cc ? cc->ge(c.pre_dir) : v.at(V_G0 + 3 * c.pre_dir, i); }

@@ -16,7 +16,12 @@ PPCX_API int ppcx_testing_set(const char* key, long long value);
  * ncclGetErrorString instead of librccl (before the first communicator is created) */
 PPCX_API int ppcx_testing_set_nccl_provider(const char* path);
 enum { PPCX_BENCH_LOGLIK = 0, PPCX_BENCH_CLOSE = 1, PPCX_BENCH_LOGLIK_CLOSE = 2, PPCX_BENCH_STEP = 3, PPCX_BENCH_UPDATE = 4,
-       PPCX_BENCH_STEP_REDUCE = 5, PPCX_BENCH_STEP_ADVANCE = 6, PPCX_BENCH_STEP_UPDATE = 7 };
+       PPCX_BENCH_STEP_REDUCE = 5, PPCX_BENCH_STEP_ADVANCE = 6, PPCX_BENCH_STEP_UPDATE = 7,
+       PPCX_BENCH_GENE = 8,           /* the gene kernel of a pipelined round on a leaf command (apply + close + anticipate) */
+       PPCX_BENCH_GENE_NO_PROP = 9,   /* the same without the proposal copy: what an index-based proposal store would save */
+       PPCX_BENCH_GENE_NO_SPEC = 10,  /* ... without the anticipated constants */
+       PPCX_BENCH_GENE_UPDATE_ONLY = 11,  /* ... the command's coordinate work only (no close) */
+       PPCX_BENCH_GENE_NEW_TRANSITION = 12 };  /* the first leaf of a transition: fresh momenta for every coordinate */
 PPCX_API int ppcx_testing_bench_kernel(ppcx_model* m, int which, int nchains, int warm_rounds, int reps, int n_merge,
                                        double* ms_per_launch, int* cmd_type);
 #ifdef __cplusplus

@@ -14,8 +14,9 @@ m.set_rounds(stream_groups=int(os.environ.get("GROUPS", 0)))
 out = []
 for seed in [int(s) for s in sys.argv[1:]]:
     t0 = time.perf_counter(); f = m.fit_nuts(chains=int(os.environ.get("CHAINS", 8)), iter=400, warmup=150, seed=seed); dt = time.perf_counter() - t0
-    tm, kt = f.timing(), f.kernel_times(); f.close()
-    out.append(dict(seed=seed, wall=round(dt, 3), grads=tm.grad_evals, us_per_round=round(1e6 * tm.seconds / max(kt["launch_triples"], 1), 2),
+    import hashlib
+    tm, kt = f.timing(), f.kernel_times(); sha = hashlib.sha1(f.diagnostics()["lp"].tobytes()).hexdigest()[:10]; f.close()
+    out.append(dict(seed=seed, wall=round(dt, 3), lp_sha=sha, grads=tm.grad_evals, us_per_round=round(1e6 * tm.seconds / max(kt["launch_triples"], 1), 2),
                     ls_us=round(1e3 * kt["loglik_ms"], 2), gene_us=round(1e3 * kt["close_ms"], 2)))
 print(json.dumps(out))
 ''' % ROOT
