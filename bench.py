@@ -152,6 +152,7 @@ def main():
     kA_ms, kA_n, kA_chains = 0.0, 0, 0.0
     ppc_obj, rounds_last, single_kt = None, 0, None
     ess_detail, depth_mean, div_total = None, [], 0
+    step_ms, stuck_fits = [], 0
     xchg_wait = (0.0, 0)
     for k in range(args.steps):
         barrier()
@@ -187,6 +188,10 @@ def main():
             kA_n += tm.gene_kernel_samples
             kA_chains += tm.gene_kernel_chain_launches_mean * tm.gene_kernel_samples
         depth_mean.append(float(dg["treedepth"].mean()))
+        step_ms.append(1e3 * dt)
+        # a chain that left warm-up with a tiny step size runs every transition to the maximum tree depth and makes the fit
+        # several times longer (2 of ~300 cfg3 fits): counted here, from this run's own fits
+        stuck_fits += int((dg["treedepth"][:, args.nuts_warmup:].mean(axis=1) > 9.0).any())
         div_total += int(dg["divergent"][:, args.nuts_warmup:].sum())
         rounds_last = kt["launch_triples"]
         if xchg is not None:
@@ -296,6 +301,8 @@ def main():
                        "ess_median_intercept_sigma_raw_rank0_chains": round(ess_gene_median, 1),
                        "grad_evals": tot_grad, "mean_treedepth": round(float(np.mean(depth_mean)), 2),
                        "divergent_after_warmup": div_total,
+                       "ms_per_step_min_max": [round(min(step_ms), 1), round(max(step_ms), 1)] if step_ms else None,
+                       "timed_fits_with_a_chain_at_max_treedepth_rank0": stuck_fits,
                        "round_structure": ("pipelined: merged log-likelihood / state-machine launch + gene kernel" if (model.get_rounds(nch)[0] and comm is None)
                                            else "three launches: log-likelihood, close, step + update"),
                        "stream_groups": args.stream_groups if args.stream_groups > 0 else ("library default (3 from eight chains on, 2 from four)" if args.mode == "chains" else 1),

@@ -37,6 +37,7 @@ extern "C" {
 #define PPCX_ERR_STEPSIZE (-4)  /* step-size heuristic left (0, 1e7) (Stan)           */
 #define PPCX_ERR_STALL (-5)     /* launch budget exhausted (internal guard)           */
 #define PPCX_ERR_LIMIT (-6)     /* size limit of this build                           */
+#define PPCX_ERR_CANCELLED (-7) /* the caller's progress callback ended the fit       */
 
 typedef struct ppcx_model ppcx_model;
 typedef struct ppcx_fit ppcx_fit;
@@ -73,8 +74,11 @@ PPCX_API int ppcx_model_set_rounds(ppcx_model* m, int pipelined, int stream_grou
    the reference's 150 warm-up iterations with a very small step size -- every transition at the maximum tree depth, DESIGN.md
    section 4 -- shows up here as one chain still running long after the others): fn(user, first_chain_of_the_group,
    chains_in_the_group, chains_done, leapfrog_rounds_issued, seconds) is called from the thread that pumps the group's launches,
-   at most every `every_seconds` and once when the group is done. NULL switches it off (default). */
-typedef void (*ppcx_progress_fn)(void* user, int first_chain, int chains, int chains_done, long long rounds, double seconds);
+   at most every `every_seconds` and once when the group is done. NULL switches it off (default).
+   The callback's return value is the caller's budget: nonzero ends the fit -- no further rounds are issued for the group, the
+   other groups end at their next report, a gene-sharded run takes its peers along as after any failure -- and the fit call
+   returns PPCX_ERR_CANCELLED with nothing to free; the model stays usable. */
+typedef int (*ppcx_progress_fn)(void* user, int first_chain, int chains, int chains_done, long long rounds, double seconds);
 PPCX_API int ppcx_model_set_progress(ppcx_model* m, ppcx_progress_fn fn, void* user, double every_seconds);
 /* what a fit of `nchains` chains of this model runs: pipelined = 1 (two launches per leapfrog: any model with X[,1] = 1 whose
    slope columns are 0 / 1 indicators -- `~ 1`, `~ Label`, formulas of factors) or 0 (three launches: continuous covariates),

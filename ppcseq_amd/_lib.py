@@ -45,7 +45,7 @@ class AdviConfig(C.Structure):
                 ("init_radius", C.c_double)]
 
 
-PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_double)
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_double)
 _lib = None
 
 
@@ -282,8 +282,9 @@ class Model:
         _check(load().ppcx_model_set_rounds(self._h, int(pipelined), int(stream_groups)))
 
     def set_progress(self, fn=None, every_seconds=1.0):
-        """fn(first_chain, chains, chains_done, rounds, seconds) during a NUTS fit of this model (None: off)."""
-        self._progress_cb = PROGRESS_FN((lambda user, c0, n, done, rounds, sec: fn(c0, n, done, rounds, sec)) if fn else 0)
+        """fn(first_chain, chains, chains_done, rounds, seconds) during a NUTS fit of this model (None: off). A true return
+        value ends the fit: the fit call raises PpcxError (PPCX_ERR_CANCELLED, -7), the model stays usable."""
+        self._progress_cb = PROGRESS_FN((lambda user, c0, n, done, rounds, sec: 1 if fn(c0, n, done, rounds, sec) else 0) if fn else 0)
         _check(load().ppcx_model_set_progress(self._h, self._progress_cb, None, float(every_seconds)))
 
     def get_rounds(self, nchains=1):

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string>
 #include <thread>
+#include <atomic>
 #include <vector>
 #include "../../include/ppcx.h"
 #include "ppcx_kernels.h"
@@ -485,6 +486,7 @@ struct Work {
   long Dpad = 0; int nb_update = 1, nb_close = 1; long launches = 0;
   hipStream_t stream = nullptr; bool own_stream = false;
   bool pipelined = false;        // two launches per round (ppcx_ls_kernel + ppcx_gene_kernel) instead of three
+  std::atomic<int>* stop = nullptr;   // shared by the chain groups of a fit: set when the progress callback ended one of them
   int *active = nullptr, *active_host = nullptr; int n_active = 0;   // chains still running (pump), 0 = all
   const XchgArgs* xchg = nullptr; int xchg_chain0 = 0;   // gene shards with the direct exchange: the group's first chain in the buffers
   ~Work() {
@@ -853,8 +855,17 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
       const auto now = std::chrono::steady_clock::now();
       if (std::chrono::duration<double>(now - t_report).count() >= sh[0].m->progress_every || n_done == nchains) {
         t_report = now;
-        sh[0].m->progress(sh[0].m->progress_user, sh[0].w->xchg_chain0, nchains, n_done, pairs, std::chrono::duration<double>(now - t_start).count());
+        const int stop = sh[0].m->progress(sh[0].m->progress_user, sh[0].w->xchg_chain0, nchains, n_done, pairs, std::chrono::duration<double>(now - t_start).count());
+        if (stop != 0 && n_done < nchains) {     // the caller's budget is spent: a local failure like any other
+          local_rc = fail(PPCX_ERR_CANCELLED, "the progress callback ended the fit");
+          if (w0.stop) w0.stop->store(1);
+          if (!guarded) { rc = local_rc; break; }
+        }
       }
+    }
+    if (w0.stop && w0.stop->load() && local_rc == PPCX_OK && n_done < nchains) {   // another chain group of this fit was ended
+      local_rc = fail(PPCX_ERR_CANCELLED, "the progress callback ended the fit");
+      if (!guarded) { rc = local_rc; break; }
     }
     if (n_done == nchains) break;
     // fewer chains in the launch: the others get their wavefronts (the list is rewritten on an idle stream: with the poll one
@@ -1204,12 +1215,14 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
   if (m->opt_stream_groups >= 1) ngrp = m->opt_stream_groups < nch ? m->opt_stream_groups : nch;
   struct Group { int c0 = 0, n = 0; Work w; RunIO io; PumpStats ps; int rc = PPCX_OK; std::string err; long long leap = 0, xticks = 0, xcount = 0; };
   std::vector<Group> grp(ngrp);
+  std::atomic<int> stop{0};
   const long long max_pairs = ((long long)iter * ((1LL << cfg->max_treedepth) + 8) + 100000) * (piped ? 2 : 1);
   for (int g = 0; g < ngrp; ++g) {
     Group& G = grp[g];
     G.w.pipelined = piped;
     G.c0 = (int)((long long)nch * g / ngrp); G.n = (int)((long long)nch * (g + 1) / ngrp) - G.c0;
     G.w.xchg_chain0 = G.c0;                    // also what a progress report names the group by
+    G.w.stop = &stop;
     if (xg && xg->nranks > 1) G.w.xchg = &xa;
     if (g > 0) { FHIP(hipStreamCreateWithFlags(&G.w.stream, hipStreamNonBlocking)); G.w.own_stream = true; }
     int rc = work_alloc(G.w, m, G.n);

@@ -303,6 +303,18 @@ def test_progress_reports_of_a_running_fit(L):
     try:
         m.set_progress(lambda c0, n, done, rounds, sec: seen.append((c0, n, done, rounds, sec)), every_seconds=0.0)
         f = m.fit_nuts(chains=4, iter=60, warmup=40, seed=2)
+        lp_whole = f.diagnostics()["lp"].copy()
+        f.close()
+        # the callback's return value is the caller's budget: a fit ended by it fails with PPCX_ERR_CANCELLED, and the model
+        # runs the next fit as if nothing had happened
+        calls = []
+        m.set_progress(lambda c0, n, done, rounds, sec: calls.append(rounds) or len(calls) >= 2, every_seconds=0.0)
+        with pytest.raises(L.PpcxError, match="-7"):
+            m.fit_nuts(chains=4, iter=60, warmup=40, seed=2)
+        assert len(calls) >= 2
+        m.set_progress(lambda c0, n, done, rounds, sec: None, every_seconds=0.0)
+        f = m.fit_nuts(chains=4, iter=60, warmup=40, seed=2)
+        assert np.array_equal(f.diagnostics()["lp"], lp_whole)
         f.close()
         m.set_progress(None)
         n_before = len(seen)
