@@ -1,5 +1,5 @@
 """Development aid: whole cfg3 fits (8 chains, 150 + 250) of several builds of the library, alternating on one box.
-usage: python scripts/gpu_fit_ab.py libA.so libB.so ... ; env ROUNDS (3), GROUPS (0 = default), CHAINS (8)
+usage: python scripts/gpu_fit_ab.py libA.so libB.so ... ; env ROUNDS (3), NGROUPS (0 = default; not GROUPS, which bash keeps for itself), CHAINS (8)
 Each (lib, seed) runs in a child process (a process binds one build)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ from ppcseq_amd import _lib as L
 from ppcseq_amd.synth import synth
 d = synth(20000, 200, seed=20253)
 m = L.Model(d["counts"], d["X"], d["exposure"], d["K"])
-m.set_rounds(stream_groups=int(os.environ.get("GROUPS", 0)))
+m.set_rounds(stream_groups=int(os.environ.get("NGROUPS", 0)))
 out = []
 for seed in [int(s) for s in sys.argv[1:]]:
     t0 = time.perf_counter(); f = m.fit_nuts(chains=int(os.environ.get("CHAINS", 8)), iter=400, warmup=150, seed=seed); dt = time.perf_counter() - t0

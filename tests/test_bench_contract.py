@@ -63,7 +63,7 @@ def test_recorded_bench_line_has_every_contract_field():
     p = d["ppc"]
     for k in ("kernel", "nb_draws", "kernel_ms", "nb_draws_per_s", "algorithmic_bytes_per_posterior_draw", "achieved", "peak", "frac", "bound"):
         assert k in p, k
-    assert p["kernel"] == "ppcx_ppc_kernel" and p["bound"] in ("alu", "hbm")
+    assert p["kernel"] in ("ppcx_ppc_kernel", "ppcx_ppc_table_kernel + ppcx_ppc_wave_kernel", "ppcx_ppc_table_kernel + ppcx_ppc_kernel") and p["bound"] in ("alu", "hbm")
     assert abs(p["nb_draws_per_s"] - p["nb_draws"] / (p["kernel_ms"] * 1e-3)) < 0.01 * p["nb_draws_per_s"]
     assert abs(p["frac"] - p["achieved"] / p["peak"]) < 1e-5
 
@@ -90,7 +90,7 @@ def test_rocprof_summary_agrees_with_the_bench_line():
     top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
     assert kernel in top["Name"]
     if int(os.path.basename(files[-1])[1:3]) >= 3:
-        assert any("ppcx_ppc_kernel" in r["Name"] for r in rows)
+        assert any("ppcx_ppc_kernel" in r["Name"] or "ppcx_ppc_wave_kernel" in r["Name"] for r in rows)
 
 
 def test_recorded_config_lines_parse():
