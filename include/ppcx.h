@@ -85,7 +85,9 @@ PPCX_API int ppcx_model_set_progress(ppcx_model* m, ppcx_progress_fn fn, void* u
    and the number of chain groups */
 PPCX_API int ppcx_model_get_rounds(const ppcx_model* m, int nchains, int* pipelined, int* stream_groups);
 /* diagnostic: the log-likelihood launch planned for `nchains` chains -- lanes per gene, workgroups per chain and the
-   gene-order positions bounds[0 .. 4 * workgroups_per_chain] delimiting the wavefronts' ranges (NULL to skip) */
+   gene-order positions bounds[0 .. 4 * workgroups_per_chain] delimiting the wavefronts' ranges (NULL to skip).
+   nchains < 0: the launch of -nchains chains of one of SEVERAL chain groups, which leaves the workgroup slots it cannot use
+   to the other groups' launches, at the lanes per gene in force (of the last fit, plan or ppcx_model_set_launch) */
 PPCX_API int ppcx_model_get_plan(ppcx_model* m, int nchains, int* lanes_per_gene, int* workgroups_per_chain, int* bounds, int cap);
 PPCX_API int ppcx_model_dim(const ppcx_model* m);          /* D = 2G + K*max(C-1,1) + 6 */
 PPCX_API void ppcx_model_destroy(ppcx_model* m);

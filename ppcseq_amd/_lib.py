@@ -212,7 +212,8 @@ class Model:
 
     def get_plan(self, nchains):
         """(lanes per gene, workgroups per chain, bounds) of the log-likelihood launch planned for `nchains` chains:
-        wavefront j of a chain walks the gene-order positions bounds[j] .. bounds[j + 1] - 1 (diagnostic)."""
+        wavefront j of a chain walks the gene-order positions bounds[j] .. bounds[j + 1] - 1 (diagnostic). nchains < 0:
+        the launch of -nchains chains of one of several chain groups, at the lanes per gene in force."""
         lanes, nb = C.c_int(), C.c_int()
         _check(load().ppcx_model_get_plan(self._h, int(nchains), C.byref(lanes), C.byref(nb), None, 0))
         b = np.zeros(4 * nb.value + 1, np.int32)

@@ -38,6 +38,8 @@ struct TestHooks {
   int force_generic = 0;                             // every gene with slopes takes the per-cell-eta path
   int no_tail_tiers = 0, plan_ignore_tiers = 0;      // timing experiments on the Stirling-tail tiers
   int slope_cost_permille = 0;                       // plan: cost of a pass with slope genes relative to a plain one (0: built-in)
+  int trim_slack_permille = -1;                      // plan: slack of a chain group's trimmed launch (-1: built-in)
+  int trim_extra_passes = 0;                         // plan: passes per wavefront of a trimmed launch beyond the fewest possible
   std::string rccl_lib;                              // another provider of the nccl* entry points (tests/loopback)
 };
 static TestHooks g_test;
@@ -150,12 +152,36 @@ static int resident_workgroups(const ppcx_model* m, int reserve) {
 }
 // workgroups per chain: all of the resident ones, a multiple of 8 (the kernel deals runs of 8 to the XCDs), not more
 // than there are passes to hand out
-static int workgroups_per_chain(const ppcx_model* m, int L, int nch, int n_res, bool whole_runs = true) {
+constexpr double kTrimSlack = 0.0;
+static int workgroups_per_chain(const ppcx_model* m, int L, int nch, int n_res, bool whole_runs = true, bool trim = false) {
   int nbpc = n_res / (nch < 1 ? 1 : nch);
   if (nbpc >= 8 && whole_runs) nbpc = nbpc / 8 * 8;
   if (nbpc < 1) nbpc = 1;
   const int gpw = 64 / L, npass = (m->d.G + gpw - 1) / gpw;
   if (nbpc > (npass + 3) / 4) nbpc = (npass + 3) / 4;
+  // trim (a launch of one of several chain groups, whose launches share the chip): ... and not more than it takes to give every
+  // wavefront the passes of the busiest one. A launch lasts as long as its wavefront with the most passes (plan_launch); with
+  // 2500 passes for 1352 wavefronts (cfg3, a chain group of three) that is two, for a sixth of the wavefronts one -- scattered
+  // by the cost balancing, so that nearly every workgroup keeps its slot for the whole launch with a wavefront less to run.
+  // 1250 wavefronts with two passes each last as long and leave 8 % of the chip's slots (39 % in a launch of two chains) to the
+  // launch of another chain group, which otherwise waits for them: cfg3, 8 chains in three groups, 2.75 -> 2.53 s per fit
+  // (round 4). A little slack (kTrimSlack) stays for the cost balancing. Alone on the chip the trimmed launch is the slower one
+  // (nobody takes the slots, and the balancing has less to work with: 3 chains 27.9 -> 30.3 us, 8 chains on one stream
+  // 2.95 -> 3.31 s per fit), so a fit on one stream keeps every resident workgroup.
+  // A gene's sums depend on the lanes per gene only: the chains do not change.
+  if (trim) {
+    double slack = kTrimSlack;
+#ifdef PPCX_TESTING
+    if (g_test.trim_slack_permille >= 0) slack = 1e-3 * g_test.trim_slack_permille;
+#endif
+    int maxp = (npass + 4 * nbpc - 1) / (4 * nbpc);
+#ifdef PPCX_TESTING
+    maxp += g_test.trim_extra_passes;
+#endif
+    int nb2 = (int)ceil((double)npass * (1.0 + slack) / (4.0 * maxp));
+    if (nb2 >= 8 && whole_runs) nb2 = (nb2 + 7) / 8 * 8;
+    if (nb2 < nbpc) nbpc = nb2;
+  }
   return nbpc;
 }
 // chain groups on their own streams (ppcx_fit_nuts): the default for a fit of `nch` chains
@@ -199,16 +225,16 @@ static void drop_plans(ppcx_model* m) {
   m->plans.clear();
 }
 // the ranges for a launch of `nch` chains beside `reserve` other workgroups
-static int plan_launch(ppcx_model* m, int nch, int reserve, ppcx_model::Plan* out) {
+static int plan_launch(ppcx_model* m, int nch, int reserve, ppcx_model::Plan* out, bool trim = false) {
   std::lock_guard<std::mutex> lk(m->plan_mutex);
   const int n_res = resident_workgroups(m, reserve);
-  const auto key = std::make_pair(nch, n_res);
+  const auto key = std::make_pair(nch, trim ? -n_res : n_res);   // (a trimmed plan under its own key)
   auto it = m->plans.find(key);
   if (it != m->plans.end()) { *out = it->second; return PPCX_OK; }
   const int G = m->d.G, L = m->L, gpw = 64 / L;
   // beside state machines (reserve > 0) the last run of the launch may be partial: their slots and the range blocks
   // together fill the chip
-  const int nbpc = workgroups_per_chain(m, L, nch, n_res, reserve == 0), wpc = 4 * nbpc, npass = (G + gpw - 1) / gpw;
+  const int nbpc = workgroups_per_chain(m, L, nch, n_res, reserve == 0, trim), wpc = 4 * nbpc, npass = (G + gpw - 1) / gpw;
   std::vector<double> cost(npass);
   double total = 0;
   for (int k = 0; k < npass; ++k) {
@@ -443,11 +469,14 @@ extern "C" int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, i
 // bounds[0 .. 4 * workgroups_per_chain] that delimit the wavefronts' ranges (bounds may be NULL; `cap` entries at most).
 // A diagnostic: tests check its invariants, nothing in the product path reads it back.
 extern "C" int ppcx_model_get_plan(ppcx_model* m, int nchains, int* lanes_per_gene, int* workgroups_per_chain, int* bounds, int cap) {
-  if (!m || nchains < 1) return fail(PPCX_ERR_ARG, "bad arguments");
+  if (!m || nchains == 0) return fail(PPCX_ERR_ARG, "bad arguments");
   HIPCHK(hipSetDevice(m->device));
-  choose_launch(m, nchains);
+  // nchains < 0: the launch of -nchains chains of ONE of several chain groups (trimmed: workgroups_per_chain), at the lanes
+  // per gene in force -- those of the fit, chosen for all its chains
+  const bool trim = nchains < 0;
+  if (trim) nchains = -nchains; else choose_launch(m, nchains);
   ppcx_model::Plan pl;
-  const int rc = plan_launch(m, nchains, 0, &pl);
+  const int rc = plan_launch(m, nchains, 0, &pl, trim);
   if (rc != PPCX_OK) return rc;
   if (lanes_per_gene) *lanes_per_gene = m->L;
   if (workgroups_per_chain) *workgroups_per_chain = pl.nbpc;
@@ -486,6 +515,7 @@ struct Work {
   long Dpad = 0; int nb_update = 1, nb_close = 1; long launches = 0;
   hipStream_t stream = nullptr; bool own_stream = false;
   bool pipelined = false;        // two launches per round (ppcx_ls_kernel + ppcx_gene_kernel) instead of three
+  bool shared_chip = false;      // one of several chain groups of a fit: its launches leave the slots they cannot use (workgroups_per_chain)
   std::atomic<int>* stop = nullptr;   // shared by the chain groups of a fit: set when the progress callback ended one of them
   int *active = nullptr, *active_host = nullptr; int n_active = 0;   // chains still running (pump), 0 = all
   const XchgArgs* xchg = nullptr; int xchg_chain0 = 0;   // gene shards with the direct exchange: the group's first chain in the buffers
@@ -595,7 +625,7 @@ static int step_runs(int nchains, int nact) { return (nchains + nact - 1) / nact
 static int loglik_args(ppcx_model* m, Work& w, int nchains, int reserve, LoglikArgs* out) {
   const int nact = w.n_active > 0 ? w.n_active : nchains;
   ppcx_model::Plan pl;
-  int rc = plan_launch(m, nact, reserve, &pl);
+  int rc = plan_launch(m, nact, reserve, &pl, w.shared_chip);
   if (rc != PPCX_OK) return rc;
   LoglikArgs& la = *out;
   la.d = m->d; la.cd.counts = m->d_counts; la.cd.low = m->d_low; la.cd.low_start = m->d_low_start; la.cd.n_hi = m->d_nhi; la.cd.low_m = m->d_low_m; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
@@ -956,6 +986,8 @@ extern "C" int ppcx_testing_set(const char* key, long long value) {
   else if (k == "no_tail_tiers") g_test.no_tail_tiers = (int)value;
   else if (k == "plan_ignore_tiers") g_test.plan_ignore_tiers = (int)value;
   else if (k == "slope_cost_permille") g_test.slope_cost_permille = (int)value;
+  else if (k == "trim_slack_permille") g_test.trim_slack_permille = (int)value;
+  else if (k == "trim_extra_passes") g_test.trim_extra_passes = (int)value;
   else return fail(PPCX_ERR_ARG, "unknown test hook " + k);
   return PPCX_OK;
 }
@@ -1223,6 +1255,7 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
     G.c0 = (int)((long long)nch * g / ngrp); G.n = (int)((long long)nch * (g + 1) / ngrp) - G.c0;
     G.w.xchg_chain0 = G.c0;                    // also what a progress report names the group by
     G.w.stop = &stop;
+    G.w.shared_chip = ngrp > 1;
     if (xg && xg->nranks > 1) G.w.xchg = &xa;
     if (g > 0) { FHIP(hipStreamCreateWithFlags(&G.w.stream, hipStreamNonBlocking)); G.w.own_stream = true; }
     int rc = work_alloc(G.w, m, G.n);

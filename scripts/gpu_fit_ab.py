@@ -1,5 +1,5 @@
 """Development aid: whole cfg3 fits (8 chains, 150 + 250) of several builds of the library, alternating on one box.
-usage: python scripts/gpu_fit_ab.py libA.so libB.so ... ; env ROUNDS (3), NGROUPS (0 = default; not GROUPS, which bash keeps for itself), CHAINS (8)
+usage: python scripts/gpu_fit_ab.py libA.so libB.so ... ; env ROUNDS (3), TRIM (testing build: trim_slack_permille), NGROUPS (0 = default; not GROUPS, which bash keeps for itself), CHAINS (8)
 Each (lib, seed) runs in a child process (a process binds one build)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +8,10 @@ import sys, os, time, json
 sys.path.insert(0, %r)
 from ppcseq_amd import _lib as L
 from ppcseq_amd.synth import synth
+if os.environ.get("TRIM"):                      # testing build: slack of a chain group's trimmed launch, per mille
+    L.testing_set("trim_slack_permille", int(os.environ["TRIM"]))
+if os.environ.get("TRIM_EXTRA"):
+    L.testing_set("trim_extra_passes", int(os.environ["TRIM_EXTRA"]))
 d = synth(20000, 200, seed=20253)
 m = L.Model(d["counts"], d["X"], d["exposure"], d["K"])
 m.set_rounds(stream_groups=int(os.environ.get("NGROUPS", 0)))

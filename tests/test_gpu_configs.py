@@ -449,6 +449,13 @@ def test_launch_plan_invariants(L, G, S, K):
             pmax = -(-npass // wpc)
             assert np.max(-(-np.diff(b) // gpw)) <= pmax, (nch, lanes, nb)
             assert nb * nch <= max(4 * 256, nch)               # resident workgroups of the chip (4 per CU), or one per chain
+            # the launch of one of several chain groups: not more workgroups than it takes to give every wavefront the passes
+            # of the busiest one -- the same number of passes at most, the same tiling, the slots left to the other groups
+            lanes_t, nb_t, bt = m.get_plan(-nch)
+            assert lanes_t == lanes and nb_t <= nb
+            assert bt[0] == 0 and bt[-1] == G and np.all(np.diff(bt) >= 0)
+            assert -(-npass // (4 * nb_t)) == pmax and np.max(-(-np.diff(bt) // gpw)) <= pmax, (nch, lanes, nb, nb_t)
+            assert nb_t == nb or 4 * (nb_t - 8) * pmax < npass        # trimmed to the fewest (whole runs of 8 workgroups)
     finally:
         m.close()
 
