@@ -229,11 +229,11 @@ __device__ __forceinline__ void block_accumulate(double* vals, double* wacc, int
 }
 
 // Sums of up to 16 quantities over the 64 lanes of a wavefront THROUGH LDS: row k = quantity k, one column per lane, rows padded
-// to 77 doubles, a row's four runs of 16 columns to 20; lane 4 k + part adds columns 16 part .. 16 part + 15 of row k, the four parts meet by two cross-lane
+// to 65 doubles; lane 4 k + part adds columns 16 part .. 16 part + 15 of row k, the four parts meet by two cross-lane
 // moves, and the lanes 4 k .. 4 k + 3 end with the total of quantity k. About 25 vector instructions and 32 LDS accesses for 16 sums,
 // against 18 vector instructions PER sum of the cross-lane scan (wave_sum_to_lane63): the gene kernel spent a quarter of its 1100
 // vector instructions per wavefront in those scans (profiles/r04_sq_counters_gene.txt). Fixed order, the scan's own (below): the same bits as before.
-constexpr int kRowStride = 77, kPartStride = 20, kRowsPerWave = 16;     // 16 lanes of one access: 16 different pairs of banks
+constexpr int kRowStride = 65, kPartStride = 16, kRowsPerWave = 16;     // 39 808 bytes of LDS per gene workgroup: four per CU (below)
 template <int N>
 __device__ __forceinline__ void wave_sums_lds(const double* vals, double* rows, double* out /* wacc + offset */, int lane) {
   static_assert(N >= 1 && N <= kRowsPerWave, "one batch");
@@ -745,7 +745,7 @@ __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c,
   for (int cc = 0; cc < CM; ++cc) acc.Tx[cc] = 0.0;
   GeneData gd;
   double phi = 1.0;
-  constexpr int kPreLev = 3;
+  constexpr int kPreLev = 2;                   // tree levels whose slots travel with the burst of loads (a third: 18 registers; see the kernel)
   double pre[kPreLev][NCM][3];
   const int n_pre = (do_close && c.type == CMD_LEAF) ? (c.n_merge < kPreLev ? c.n_merge : kPreLev) : 0;
   if (do_close) {
@@ -795,7 +795,7 @@ __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c,
 #pragma unroll
     for (int j = 0; j < NCM; ++j) nv[j] = NodeVals{pn[j], pn[j]};
     // the ten sums of the leaf travel with the six U-turn products of the first level it closes (one batch of 16), the
-    // second and third level with the top-level criteria
+    // further prefetched levels in a batch of their own
 #pragma unroll
     for (int k = 0; k < 6; ++k) part[10 + k] = 0.0;
     if (n_pre > 0) {
@@ -804,18 +804,19 @@ __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c,
     }
     wave_sums_lds<16>(part, rows, wrow, lane);   // wrow[0 .. 9] the leaf, wrow[PT_DOTS .. PT_DOTS + 5] level 0 (PT_DOTS = 10)
     static_assert(PT_DOTS == 10, "the first level's products follow the leaf's ten sums");
-    if (n_pre > 1) {
-      double two[12];
+    if constexpr (kPreLev > 1) if (n_pre > 1) {
+      constexpr int NB = 6 * (kPreLev - 1);
+      double more[NB];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) two[k] = 0.0;
+      for (int k = 0; k < NB; ++k) more[k] = 0.0;
 #pragma unroll
       for (int lev = 1; lev < kPreLev; ++lev) {
         if (lev < n_pre) {
 #pragma unroll
-          for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots_vals(pre[lev][j][0], pre[lev][j][1], pre[lev][j][2], pn[j], minv[j], &nv[j], two + 6 * (lev - 1));
+          for (int j = 0; j < NCM; ++j) if (j < x.ncoord) coord_merge_dots_vals(pre[lev][j][0], pre[lev][j][1], pre[lev][j][2], pn[j], minv[j], &nv[j], more + 6 * (lev - 1));
         }
       }
-      wave_sums_lds<12>(two, rows, wrow + PT_DOTS + 6, lane);
+      wave_sums_lds<NB>(more, rows, wrow + PT_DOTS + 6, lane);
     }
     for (int lev = kPreLev; lev < c.n_merge; ++lev) {
       double dots[6] = {0, 0, 0, 0, 0, 0};
@@ -850,11 +851,19 @@ __device__ __forceinline__ void gene_block_finish(const Cmd& c, bool do_update, 
   }
 }
 
+// Register budget of the two-column instantiation: 128 vector registers, four wavefronts per SIMD -- what a log-likelihood
+// wavefront holds. In a fit with chain groups this kernel starts while another group's log-likelihood wavefronts, four to a SIMD,
+// own every register of the chip: a wavefront of 128 registers moves in as soon as ONE of them retires, a wavefront of 146 (152
+// allocated: what the body took with three prefetched tree levels) only after two on the same SIMD have, and this kernel is what
+// its group's next log-likelihood launch waits for. cfg3, 8 chains in three groups (round 4, five seeds, alternating builds):
+// 2.52 s per fit with 146 registers, 2.41 s with 128 and 36 of them spilled, 2.35 s with two prefetched levels instead of three
+// (kPreLev: 128 registers without a spill; alone on the chip as fast as before, 2.94 s on one stream, 1.03 s a lone chain).
+// (Four columns: 230 registers; 168 or 128 with 120 / 202 spilled made the factor design's fits 7 % / 14 % slower.)
 template <int CM>
-__global__ __launch_bounds__(256, CM <= 2 ? 3 : (CM <= 4 ? 2 : 1)) void ppcx_gene_kernel(GeneArgs ga) {
+__global__ __launch_bounds__(256, CM <= 2 ? 4 : (CM <= 4 ? 2 : 1)) void ppcx_gene_kernel(GeneArgs ga) {
   __shared__ double wacc[4 * PT_COUNT];
   __shared__ __attribute__((aligned(16))) double s_tab[2 * kLogTabSize];
-  __shared__ double s_rows[4 * kRowsPerWave * kRowStride];      // wave_sums_lds: 9.9 KB per wavefront
+  __shared__ double s_rows[4 * kRowsPerWave * kRowStride];      // wave_sums_lds: 8.3 KB per wavefront
   const CloseArgs& a = ga.c;
   const int chain = blockIdx.y;
   // the chain's command, copied into registers HERE: read through the reference its fields would be requested where they are
