@@ -197,7 +197,8 @@ static void choose_launch(ppcx_model* m, int nchains) {
   // (Choosing L for the chain groups a fit runs in -- launches of a third of the chains, whose idle slots other groups fill:
   // L = 4 at 7 and 8 chains, one pass of 16 genes per wavefront -- made regular 8-chain fits 9 % faster, 2.75 -> 2.50 s, but of
   // 61 seeds two ended warm-up with a chain at tree depth 10 (13.5 and 4.8 s; none of 233 fits with L = 8 did; Fisher p = 0.04):
-  // the means over all fits tried are 2.72 and 2.75 s. Not adopted)
+  // the means over all fits tried are 2.72 and 2.75 s. Not adopted; DESIGN section 3. Round 4, with the groups' launches trimmed to
+  // whole passes: L = 4 gains nothing any more -- 2.40-2.47 s against 2.35 s over the driver's seeds for all 8 ranks, one of 200 stuck.)
   const double slots = 4.0 * (double)resident_workgroups(m, 0);
   int bestL = 64, bestL_any = 64; double best = 1e300, best_any = 1e300;
   for (int L = 1; L <= 64; L <<= 1) {

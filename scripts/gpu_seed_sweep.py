@@ -7,6 +7,8 @@ from ppcseq_amd import _lib as L
 from ppcseq_amd.synth import synth
 d = synth(20000, 200, seed=20253)
 m = L.Model(d["counts"], d["X"], d["exposure"], d["K"])
+if os.environ.get("LANES"):                    # lanes per gene of the log-likelihood launch (default: the library's choice)
+    m.set_launch(int(os.environ["LANES"]), 0)
 for seed in [int(x) for x in os.environ.get("SEEDS", "1,2,3,4,5,6,7,8,9,10,11,12").split(",")]:
     t0 = time.perf_counter()
     f = m.fit_nuts(chains=8, iter=400, warmup=150, seed=seed, chain_id_offset=int(os.environ.get("OFFSET", 0)))
