@@ -165,7 +165,8 @@ static int workgroups_per_chain(const ppcx_model* m, int L, int nch, int n_res, 
   // by the cost balancing, so that nearly every workgroup keeps its slot for the whole launch with a wavefront less to run.
   // 1250 wavefronts with two passes each last as long and leave 8 % of the chip's slots (39 % in a launch of two chains) to the
   // launch of another chain group, which otherwise waits for them: cfg3, 8 chains in three groups, 2.75 -> 2.53 s per fit
-  // (round 4). A little slack (kTrimSlack) stays for the cost balancing. Alone on the chip the trimmed launch is the slower one
+  // (round 4). No slack beyond the whole run of 8 workgroups pays (kTrimSlack: 0 / 1.5 / 3 / 6 / 12 % -> 2.55 / 2.55 / 2.58 / 2.62 /
+  // 2.66 s), nor a pass more per wavefront on fewer workgroups (2.82 s). Alone on the chip the trimmed launch is the slower one
   // (nobody takes the slots, and the balancing has less to work with: 3 chains 27.9 -> 30.3 us, 8 chains on one stream
   // 2.95 -> 3.31 s per fit), so a fit on one stream keeps every resident workgroup.
   // A gene's sums depend on the lanes per gene only: the chains do not change.
