@@ -433,6 +433,30 @@ def test_a_chain_does_not_depend_on_the_chains_it_shares_launches_with(L, monkey
         m.close()
 
 
+def test_cfg3_chain_groups_run_the_single_stream_chains(L):
+    """At BASELINE size: a fit in chain groups -- whose launches are trimmed to whole passes per wavefront and share the chip with
+    the other groups'  -- gives every chain the draws it has on one stream, bit for bit."""
+    G, S = CONFIGS["cfg3"][0], CONFIGS["cfg3"][1]
+    d = ind.synth(G, S, seed=CONFIGS["cfg3"][2])
+    m = L.Model(d["counts"], d["X"], d["exposure"], d["K"])
+    try:
+        m.set_launch(8, 0)                                               # the lanes per gene of an 8-chain fit, for every fit below
+        kw = dict(chains=5, iter=45, warmup=30, seed=11)
+        m.set_rounds(stream_groups=1)
+        f = m.fit_nuts(**kw); lp1, n1 = f.diagnostics()["lp"].copy(), f.diagnostics()["n_leapfrog"].copy(); f.close()
+        for groups in (2, 3):
+            m.set_rounds(stream_groups=groups)
+            assert m.get_rounds(5) == (True, groups)
+            f = m.fit_nuts(**kw)
+            assert np.array_equal(f.diagnostics()["n_leapfrog"], n1) and np.array_equal(f.diagnostics()["lp"], lp1), groups
+            f.close()
+        lanes, nb, _ = m.get_plan(2)
+        lanes_t, nb_t, _ = m.get_plan(-2)
+        assert lanes_t == 8 and nb_t < nb                                # the groups' launches really are the trimmed ones here
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("G,S,K", [(20000, 200, 1000), (5000, 50, 250), (300, 12, 20), (7, 3, 2)])
 def test_launch_plan_invariants(L, G, S, K):
     """The host's plan of a log-likelihood launch: the wavefronts' ranges tile the gene order and none holds more passes
