@@ -274,6 +274,9 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(chains_per_launch), "fp64_issue": issue_profile(),
                     "algorithmic_bytes_per_launch": b_grad * chains_per_launch, "avg_launch_ms": round(ms, 5),
                     "timed_launches": int(kA_n),
+                    "measured_by_this_run": ["achieved", "frac", "avg_launch_ms", "timed_launches"],
+                    "from_committed_profiles": {"traffic": "profiles/rNN_pmc.json (rocprofv3 --pmc passes of the same command: counters need their own runs)",
+                                                "fp64_issue": "profiles/rNN_loglik_issue.json (SQ counters; `stale` says whether the kernel sources have changed since)"},
                     "sampled_in": "a fit on one in-order stream (stream_groups = 1) after the timed fits" if args.mode == "chains" else "the timed fits",
                     "note": "achieved = algorithmic bytes (SURVEY 8d: count matrix + coordinates, per chain gradient) x chains per "
                             "launch / launch time: an effective-throughput figure. ppcx_ls_kernel is the merged launch of a "
