@@ -3,7 +3,7 @@
 // oracle/ppc_oracle.c is a literal restatement of the Stan program (libm lgamma, series digamma and a log1p_exp per
 // cell: ~500 ns per cell and thread), which makes "GPU vs CPU" ratios meaningless as a bar. This file evaluates the
 // same log density and gradient (inst/stan/negBinomial_MPI.stan:58-120,:180-240) the way the PRODUCT formulates it
-// -- per-gene sufficient statistics, one table logarithm and one reciprocal per cell, Stirling tails, low-count lists:
+// -- per-gene sufficient statistics, one table logarithm and one reciprocal per cell, per-gene dispersion tables:
 // the __host__ __device__ headers of ppcseq_amd/csrc compiled for the host -- with OpenMP threads over genes
 // (mirrors map_rect / STAN_NUM_THREADS, R/utilities.R:1383-1386,1479), built -O3 -march=native.
 // Only bench.py (cpu_baseline) and tests/ load it; the product package never does.
@@ -22,7 +22,7 @@ using namespace ppcx;
 struct FastModel {
   Dims d; int CM;
   std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, SX, ncell, Lg1, tab;
-  std::vector<unsigned> low; std::vector<int> low_start, nhi; std::vector<unsigned short> low_m;
+  std::vector<double> disp; std::vector<unsigned char> gflags;     // dispersion tables (ppcx_disp.h), bit 0: excluded cells
   std::vector<double> vecs, hv;
   int threads = 1;                 // of ppcf_lp_callback
 };
@@ -40,18 +40,17 @@ void* ppcf_model_create(int G, int S, int C, int K, const int32_t* counts, const
   for (size_t i = (size_t)S; i < (size_t)S * C && x1b; ++i) if (X[i] != 0.0 && X[i] != 1.0) x1b = 0;
   m->d.x1_binary = x1b;
   m->Sy.assign(G, 0); m->SyE.assign(G, 0); m->SyX.assign((size_t)C * G, 0); m->SX.assign((size_t)C * G, 0); m->ncell.assign(G, 0); m->Lg1.assign(G, 0);
-  m->low_start.assign(G + 1, 0); m->nhi.assign(G, 0); m->low_m.assign((size_t)G * 8, 0);
+  m->gflags.assign(G, 0); m->disp.assign((size_t)G * kDispGeneDoubles, 0.0);
+  DispFit fit; disp_fit_init(fit);
+#pragma omp parallel for schedule(dynamic, 16)
   for (int g = 0; g < G; ++g) {
-    int ymin = 2147483647; m->low_start[g] = (int)m->low.size();
     for (int s = 0; s < S; ++s) {
       const int y = m->counts[(size_t)g * S + s];
-      if (y < kLowCount) { m->low.push_back(((unsigned)y << 16) | (unsigned)s); for (int k = 0; k < y; ++k) m->low_m[(size_t)g * 8 + k]++; } else { m->nhi[g]++; if (y < ymin) ymin = y; }
       m->Sy[g] += y; m->SyE[g] += (double)y * expo[s]; m->ncell[g] += 1; m->Lg1[g] += lgamma((double)y + 1.0);
       for (int c = 0; c < C; ++c) { m->SyX[(size_t)c * G + g] += (double)y * X[(size_t)c * S + s]; m->SX[(size_t)c * G + g] += X[(size_t)c * S + s]; }
     }
-    m->nhi[g] |= gene_tier(ymin, m->nhi[g], S) << 28;
+    disp_build_gene_host(fit, m->counts.data() + (size_t)g * S, S, m->disp.data() + (size_t)g * kDispGeneDoubles);
   }
-  m->low_start[G] = (int)m->low.size(); m->low.resize(m->low.size() + 64, 0u);
   m->tab.resize(2 * kLogTabSize); fill_log_table(m->tab.data());
   m->vecs.assign((size_t)V_COUNT * m->d.D, 0.0); m->hv.assign((size_t)V_COUNT * 8, 0.0);
   return m;
@@ -68,7 +67,7 @@ static double eval(FastModel& m, const double* u, double* grad, int threads) {
   for (int k = 0; k < 6; ++k) c.hyp_q[k] = u[hyper_index(d, k)];
   c.hy = make_hyper(c.hyp_q, d.lambda_mu_mu);
   const double* tab = m.tab.data();
-  CellData cd; cd.counts = m.counts.data(); cd.low = m.low.data(); cd.low_start = m.low_start.data(); cd.n_hi = m.nhi.data(); cd.low_m = m.low_m.data();
+  CellData cd; cd.counts = m.counts.data(); cd.disp = m.disp.data(); cd.gflags = m.gflags.data();
   double lp = 0.0, h[6] = {0, 0, 0, 0, 0, 0};
 #pragma omp parallel for schedule(static) num_threads(threads) reduction(+ : lp, h[:6])
   for (int g = 0; g < d.G; ++g) {
@@ -77,7 +76,7 @@ static double eval(FastModel& m, const double* u, double* grad, int threads) {
     for (int j = 0; j < x.ncoord; ++j) {                       // what the update kernel leaves next to the coordinates
       const int i = x.idx[j];
       v.at(V_Q1, i) = u[i]; v.at(V_P1, i) = 0.0; v.at(V_MINV, i) = 1.0;
-      coord_consts(d, v, i, u[i], tab);
+      coord_consts(d, v, i, u[i]);
     }
     GeneSumsV<CM> o;
     lane_gene_sums<CM, 1>(d, c, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), tab, o);

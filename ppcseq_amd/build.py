@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libppcx.so")
 # with the tests, not in the package
 TESTING_LIB = os.path.join(os.path.dirname(HERE), "tests", "libppcx_testing.so")
 SOURCES = ["ppcx_kernels.hip", "ppcx_capi.hip"]
-HEADERS = ["ppcx_math.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h", "ppcx_kernels.h", "ppcx_testing.h",
+HEADERS = ["ppcx_math.h", "ppcx_disp.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h", "ppcx_kernels.h", "ppcx_testing.h",
            os.path.join("..", "..", "include", "ppcx.h")]
 
 

@@ -36,7 +36,6 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct TestHooks {
   long long fail_at_round = 0; int fail_rank = -1;   // fault injection into the pump of a gene-sharded run
   int force_generic = 0;                             // every gene with slopes takes the per-cell-eta path
-  int no_tail_tiers = 0, plan_ignore_tiers = 0;      // timing experiments on the Stirling-tail tiers
   int slope_cost_permille = 0;                       // plan: cost of a pass with slope genes relative to a plain one (0: built-in)
   int trim_slack_permille = -1;                      // plan: slack of a chain group's trimmed launch (-1: built-in)
   int trim_extra_passes = 0;                         // plan: passes per wavefront of a trimmed launch beyond the fewest possible
@@ -58,9 +57,9 @@ struct ppcx_model {
   int opt_pipelined = -1, opt_stream_groups = 0;
   // progress reports of a running fit (ppcx_model_set_progress): the pump calls it at a poll, at most every progress_every s
   ppcx_progress_fn progress = nullptr; void* progress_user = nullptr; double progress_every = 1.0;
-  // gene order of the log-likelihood launch (upload_counts): per position, the length of the gene's low-count list
-  // and whether it has slopes -- what a pass of a wavefront costs (plan_launch)
-  std::vector<int> pos_low; std::vector<char> pos_slope, pos_tier;
+  // gene order of the log-likelihood launch (upload_counts): per position, whether the gene has slopes -- what a pass of a
+  // wavefront costs (plan_launch)
+  std::vector<char> pos_slope;
   struct Plan { int nbpc = 0; int* d_bounds = nullptr; };
   std::map<std::pair<int, int>, Plan> plans;   // (chains in the launch, resident workgroups it may use) -> ranges
   std::mutex plan_mutex;
@@ -68,9 +67,9 @@ struct ppcx_model {
   std::vector<double> X_host, expo_host;
   int* d_counts = nullptr;
   double *d_E = nullptr, *d_expo = nullptr, *d_X = nullptr, *d_Sy = nullptr, *d_SyE = nullptr, *d_SyX = nullptr, *d_SX = nullptr, *d_ncell = nullptr, *d_Lg1 = nullptr;
-  unsigned* d_low = nullptr; size_t low_cap = 0;   // low-count cell list (ppcx_gene.h low_cells) and its capacity
-  int *d_low_start = nullptr, *d_nhi = nullptr;
-  unsigned short* d_low_m = nullptr;           // [G][8] entry k < 7: number of list cells with count > k
+  double* d_disp = nullptr;                    // [G][kDispGeneDoubles] the genes' dispersion tables (ppcx_disp.h)
+  unsigned char* d_gflags = nullptr;           // [G] bit 0: the gene has excluded cells
+  DispFit fit;                                 // nodes and transforms of the table build
   double* d_logtab = nullptr;
   int* d_order = nullptr;        // gene_order: position in the log-likelihood kernel's launch -> gene
   hipStream_t stream = nullptr;
@@ -122,15 +121,8 @@ extern "C" int ppcx_device_memory(int device, unsigned long long* free_bytes, un
 //   cost crosses j / (wavefronts per chain) of the total; recomputed when chains finish and the others get their slots.
 static double pass_cost(const ppcx_model* m, int L, int p, int n) {
   const int S = m->d.S;
-  int lowmax = 0, tier = 2; bool slope = false;
-  for (int i = p; i < p + n; ++i) { if (m->pos_low[i] > lowmax) lowmax = m->pos_low[i]; slope = slope || m->pos_slope[i]; if (m->pos_tier[i] < tier) tier = m->pos_tier[i]; }
-  // a pass of plain genes that all allow shorter Stirling tails saves 4 (tier 1) or 6 (tier 2) of the ~44 instructions of a cell-iteration
-#ifdef PPCX_TESTING
-  const bool ignore_tiers = g_test.plan_ignore_tiers != 0;
-#else
-  const bool ignore_tiers = false;
-#endif
-  const double tail = (slope || ignore_tiers) ? 1.0 : (tier >= 2 ? 0.86 : (tier >= 1 ? 0.91 : 1.0));
+  bool slope = false;
+  for (int i = p; i < p + n; ++i) slope = slope || m->pos_slope[i];
   // a pass of genes with slopes: 1.15 x a plain one in a two-group design. With more indicator columns it costs 1.43 x (C = 3, all
   // genes with slopes against none: 83.9 vs 58.4 us per launch) -- but weighting it so makes the launch SLOWER (K = 1000 of 20 000
   // genes: weight 1.0 -> 63.4 us, 1.45 -> 67.5, 2.0 -> 72.8; scripts/gpu_factor_k.py): the four wavefronts of a SIMD come from four
@@ -140,8 +132,8 @@ static double pass_cost(const ppcx_model* m, int L, int p, int n) {
 #ifdef PPCX_TESTING
   if (g_test.slope_cost_permille > 0) slope_w = 1e-3 * g_test.slope_cost_permille;
 #endif
-  const double sweep = (double)((S + L - 1) / L) * tail * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? slope_w : 1.0));
-  return 5.8 + sweep + 0.75 * (double)((lowmax + L - 1) / L);
+  const double sweep = (double)((S + L - 1) / L) * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? slope_w : 1.0));
+  return 5.8 + sweep;
 }
 // reserve: workgroups of the same launch that are not log-likelihood workgroups (the state machines of a pipelined
 // round's merged launch; they are dispatched first and resident for a part of the launch)
@@ -280,67 +272,49 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
     cnt[excl[e]] = -1;
   }
   std::vector<double> Sy(G, 0.0), SyE(G, 0.0), SyX((size_t)C * G, 0.0), SX((size_t)C * G, 0.0), ncell(G, 0.0), Lg1(G, 0.0);
-  std::vector<unsigned> low; std::vector<int> low_start(G + 1, 0), nhi(G, 0);
-  std::vector<unsigned short> low_m((size_t)G * 8, 0);
-  std::vector<int> tier(G, 0);
+  std::vector<unsigned char> gflags(G, 0);
   for (int g = 0; g < G; ++g) {
     double sy = 0, sye = 0, nc = 0, lg1 = 0;
-    int ymin = 2147483647;                       // smallest count among the row-sweep cells
-    low_start[g] = (int)low.size();
     for (int s = 0; s < S; ++s) {
       const int y = cnt[(size_t)g * S + s];
-      if (y < 0) continue;
+      if (y < 0) { gflags[g] |= 1; continue; }
       sy += y; sye += (double)y * m->expo_host[s]; nc += 1.0; lg1 += lgamma((double)y + 1.0);
-      if (y < kLowCount) { low.push_back(((unsigned)y << 16) | (unsigned)s); for (int k = 0; k < y; ++k) low_m[(size_t)g * 8 + k]++; } else { nhi[g]++; if (y < ymin) ymin = y; }
       for (int c = 0; c < C; ++c) { SyX[(size_t)c * G + g] += (double)y * m->X_host[(size_t)c * S + s]; SX[(size_t)c * G + g] += m->X_host[(size_t)c * S + s]; }
     }
     Sy[g] = sy; SyE[g] = sye; ncell[g] = nc; Lg1[g] = lg1;
-    tier[g] = gene_tier(ymin, nhi[g], S);
-#ifdef PPCX_TESTING
-    if (g_test.no_tail_tiers) tier[g] = 0;                   // every pass with the full tails
-#endif
-    nhi[g] |= tier[g] << 28;                                 // CellData::n_hi
   }
-  low_start[G] = (int)low.size();
-  low.resize(low.size() + 64, 0u);             // the cell loops request the next entry before testing the range
-  if (low.size() > m->low_cap) {
-    (void)hipFree(m->d_low); m->d_low = nullptr; m->low_cap = 0;
-    HIPCHK(hipMalloc(&m->d_low, sizeof(unsigned) * low.size()));
-    m->low_cap = low.size();
-  }
-  HIPCHK(hipMemcpy(m->d_low, low.data(), sizeof(unsigned) * low.size(), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(m->d_low_start, low_start.data(), sizeof(int) * (size_t)(G + 1), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(m->d_nhi, nhi.data(), sizeof(int) * (size_t)G, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(m->d_low_m, low_m.data(), sizeof(unsigned short) * low_m.size(), hipMemcpyHostToDevice));
-  // gene_order: a wavefront holds several genes, runs the plain and the slope cell paths one after the other when it
-  // holds genes of both kinds, and stays in the low-count loop (ppcx_gene.h low_cells) for as long as its gene with the
-  // longest list needs. So neighbours in the launch should be alike: genes with slopes first, then by the length of
-  // their low-count list, longest first -- the expensive wavefronts start first, the cheap ones fill the tail.
+  HIPCHK(hipMemcpy(m->d_gflags, gflags.data(), (size_t)G, hipMemcpyHostToDevice));
+  // gene_order: a wavefront holds several genes and runs the cell path its most demanding gene needs -- the slope columns if
+  // one of them has slopes, the test for excluded cells if one of them has such cells. So neighbours in the launch should be
+  // alike: genes with slopes first, among them and among the plain ones those with excluded cells first. Every count costs the
+  // same since round 5 (ppcx_disp.h), so nothing else distinguishes two genes.
   {
     std::vector<int> ord(G);
     for (int g = 0; g < G; ++g) ord[g] = g;
     const int K = m->d.K;
-    // ... and then by tail tier, lowest first: a pass evaluates the Stirling tails with the shortest polynomials all of its
-    // genes allow (ppcx_gene.h lane_gene_sums), so genes of one tier should sit together
     std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
       const bool sa = a < K && C >= 2, sb = b < K && C >= 2;
       if (sa != sb) return sa;
-      const int la = low_start[a + 1] - low_start[a], lb = low_start[b + 1] - low_start[b];
-      if (la != lb) return la > lb;
-      return tier[a] < tier[b];
+      return gflags[a] > gflags[b];
     });
     HIPCHK(hipMemcpy(m->d_order, ord.data(), sizeof(int) * (size_t)G, hipMemcpyHostToDevice));
-    m->pos_low.resize(G); m->pos_slope.resize(G); m->pos_tier.resize(G);
-    for (int p = 0; p < G; ++p) { m->pos_low[p] = low_start[ord[p] + 1] - low_start[ord[p]]; m->pos_slope[p] = ord[p] < K && C >= 2; m->pos_tier[p] = (char)tier[ord[p]]; }
+    m->pos_slope.resize(G);
+    for (int p = 0; p < G; ++p) m->pos_slope[p] = ord[p] < K && C >= 2;
     drop_plans(m);
   }
   HIPCHK(hipMemcpy(m->d_counts, cnt.data(), sizeof(int32_t) * cnt.size(), hipMemcpyHostToDevice));
+  // the dispersion tables of all genes from the counts now on the device (a few milliseconds; excluded cells are left out of them)
+  {
+    const hipError_t e = launch_disp_build_kernel(m->d_counts, G, S, nullptr, G, m->fit, m->d_disp, m->stream);
+    if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("dispersion-table kernel: ") + hipGetErrorString(e));
+  }
   HIPCHK(hipMemcpy(m->d_Sy, Sy.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_SyE, SyE.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_SyX, SyX.data(), sizeof(double) * SyX.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_SX, SX.data(), sizeof(double) * SX.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_ncell, ncell.data(), sizeof(double) * G, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->d_Lg1, Lg1.data(), sizeof(double) * G, hipMemcpyHostToDevice));
+  HIPCHK(hipStreamSynchronize(m->stream));
   return PPCX_OK;
 }
 
@@ -403,9 +377,9 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   MHIP(hipMalloc(&m->d_SyX, sizeof(double) * (size_t)C * G));
   MHIP(hipMalloc(&m->d_SX, sizeof(double) * (size_t)C * G));
   MHIP(hipMalloc(&m->d_ncell, sizeof(double) * G));
-  MHIP(hipMalloc(&m->d_low_start, sizeof(int) * (size_t)(G + 1)));
-  MHIP(hipMalloc(&m->d_nhi, sizeof(int) * (size_t)G));
-  MHIP(hipMalloc(&m->d_low_m, sizeof(unsigned short) * (size_t)G * 8));
+  MHIP(hipMalloc(&m->d_disp, sizeof(double) * (size_t)G * kDispGeneDoubles));
+  MHIP(hipMalloc(&m->d_gflags, (size_t)G));
+  disp_fit_init(m->fit);
   MHIP(hipMalloc(&m->d_Lg1, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_logtab, sizeof(double) * 2 * kLogTabSize));
   { double tab[2 * kLogTabSize]; fill_log_table(tab); MHIP(hipMemcpy(m->d_logtab, tab, sizeof(tab), hipMemcpyHostToDevice)); }
@@ -496,7 +470,7 @@ extern "C" void ppcx_model_destroy(ppcx_model* m) {
   (void)hipSetDevice(m->device);
   drop_plans(m);
   (void)hipFree(m->d_counts); (void)hipFree(m->d_E); (void)hipFree(m->d_expo); (void)hipFree(m->d_X);
-  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_SX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_low); (void)hipFree(m->d_low_start); (void)hipFree(m->d_nhi); (void)hipFree(m->d_low_m); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_order);
+  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_SX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_disp); (void)hipFree(m->d_gflags); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_order);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -596,13 +570,13 @@ static void step_args(ppcx_model* m, Work& w, const RunIO& io, int phases, bool 
   sa.draws = io.draws; sa.draws_chain_stride = io.draws_stride; sa.n_keep = io.n_keep; sa.iter = io.iter;
   sa.out_lp = io.lp; sa.out_stepsize = io.stepsize; sa.out_treedepth = io.treedepth; sa.out_n_leapfrog = io.nleap;
   sa.out_divergent = io.div; sa.out_accept = io.accept; sa.done = w.done;
-  sa.upd_vecs = nullptr; sa.upd_Dpad = 0; sa.upd_t0_out = nullptr; sa.upd_logtab = nullptr;
+  sa.upd_vecs = nullptr; sa.upd_Dpad = 0; sa.upd_t0_out = nullptr;
   sa.x = XchgArgs();
   if (w.xchg) {                                  // this group's chains start at xchg_chain0 of the exchange buffers
     sa.x = *w.xchg;
     sa.x.chain0 = w.xchg_chain0;
   }
-  if (with_update && (phases & STEP_ADVANCE)) { sa.upd_vecs = w.vecs; sa.upd_Dpad = w.Dpad; sa.upd_t0_out = w.t0[out]; sa.upd_logtab = m->d_logtab; }
+  if (with_update && (phases & STEP_ADVANCE)) { sa.upd_vecs = w.vecs; sa.upd_Dpad = w.Dpad; sa.upd_t0_out = w.t0[out]; }
 }
 static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int phases, bool with_update = false) {
   StepArgs sa;
@@ -616,7 +590,7 @@ static int launch_step(ppcx_model* m, Work& w, int nchains, const RunIO& io, int
 static int launch_update(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
   UpdateArgs ua;
   ua.d = m->d; ua.cmds = w.cmds[w.launches & 1]; ua.vecs = w.vecs; ua.Dpad = w.Dpad;
-  ua.draws = io.draws; ua.draws_chain_stride = io.draws_stride; ua.t0_out = w.t0[w.launches & 1]; ua.logtab = m->d_logtab;
+  ua.draws = io.draws; ua.draws_chain_stride = io.draws_stride; ua.t0_out = w.t0[w.launches & 1];
   hipError_t e = launch_update_kernel(ua, w.nb_update, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("update kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
@@ -630,7 +604,7 @@ static int loglik_args(ppcx_model* m, Work& w, int nchains, int reserve, LoglikA
   int rc = plan_launch(m, nact, reserve, &pl, w.shared_chip);
   if (rc != PPCX_OK) return rc;
   LoglikArgs& la = *out;
-  la.d = m->d; la.cd.counts = m->d_counts; la.cd.low = m->d_low; la.cd.low_start = m->d_low_start; la.cd.n_hi = m->d_nhi; la.cd.low_m = m->d_low_m; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
+  la.d = m->d; la.cd.counts = m->d_counts; la.cd.disp = m->d_disp; la.cd.gflags = m->d_gflags; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
   la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order;
   la.lgL = 0; while ((1 << la.lgL) < m->L) ++la.lgL;
   la.nchains = nact; la.active = w.n_active > 0 ? w.active : nullptr; la.nbpc = pl.nbpc; la.bounds = pl.d_bounds;
@@ -665,7 +639,7 @@ static int launch_ls(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
 static int launch_gene_round(ppcx_model* m, Work& w, int nchains, const RunIO& io, int spec = 1) {
   GeneArgs ga;
   close_args(m, w, &ga.c);
-  ga.draws = io.draws; ga.draws_chain_stride = io.draws_stride; ga.logtab = m->d_logtab; ga.spec = spec;
+  ga.draws = io.draws; ga.draws_chain_stride = io.draws_stride; ga.spec = spec;
   hipError_t e = launch_gene_kernel(m->CM, ga, w.nb_close, nchains, w.stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("gene kernel: ") + hipGetErrorString(e));
   return PPCX_OK;
@@ -985,8 +959,6 @@ extern "C" int ppcx_testing_set(const char* key, long long value) {
   if (k == "fail_at_round") g_test.fail_at_round = value;
   else if (k == "fail_rank") g_test.fail_rank = (int)value;
   else if (k == "force_generic") g_test.force_generic = (int)value;
-  else if (k == "no_tail_tiers") g_test.no_tail_tiers = (int)value;
-  else if (k == "plan_ignore_tiers") g_test.plan_ignore_tiers = (int)value;
   else if (k == "slope_cost_permille") g_test.slope_cost_permille = (int)value;
   else if (k == "trim_slack_permille") g_test.trim_slack_permille = (int)value;
   else if (k == "trim_extra_passes") g_test.trim_extra_passes = (int)value;
@@ -1333,7 +1305,7 @@ static int advi_launch(AdviRun& r, int op, int n_slots, double eta_scaled, int f
   AdviArgs a;
   a.d = r.m->d; a.vecs = r.w->vecs; a.Dpad = r.w->Dpad; a.hyper = r.w->hyper_vecs[0]; a.cmds = r.w->cmds[0]; a.red = r.w->red;
   a.op = op; a.n_slots = n_slots; a.first_iter = first_iter; a.eta_scaled = eta_scaled; a.k0 = r.k0; a.prev_draw = prev_draw;
-  a.draw_base = draw_base; a.out_draws = out_draws; a.out_row0 = out_row0; a.omega_part = r.d_omega; a.logtab = r.m->d_logtab;
+  a.draw_base = draw_base; a.out_draws = out_draws; a.out_row0 = out_row0; a.omega_part = r.d_omega;
   hipError_t e = launch_advi_kernel(a, r.nb_advi, r.w->stream);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("advi kernel: ") + hipGetErrorString(e));
   return PPCX_OK;

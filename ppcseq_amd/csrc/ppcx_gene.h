@@ -22,15 +22,13 @@ struct GeneCtx {
 };
 
 // Constants of the cell loop that depend on ONE coordinate, written next to the coordinate by whoever moves it (the
-// update kernel, the ADVI kernel), one thread per coordinate, instead of being recomputed by every lane of every gene
-// in the log-likelihood kernel:  intercept, slopes: exp(q);  sigma_raw: phi = exp(-q) (.stan:203), 1/phi and the
-// Stirling excess of phi (ppcx_math.h). `tab` is the log table (global memory here).
-PPCX_HD void coord_consts(const Dims& d, const VecRef& v, int i, double q, const double* tab) {
+// update kernel, the gene kernel, the ADVI kernel), one thread per coordinate, instead of being recomputed by every lane of
+// every gene in the log-likelihood kernel:  intercept, slopes: exp(q);  sigma_raw: phi = exp(-q) (.stan:203) and q itself --
+// the log-likelihood kernel of a pipelined round reads constants only (they may belong to an anticipated position that is in
+// none of the trajectory's ends yet), and it needs sigma_raw to address the gene's dispersion table (ppcx_disp.h).
+PPCX_HD void coord_consts(const Dims& d, const VecRef& v, int i, double q) {
   if (i >= d.off_sigma_raw && i < d.off_tail) {
-    const double phi = fast_exp(-q);
-    double dlt, dps;
-    stirling_excess(phi, -q, tab, PPCX_WAVE_ANY(phi < 8.0), &dlt, &dps);
-    v.at(V_C0, i) = phi; v.at(V_C2, i) = dlt; v.at(V_C3, i) = dps;      // 1/phi: the reader takes fast_rcp(phi) itself (V_C1 is unused)
+    v.at(V_C0, i) = fast_exp(-q); v.at(V_C2, i) = q;         // 1/phi: the reader takes fast_rcp(phi) itself (V_C1, V_C3 are unused)
   } else if (i >= d.off_intercept && i < d.off_sigma_raw) {
     v.at(V_C0, i) = fast_exp(q);
   }
@@ -61,7 +59,7 @@ PPCX_HD void gene_params(const Dims& d, const VecRef& v, GeneCtx<CM>& x) {
   for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < d.C) ? x.q[cc + 1] : 0.0;
   x.gp.sigma_raw = x.q[1];
   x.gp.phi = x.active ? v.at(V_C0, x.idx[1]) : 1.0;        // sigma = 1 ./ exp(sigma_raw)   (.stan:203)
-  x.gp.invphi = 0.0; x.gp.dlt = 0.0; x.gp.dps = 0.0; x.gp.A = 0.0; x.gp.A1 = 0.0;
+  x.gp.invphi = 0.0;
 }
 template <int CM>
 PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, GeneCtx<CM>& x) {
@@ -74,33 +72,31 @@ PPCX_HD void gene_load(const Dims& d, const Cmd& c, const VecRef& v, int g, Gene
 
 // ---------------------------------------------------------------------------------------------------------------
 // The log-likelihood kernel's work on one gene, as seen by ONE of the L lanes that share the gene (sub = 0 .. L - 1):
-//   (1) the row sweep: cells s = sub, sub + L, ... with y >= 8 -- one regime, straight-line code (cell_eval); cells with
-//       smaller or excluded (-1) counts are passed over. Four cells per trip, the counts of the next trip requested
-//       before the current one is evaluated; L is a compile-time constant, so the four loads of a trip differ by
-//       immediate offsets and a trip costs one address update;
-//   (2) the gene's low-count list (0 <= y <= 7; entries (y << 16) | s, built by the host in sample order): cell_eval_low;
-//   (3) the count part of the list cells, low_terms, term k by lane k (mod L).
+//   (1) the row sweep: cells s = sub, sub + L, ... -- every count takes the same straight-line code (cell_eval: the sample
+//       part, ln w and 1/w); excluded cells (-1) are passed over, in passes that hold a gene with such cells (MASKED; the
+//       other passes do not look at the count). Four cells per trip, the counts of the next trip requested before the
+//       current one is evaluated; L is a compile-time constant, so the four loads of a trip differ by immediate offsets
+//       and a trip costs one address update;
+//   (2) the count-and-dispersion part of the whole gene from its table (ppcx_disp.h): lane 0 evaluates Fh, lane 1 Dh (one
+//       Horner recurrence each, side by side; a lone lane does both); the panel's coefficients are requested before the sweep.
+//       A position outside the tabulated range is evaluated directly from the row by all the gene's lanes (disp_row).
 // Genes with slopes in a two-group design take the same route with e^t = E_s A or E_s A1 by the sample's group; with more
 // indicator columns (factor designs, C > 2; model.matrix of a multi-level factor or of `~ a + b`, R/utilities.R:887-900)
 // e^t = E_s A prod exp(slope_c) over the sample's columns, from the per-coordinate constants exp(q) -- no exp per cell; any
 // other gene with slopes, and every gene when X[,1] != 1, forms eta per cell (generic_cells: an exp per cell).
-// `counts` must be readable 4 L entries past the end of the matrix, `sE` / `sX` (LDS) 4 L entries past S, `low` L past
-// its end: the host and the kernel pad them.
+// `counts` must be readable 4 L entries past the end of the matrix, `sE` / `sX` (LDS) 4 L entries past S: the host and
+// the kernel pad them.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kLowCount = 8;     // counts below this are list cells
 struct CellData {                // the chain-independent inputs of the log-likelihood kernel (device pointers)
   const int* counts;             // G x S gene-major, excluded cells = -1
-  const unsigned* low;           // the cells with 0 <= count <= 7, gene after gene: (count << 16) | sample
-  const int* low_start;          // [G + 1] a gene's range in `low`
-  const int* n_hi;               // [G] number of cells with count >= 8 (bits 0..27) and the gene's tail tier (bits 28..29:
-                                 // ppcx_math.h gene_tier: from the smallest of those counts, 0 unless all S cells are such)
-  const unsigned short* low_m;   // [G][8] entry k < 7: number of list cells with count > k
+  const double* disp;            // [G][kDispPanels][2][kDispStride] the genes' dispersion tables (ppcx_disp.h)
+  const unsigned char* gflags;   // [G] bit 0: the gene has excluded cells
 };
 
 // MODE 0: plain gene (e^t = E_s A); 1: two-group design (A or A1 by the sample's group, sX1 = the group column);
 // 2: more indicator columns (C > 2; sX1 = column 1 of X in LDS, column c at sX1 + (c - 1) S; ec[c] = exp(slope_c)):
 // A times the ec of the sample's columns
-template <int CM, int L, int MODE, int TAIL = 4>
+template <int CM, int L, int MODE, bool MASKED>
 PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* sX1, int sub, double A, double A1,
                          const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& acc, const double* ec = nullptr, int C = 2) {
   const int nmin = S / L;                                  // cells every lane of the gene has
@@ -111,17 +107,17 @@ PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* 
   int y0 = p[0], y1 = p[L], y2 = p[2 * L], y3 = p[3 * L];
   int k = 0;
 #define PPCX_SWEEP_CELL(Y, E, XB, OFF, COND)                                                    \
-  if ((COND) && (TAIL < 4 || (Y) >= kLowCount)) {      /* tiers 1, 2: every cell of the gene is a row-sweep cell */ \
-    if (MODE == 1) { const double rho_ = cell_eval<CM, TAIL>(Y, E, (XB) != 0.0 ? A1 : A, gp, tab, acc); \
+  if ((COND) && (!MASKED || (Y) >= 0)) {                                                        \
+    if (MODE == 1) { const double rho_ = cell_eval<CM, true>(Y, E, (XB) != 0.0 ? A1 : A, gp, tab, acc); \
                      acc.Tx[1] = fma(XB, rho_, acc.Tx[1]); }                                    \
     else if (MODE == 2) {                                                                       \
       double a_ = (XB) != 0.0 ? A1 : A; double xk_[CM];                                         \
       _Pragma("unroll") for (int cc = 2; cc < CM; ++cc) { xk_[cc] = cc < C ? qx[(cc - 1) * S + (OFF)] : 0.0; a_ = xk_[cc] != 0.0 ? a_ * ec[cc] : a_; } \
-      const double rho_ = cell_eval<CM, TAIL>(Y, E, a_, gp, tab, acc);                          \
+      const double rho_ = cell_eval<CM, true>(Y, E, a_, gp, tab, acc);                          \
       acc.Tx[1] = fma(XB, rho_, acc.Tx[1]);                                                     \
       _Pragma("unroll") for (int cc = 2; cc < CM; ++cc) acc.Tx[cc] = fma(xk_[cc], rho_, acc.Tx[cc]); \
     }                                                                                           \
-    else (void)cell_eval<CM, TAIL>(Y, E, A, gp, tab, acc);                                      \
+    else (void)cell_eval<CM, false>(Y, E, A, gp, tab, acc);                                     \
   }
   for (; k + 4 <= nmin; k += 4) {
     const double e0 = q[0], e1 = q[L], e2 = q[2 * L], e3 = q[3 * L];
@@ -129,12 +125,23 @@ PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* 
     if (MODE != 0) { x0 = qx[0]; x1 = qx[L]; x2 = qx[2 * L]; x3 = qx[3 * L]; }
     p += 4 * L; q += 4 * L; qx += 4 * L;
     const int n0 = p[0], n1 = p[L], n2 = p[2 * L], n3 = p[3 * L];
-    PPCX_SWEEP_CELL(y0, e0, x0, -4 * L, true)              // (MODE 2 reads its further columns behind the advanced pointer)
-    PPCX_SWEEP_CELL(y1, e1, x1, -3 * L, true)
-    PPCX_SWEEP_CELL(y2, e2, x2, -2 * L, true)
-    PPCX_SWEEP_CELL(y3, e3, x3, -L, true)
-    PPCX_KEEP_BRANCH();
-    acc.renorm();
+    if (MODE == 0 && !MASKED) {
+      // the common trip: the four first halves, then the four second halves (cell_front / cell_back, ppcx_model.h)
+      CellMid c0, c1, c2, c3;
+      (void)cell_front<CM, false>(y0, e0, A, gp, tab, acc, c0);
+      (void)cell_front<CM, false>(y1, e1, A, gp, tab, acc, c1);
+      (void)cell_front<CM, false>(y2, e2, A, gp, tab, acc, c2);
+      (void)cell_front<CM, false>(y3, e3, A, gp, tab, acc, c3);
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      cell_back<CM>(c0, acc); cell_back<CM>(c1, acc); cell_back<CM>(c2, acc); cell_back<CM>(c3, acc);
+    } else {
+      PPCX_SWEEP_CELL(y0, e0, x0, -4 * L, true)            // (MODE 2 reads its further columns behind the advanced pointer)
+      PPCX_SWEEP_CELL(y1, e1, x1, -3 * L, true)
+      PPCX_SWEEP_CELL(y2, e2, x2, -2 * L, true)
+      PPCX_SWEEP_CELL(y3, e3, x3, -L, true)
+    }
     y0 = n0; y1 = n1; y2 = n2; y3 = n3;
   }
   if (k < nlane) {                                         // the last, partial trip
@@ -145,34 +152,8 @@ PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* 
     PPCX_SWEEP_CELL(y1, e1, x1, L, k + 1 < nlane)
     PPCX_SWEEP_CELL(y2, e2, x2, 2 * L, k + 2 < nlane)
     PPCX_SWEEP_CELL(y3, e3, x3, 3 * L, k + 3 < nlane)
-    acc.renorm();
   }
 #undef PPCX_SWEEP_CELL
-}
-
-template <int CM, int L, int MODE>
-PPCX_HD void low_cells(const unsigned* low, int low_n, const double* sE, const double* sX1, int sub, double A, double A1,
-                       const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& acc, const double* ec = nullptr, int C = 2, int S = 0) {
-  unsigned en = low[sub];
-  for (int i = sub; i < low_n; i += L) {
-    const unsigned ec_ = en;
-    en = low[i + L];
-    const int sl = (int)(ec_ & 0xffffu);
-    if (MODE == 1) {
-      const double xb = sX1[sl];
-      const double rho = cell_eval_low<CM>((int)(ec_ >> 16), sE[sl], xb != 0.0 ? A1 : A, gp, tab, acc);
-      acc.Tx[1] = fma(xb, rho, acc.Tx[1]);
-    } else if (MODE == 2) {
-      const double xb = sX1[sl];
-      double a_ = xb != 0.0 ? A1 : A; double xk_[CM];
-#pragma unroll
-      for (int cc = 2; cc < CM; ++cc) { xk_[cc] = cc < C ? sX1[(cc - 1) * S + sl] : 0.0; a_ = xk_[cc] != 0.0 ? a_ * ec[cc] : a_; }
-      const double rho = cell_eval_low<CM>((int)(ec_ >> 16), sE[sl], a_, gp, tab, acc);
-      acc.Tx[1] = fma(xb, rho, acc.Tx[1]);
-#pragma unroll
-      for (int cc = 2; cc < CM; ++cc) acc.Tx[cc] = fma(xk_[cc], rho, acc.Tx[cc]);
-    } else (void)cell_eval_low<CM>((int)(ec_ >> 16), sE[sl], A, gp, tab, acc);
-  }
 }
 
 // a gene whose linear predictor has to be formed per cell: t = exposure_s + X_s . coef + sigma_raw, u = exp(t)
@@ -185,7 +166,6 @@ PPCX_HD void generic_cells(const Dims& d, const Cmd& c, const VecRef& v, int g, 
   gp.coef[0] = v.at(V_Q0 + 3 * c.dir, d.off_intercept + g);
 #pragma unroll
   for (int cc = 1; cc < CM; ++cc) gp.coef[cc] = (has_slopes && cc < C) ? v.at(V_Q0 + 3 * c.dir, coef_index(d, cc, g)) : 0.0;
-  int it = 0;
   for (int s = sub; s < S; s += L) {
     const int y = row[s];
     if (y >= 0) {
@@ -193,16 +173,15 @@ PPCX_HD void generic_cells(const Dims& d, const Cmd& c, const VecRef& v, int g, 
 #pragma unroll
       for (int cc = 0; cc < CM; ++cc) if (cc < C) t += sX[cc * S + s] * gp.coef[cc];
       const double u = fast_exp(t);
-      const double rho = y >= kLowCount ? cell_eval<CM>(y, u, 1.0, gp, tab, acc) : cell_eval_low<CM>(y, u, 1.0, gp, tab, acc);
+      const double rho = cell_eval<CM, true>(y, u, 1.0, gp, tab, acc);
 #pragma unroll
       for (int cc = 0; cc < CM; ++cc) if (cc < C) acc.Tx[cc] = fma(sX[cc * S + s], rho, acc.Tx[cc]);
     }
-    if ((++it & (kRenormEvery - 1)) == 0) { PPCX_KEEP_BRANCH(); acc.renorm(); }
   }
 }
 
 // one lane's share of gene g: the hand-over sums before the L-lane reduction
-// GEN = false: a model in which every gene factorises (X[,1] == 1 and slopes only in a two-group design) -- the
+// GEN = false: a model in which every gene factorises (X[,1] == 1 and slopes only on indicator columns) -- the
 // per-cell-eta path is not compiled in, which leaves the registers to the sweep
 template <int CM, int L, bool GEN = true>
 PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const CellData& m, int g, int sub,
@@ -214,14 +193,21 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   const bool two = has_slopes && d.x0_is_one && d.x1_binary;
   const bool generic = GEN && (!d.x0_is_one || (has_slopes && !two));
   GeneParams<CM> gp;
-  gp.phi = v.at(V_C0, i_sr); gp.dlt = v.at(V_C2, i_sr); gp.dps = v.at(V_C3, i_sr);
-  gp.invphi = fast_rcp(gp.phi);                             // once per gene and pass: cheaper than a fourth constant in memory
+  gp.phi = v.at(V_C0, i_sr);
+  const double sigma = v.at(V_C2, i_sr);
+  gp.sigma_raw = sigma;
+  gp.invphi = fast_rcp(gp.phi);                             // once per gene and pass: cheaper than another constant in memory
   const double A = v.at(V_C0, d.off_intercept + g) * gp.invphi;       // exp(intercept + sigma_raw)
-  const int lo = m.low_start[g], low_n = m.low_start[g + 1] - lo;
-  const int nhi_w = m.n_hi[g];
-  const double nhi = sub == 0 ? (double)(nhi_w & 0x0fffffff) : 0.0;
-  const int tier = nhi_w >> 28;                            // wave-uniform use only: the pass takes the shortest tails all its genes allow
+  const bool masked = (m.gflags[g] & 1) != 0;
   const int* row = m.counts + (long)g * S;
+  // the gene's table: lane 0 takes the panel's Fh coefficients, lane 1 its Dh coefficients (a lone lane both). Their first and
+  // last ones are requested here, ahead of the sweep -- that brings the panel's cache lines in -- and the others after it: held
+  // across the sweep they would cost it 18 registers
+  const DispRef dr = disp_ref(sigma);
+  const bool tab_lane = dr.in && sub < 2;
+  const double* pc = m.disp + (((long)g * kDispPanels + dr.panel) * 2 + (L > 1 && sub == 1 ? 1 : 0)) * kDispStride;
+  double cf_first = 0.0, cf_last = 0.0;
+  if (tab_lane) { cf_first = pc[0]; cf_last = pc[L > 1 ? kDispDeg : kDispStride + kDispDeg]; }
   CellAcc<CM> acc; acc.zero();
   if (GEN) {
     if (PPCX_WAVE_ANY(generic)) {
@@ -230,36 +216,48 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   }
   if (!GEN || PPCX_WAVE_ANY(!generic)) {
     if (!generic) {
+      const bool any_masked = PPCX_WAVE_ANY(masked);
       if (CM > 2 && d.C > 2 && PPCX_WAVE_ANY(two)) {       // indicator columns, C > 2 (factor designs): e^t = E_s A times the
         double ec[CM];                                     // exp(slope_c) of the sample's columns; a plain gene of the same
         ec[0] = 1.0;                                       // pass (the host puts genes with slopes first) runs it with ec = 1
 #pragma unroll
         for (int cc = 1; cc < CM; ++cc) ec[cc] = (two && cc < d.C) ? v.at(V_C0, coef_index(d, cc, g)) : 1.0;
         const double A1 = A * ec[1];
-        sweep_cells<CM, L, 2>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc, ec, d.C);
-        low_cells<CM, L, 2>(m.low + lo, low_n, sE, sX + S, sub, A, A1, gp, tab, acc, ec, d.C, S);
+        if (any_masked) sweep_cells<CM, L, 2, true>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc, ec, d.C);
+        else sweep_cells<CM, L, 2, false>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc, ec, d.C);
       } else if (PPCX_WAVE_ANY(two)) {                     // e^t = E_s A or E_s A1 by the sample's group (X[,2] is 0 or 1)
         const double A1 = two ? A * v.at(V_C0, coef_index(d, 1, g)) : A;
-        sweep_cells<CM, L, 1>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc);
-        low_cells<CM, L, 1>(m.low + lo, low_n, sE, sX + S, sub, A, A1, gp, tab, acc);
+        if (any_masked) sweep_cells<CM, L, 1, true>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc);
+        else sweep_cells<CM, L, 1, false>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc);
       } else {
-#ifdef PPCX_FORCE_TAIL          // development aid (timing only, wrong results): every pass with one tail length
-        (void)tier; sweep_cells<CM, L, 0, PPCX_FORCE_TAIL>(S, row, sE, sX, sub, A, A, gp, tab, acc);
-#else
-        if (PPCX_WAVE_ALL(tier >= 2)) sweep_cells<CM, L, 0, 1>(S, row, sE, sX, sub, A, A, gp, tab, acc);
-        else if (PPCX_WAVE_ALL(tier >= 1)) sweep_cells<CM, L, 0, 2>(S, row, sE, sX, sub, A, A, gp, tab, acc);
-        else sweep_cells<CM, L, 0>(S, row, sE, sX, sub, A, A, gp, tab, acc);
-#endif
-        low_cells<CM, L, 0>(m.low + lo, low_n, sE, sX, sub, A, A, gp, tab, acc);
+        if (any_masked) sweep_cells<CM, L, 0, true>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+        else sweep_cells<CM, L, 0, false>(S, row, sE, sX, sub, A, A, gp, tab, acc);
       }
     }
   }
-  double low_lik = 0.0, low_dph = 0.0;
-  if (PPCX_WAVE_ANY(low_n > 0)) {
-    if (low_n > 0)
-      for (int k = sub; k < kLowCount - 1; k += L) low_terms(k, (double)m.low_m[(long)g * 8 + k], gp.invphi, tab, &low_lik, &low_dph);
+  cell_acc_close<CM>(gp, acc, &o);
+  if (tab_lane) {
+    if (L > 1) {
+      double p = cf_last;
+#pragma unroll
+      for (int k = kDispDeg - 1; k >= 1; --k) p = fma(p, dr.x, pc[k]);
+      p = fma(p, dr.x, cf_first);
+      if (sub == 0) o.lik += p; else o.dph += p;
+    } else {
+      double p = pc[kDispDeg], p2 = cf_last;
+#pragma unroll
+      for (int k = kDispDeg - 1; k >= 1; --k) { p = fma(p, dr.x, pc[k]); p2 = fma(p2, dr.x, pc[kDispStride + k]); }
+      o.lik += fma(p, dr.x, cf_first); o.dph += fma(p2, dr.x, pc[kDispStride]);
+    }
   }
-  cell_acc_close<CM>(gp, acc, tab, nhi, low_lik, low_dph, &o);
+  if (PPCX_WAVE_ANY(!dr.in)) {                              // outside the tabulated range: the functions themselves, from the row
+    PPCX_KEEP_BRANCH();
+    if (!dr.in) {
+      double F, D;
+      disp_row_at(row, S, sub, L, sigma, &F, &D);
+      o.lik += F; o.dph += D;
+    }
+  }
 }
 
 // close the gene with its reduced sums: gradient, second half kick, stores, partial sums part[0..9].
@@ -328,7 +326,7 @@ PPCX_HD void gene_finish(const Dims& d, const Cmd& c, const VecRef& v, const Gen
 // the next leapfrog (written in place into the end being advanced) and the constants of the new position. A command
 // without a step (eps = 0: the evaluation of a given point) leaves position and momentum as they are.
 PPCX_HD void coord_update(const Dims& d, const Cmd& nc, const VecRef& v, int i, double* draws, double* T0,
-                          const double* tab, const CoordCache* cc = nullptr) {
+                          const CoordCache* cc = nullptr) {
   const CoordVals cv = coord_pre(nc, v, i, i, global_flat(d, i), true, draws, d.D, nc.k0, nc.k1, T0, cc);
   if (nc.type == CMD_FLUSH) return;
   double qn = cv.q;
@@ -338,7 +336,7 @@ PPCX_HD void coord_update(const Dims& d, const Cmd& nc, const VecRef& v, int i, 
     v.at(V_P0 + 3 * nc.dir, i) = ph;
     v.at(V_Q0 + 3 * nc.dir, i) = qn;
   }
-  coord_consts(d, v, i, qn, tab);
+  coord_consts(d, v, i, qn);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -375,7 +373,7 @@ PPCX_HD int gene_rare_pre(const Dims& d, const Cmd& c, const VecRef& v, const Ge
 // -1 = not run yet.
 template <int CM, bool CACHED = false>
 PPCX_HD void gene_coord_update(const Dims& d, const Cmd& c, const VecRef& v, GeneCtx<CM>& x, double* draws, double* T0,
-                               const double* tab, bool consts, const CoordCache* cache = nullptr, double* p_out = nullptr,
+                               bool consts, const CoordCache* cache = nullptr, double* p_out = nullptr,
                                double* minv_out = nullptr, bool store_p = true, int fmask = -1) {
   constexpr int NCM = CM + 1;
   if (!CACHED && fmask == -1) fmask = gene_rare_pre<CM>(d, c, v, x, draws, T0);
@@ -395,7 +393,7 @@ PPCX_HD void gene_coord_update(const Dims& d, const Cmd& c, const VecRef& v, Gen
           if (store_p) v.at(V_P0 + 3 * c.dir, i) = ph;       // not when the close that follows overwrites it anyway
           v.at(V_Q0 + 3 * c.dir, i) = qn;
         }
-        if (consts) coord_consts(d, v, i, qn, tab);
+        if (consts) coord_consts(d, v, i, qn);
       }
       x.q[j] = qn;
       if (p_out) { p_out[j] = ph; minv_out[j] = cv.minv; }
@@ -407,7 +405,7 @@ PPCX_HD void gene_coord_update(const Dims& d, const Cmd& c, const VecRef& v, Gen
 // doubling in the OTHER direction the same step from the other end of the trajectory, with the step's sign turned.
 template <int CM>
 PPCX_HD void gene_spec_consts(const Dims& d, const Cmd& c, const VecRef& v, const GeneCtx<CM>& x, const double* pn,
-                              const double* gn, const double* minv, const double* tab) {
+                              const double* gn, const double* minv) {
   constexpr int NCM = CM + 1;
   const bool turn = c.next_dir != c.dir;
   const int o = 1 - c.dir;
@@ -417,7 +415,7 @@ PPCX_HD void gene_spec_consts(const Dims& d, const Cmd& c, const VecRef& v, cons
       double ph, qn;
       if (turn) kick_drift(v.at(V_Q0 + 3 * o, x.idx[j]), v.at(V_P0 + 3 * o, x.idx[j]), v.at(V_G0 + 3 * o, x.idx[j]), -c.eps, minv[j], &ph, &qn);
       else kick_drift(x.q[j], pn[j], gn[j], c.eps, minv[j], &ph, &qn);
-      coord_consts(d, v, x.idx[j], qn, tab);
+      coord_consts(d, v, x.idx[j], qn);
     }
   }
 }

@@ -8,7 +8,7 @@ namespace ppcx {
 constexpr int kLdsPad = 256;     // entries the sweep may read past the per-sample arrays in LDS (4 x 64 lanes)
 struct LoglikArgs {
   Dims d;
-  CellData cd;                  // counts, low-count lists (ppcx_gene.h)
+  CellData cd;                  // counts, dispersion tables, gene flags (ppcx_gene.h)
   const double* sampleE;        // exp(exposure_s)
   const double* exposure;       // S
   const double* X;              // S x C column-major
@@ -44,7 +44,6 @@ struct CloseArgs {
 struct GeneArgs {
   CloseArgs c;
   double* draws; long draws_chain_stride;   // PRE_STORE_DRAW
-  const double* logtab;         // log table (global memory), staged in LDS for coord_consts
   int spec;                     // anticipate the next leaf's position (models whose cell paths read the constants only)
 };
 
@@ -86,7 +85,7 @@ struct StepArgs {
   int* done;                    // [chains]
   // the per-coordinate work of the new command in the same launch (null upd_vecs: a separate ppcx_update_kernel does
   // it): grid.x workgroups per chain, each runs the step redundantly and updates its share of the coordinates
-  double* upd_vecs; long upd_Dpad; double* upd_t0_out; const double* upd_logtab;
+  double* upd_vecs; long upd_Dpad; double* upd_t0_out;
   XchgArgs x;                   // nranks > 1: the sums are exchanged with the other ranks' state machines (pipelined rounds)
 };
 
@@ -99,7 +98,6 @@ struct UpdateArgs {
   double* vecs; long Dpad;
   double* draws; long draws_chain_stride;
   double* t0_out;               // [chains][nblocks_update]
-  const double* logtab;         // log table (global memory): coord_consts
 };
 
 enum AdviOp : int { ADVI_DRAW = 0, ADVI_RESET = 1, ADVI_STEP = 2 };
@@ -114,7 +112,6 @@ struct AdviArgs {
   uint32_t k0, prev_draw, draw_base;
   double* out_draws; int out_row0;   // non-null: write the draws to [row][D] instead of the evaluation slots
   double* omega_part;           // [nblocks]
-  const double* logtab;         // log table (global memory): coord_consts
 };
 struct AdviElboArgs { Dims d; const Cmd* cmds; const double* red; int n_slots; double* acc; const double* omega_part; int n_omega_parts; };
 
@@ -151,6 +148,8 @@ size_t ppc_wave_lds_bytes(int n_gen);
 int ppc_wave_max_draws();
 hipError_t launch_ppc_table_kernel(const double* draws, long n_draws, const Dims& d, double tc, double* T, hipStream_t st);
 hipError_t launch_ppc_wave_kernel(const PpcArgs& a, const double* T, int nblocks, hipStream_t st);
+// the dispersion tables (ppcx_disp.h) of the genes in `genes` (null: genes 0 .. n_genes - 1), one workgroup per gene
+hipError_t launch_disp_build_kernel(const int* counts, int G, int S, const int* genes, int n_genes, const DispFit& fit, double* table, hipStream_t st);
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st);
 hipError_t launch_fill_kernel(double* p, long n, double val, hipStream_t st);
 hipError_t launch_xchg_abort_kernel(const XchgArgs& x, hipStream_t st);      // tells every peer that this rank has left the fit

@@ -377,9 +377,6 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   constexpr int NST = (int)(sizeof(ChainState) / sizeof(int)), NCMD = (int)(sizeof(Cmd) / sizeof(int)), NHV = V_COUNT * 8;
   static_assert(NST <= 4 * 256 && NCMD <= 256 && NHV <= 3 * 256 && PT_COUNT <= 96, "step kernel staging sizes");
   __shared__ Cmd s_nc;
-  double* s_tab = &sm[0][0][0];                // log table for coord_consts (with a.upd_vecs): takes the reduction's scratch once that is
-                                               // done -- three workgroups of this kernel fit a CU only below 21 KB of LDS each
-  static_assert(3 * 8 * 32 >= 2 * kLogTabSize, "the table fits the reduction's scratch");
   const int chain = blockIdx.y, tid = threadIdx.x;
   const bool lead = blockIdx.x == 0;           // with a.upd_vecs the grid has several workgroups per chain: all of them run the
                                                // step on the same inputs, the first one writes what the step leaves in memory
@@ -398,9 +395,6 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) r_hv[k] = tid + 256 * k < NHV ? hvg[tid + 256 * k] : 0.0;
   }
-  double r_tab[2] = {0.0, 0.0};                // the table's round trip overlaps the reduction too
-  if (a.upd_vecs) { r_tab[0] = a.upd_logtab[tid]; r_tab[1] = a.upd_logtab[tid + 256]; }
-  static_assert(2 * kLogTabSize == 512, "two table entries per thread");
   if (a.phases & STEP_REDUCE) {
     const double* slab = a.partials + (long)chain * a.slab_stride * PT_COUNT;
     // one pass: thread (c, ch) sums rows ch, ch+8, ... of columns c, c+32, c+64, loads of several rows in flight; then
@@ -462,7 +456,6 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
     if (tid < NCMD) reinterpret_cast<word_t*>(&s_ex)[tid] = r_cmd;
 #pragma unroll
     for (int k = 0; k < 3; ++k) if (tid + 256 * k < NHV) hv[tid + 256 * k] = r_hv[k];
-    s_tab[tid] = r_tab[0]; s_tab[tid + 256] = r_tab[1];
   }
   __syncthreads();
   const bool have_parts = s_st.sc.phase != PH_START;
@@ -502,7 +495,7 @@ __global__ __launch_bounds__(256) void ppcx_step_kernel(StepArgs a) {
   if (s_nc.type != CMD_DONE) {
     const VecRef v{a.upd_vecs + (long)chain * V_COUNT * a.upd_Dpad, a.upd_Dpad};
     double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
-    for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, s_nc, v, i, draws, &T0, s_tab);
+    for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, s_nc, v, i, draws, &T0);
   }
   if ((s_nc.pre_flags & (PRE_NEW_TRANSITION | PRE_EPS_TRY)) == 0) return;
   __syncthreads();                             // sT0 was used by the reduction above
@@ -714,7 +707,7 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC_FAST) void ppcx_ls_kernel(Logl
 // command through a flag -- and measured: 90 us per launch against 63 + 20 for the two launches)
 template <int CM>
 __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c, int chain, int g,
-                                               double* wacc, double* rows, const double* s_tab, int wave, int lane, bool do_update, bool do_close) {
+                                               double* wacc, double* rows, int wave, int lane, bool do_update, bool do_close) {
   constexpr int NCM = CM + 1;
   constexpr int NS = GeneSums<CM>::N;
   const CloseArgs& a = ga.c;
@@ -773,7 +766,7 @@ __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c,
     }
   }
   // ---- the command's work on the gene's coordinates
-  if (do_update) gene_coord_update<CM, true>(d, c, v, x, draws, &T0, s_tab, !do_close, cache, p_cur, minv, !do_close, fmask);
+  if (do_update) gene_coord_update<CM, true>(d, c, v, x, draws, &T0, !do_close, cache, p_cur, minv, !do_close, fmask);
   if (!do_close) {                             // the command's position has not been evaluated yet: nothing to close
     double t0v[1] = {T0};
     wave_sums_lds<1>(t0v, rows, wacc + wave * PT_COUNT, lane);
@@ -784,7 +777,7 @@ __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c,
 #pragma unroll
   for (int cc = 1; cc < CM; ++cc) x.gp.coef[cc] = (x.has_slopes && cc < d.C) ? x.q[cc + 1] : 0.0;
   x.gp.sigma_raw = x.q[1];
-  x.gp.phi = phi; x.gp.invphi = 0.0; x.gp.dlt = 0.0; x.gp.dps = 0.0; x.gp.A = 0.0; x.gp.A1 = 0.0;
+  x.gp.phi = phi; x.gp.invphi = 0.0;
   double pn[NCM], gn[NCM], part[16];
   gene_finish_vals<CM>(d, c, v, x, acc, gd, p_cur, minv, part, pn, gn);
   part[PT_T0] = T0;
@@ -834,7 +827,7 @@ __device__ __forceinline__ void gene_wave_part(const GeneArgs& ga, const Cmd& c,
       wave_sums_lds<6>(top, rows, wrow + PT_TOP, lane);
     }
     // ahead of the state machine: the constants of the position the next leaf evaluates if the tree goes on
-    if (ga.spec) gene_spec_consts<CM>(d, c, v, x, pn, gn, minv, s_tab);
+    if (ga.spec) gene_spec_consts<CM>(d, c, v, x, pn, gn, minv);
   }
 }
 // after a workgroup barrier: the four wavefronts' partial sums -> the workgroup's row of the slab
@@ -862,7 +855,6 @@ __device__ __forceinline__ void gene_block_finish(const Cmd& c, bool do_update, 
 template <int CM>
 __global__ __launch_bounds__(256, CM <= 2 ? 4 : (CM <= 4 ? 2 : 1)) void ppcx_gene_kernel(GeneArgs ga) {
   __shared__ double wacc[4 * PT_COUNT];
-  __shared__ __attribute__((aligned(16))) double s_tab[2 * kLogTabSize];
   __shared__ double s_rows[4 * kRowsPerWave * kRowStride];      // wave_sums_lds: 8.3 KB per wavefront
   const CloseArgs& a = ga.c;
   const int chain = blockIdx.y;
@@ -873,10 +865,7 @@ __global__ __launch_bounds__(256, CM <= 2 ? 4 : (CM <= 4 ? 2 : 1)) void ppcx_gen
   const bool do_update = !c.updated, do_close = c.evaluated && c.type != CMD_FLUSH;      // uniform over the launch's chain
   if (!do_update && !do_close) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  static_assert(2 * kLogTabSize == 512, "two table entries per thread");
-  reinterpret_cast<dpair_t*>(s_tab)[tid] = reinterpret_cast<const dpair_t*>(ga.logtab)[tid];     // one 16-byte request per thread
-  __syncthreads();
-  gene_wave_part<CM>(ga, c, chain, blockIdx.x * 256 + tid, wacc, s_rows + wave * kRowsPerWave * kRowStride, s_tab, wave, lane, do_update, do_close);
+  gene_wave_part<CM>(ga, c, chain, blockIdx.x * 256 + tid, wacc, s_rows + wave * kRowsPerWave * kRowStride, wave, lane, do_update, do_close);
   __syncthreads();
   gene_block_finish(c, do_update, do_close, wacc, a.partials + ((long)chain * gridDim.x + blockIdx.x) * PT_COUNT, tid);
 }
@@ -904,7 +893,7 @@ __global__ __launch_bounds__(256) void ppcx_update_kernel(UpdateArgs a) {
   if (nc.type != CMD_DONE) {
     const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
     double* draws = a.draws ? a.draws + (long)chain * a.draws_chain_stride : nullptr;
-    for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, nc, v, i, draws, &T0, a.logtab);
+    for (int i = 3 + blockIdx.x * 256 + tid; i < d.off_tail; i += gridDim.x * 256) coord_update(d, nc, v, i, draws, &T0);
   }
   // kinetic energy of freshly drawn momenta: only commands that draw momenta leave something (the step kernel's reduce
   // phase reads the slab for exactly those commands)
@@ -968,7 +957,7 @@ __global__ __launch_bounds__(256) void ppcx_advi_kernel(AdviArgs a) {
       if (a.out_draws) a.out_draws[(long)(a.out_row0 + c) * d.D + i] = z;
       else {
         a.vecs[((long)c * V_COUNT + V_Q1) * a.Dpad + i] = z;
-        coord_consts(d, VecRef{a.vecs + (long)c * V_COUNT * a.Dpad, a.Dpad}, i, z, a.logtab);
+        coord_consts(d, VecRef{a.vecs + (long)c * V_COUNT * a.Dpad, a.Dpad}, i, z);
       }
     }
   }
@@ -1303,6 +1292,43 @@ __global__ __launch_bounds__(256) void ppcx_ppc_wave_kernel(PpcArgs a, const dou
   }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// The genes' dispersion tables (ppcx_disp.h), built once per model and whenever the exclusions change: one workgroup per
+// gene. Phase 1: thread (panel, node) evaluates Fh and Dh at its node -- a loop over the gene's row in LDS, every thread on
+// the same cell (so the y < 8 / y >= 8 branch of disp_cell is uniform). Phase 2: thread (panel, function) turns the panel's
+// node values into its polynomial. 352 nodes x S cells per gene: a few milliseconds at 20 000 x 200.
+// -----------------------------------------------------------------------------------------------------
+constexpr int kDispThreads = 384;             // 352 nodes: one round
+__global__ __launch_bounds__(kDispThreads) void ppcx_disp_build_kernel(const int* counts, int G, int S, const int* genes, int n_genes,
+                                                                        DispFit fit, double* table) {
+  extern __shared__ int s_row[];              // S counts, then (8-byte aligned) 2 x kDispPanels x kDispN node values
+  const int gi = blockIdx.x;
+  if (gi >= n_genes) return;
+  const int g = genes ? genes[gi] : gi;
+  const int tid = threadIdx.x;
+  double* s_val = reinterpret_cast<double*>(s_row + ((S + 1) & ~1));
+  for (int s = tid; s < S; s += kDispThreads) s_row[s] = counts[(long)g * S + s];
+  __syncthreads();
+  constexpr int NN = kDispPanels * kDispN;
+  for (int t = tid; t < NN; t += kDispThreads) {
+    const int p = t / kDispN, k = t - p * kDispN;
+    double lo;
+    const double sg = disp_node_sigma(fit, p, k, &lo);
+    const DispPoint pt = disp_point(sg, lo);
+    double F, D;
+    disp_row(s_row, S, 0, 1, pt, &F, &D);
+    s_val[(p * 2 + 0) * kDispN + k] = F; s_val[(p * 2 + 1) * kDispN + k] = D;
+  }
+  __syncthreads();
+  for (int t = tid; t < 2 * kDispPanels; t += kDispThreads) {
+    double out[kDispStride];
+    disp_fit_panel(fit, s_val + t * kDispN, out);
+    double* dst = table + (long)g * kDispGeneDoubles + (long)t * kDispStride;
+#pragma unroll
+    for (int m = 0; m < kDispStride; ++m) dst[m] = out[m];
+  }
+}
+
 __global__ void ppcx_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows * n_cols) return;
@@ -1436,6 +1462,16 @@ hipError_t launch_ppc_wave_kernel(const PpcArgs& a, const double* T, int nblocks
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(ppcx_ppc_wave_kernel, dim3(nblocks), dim3(256), lds, st, a, T);
+  return hipGetLastError();
+}
+size_t disp_build_lds_bytes(int S) { return sizeof(int) * (size_t)((S + 1) & ~1) + sizeof(double) * 2 * kDispPanels * kDispN; }
+hipError_t launch_disp_build_kernel(const int* counts, int G, int S, const int* genes, int n_genes, const DispFit& fit, double* table, hipStream_t st) {
+  const size_t lds = disp_build_lds_bytes(S);
+  if (lds > 64u * 1024u) {
+    hipError_t e = hipFuncSetAttribute((const void*)ppcx_disp_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(ppcx_disp_build_kernel, dim3((unsigned)n_genes), dim3(kDispThreads), lds, st, counts, G, S, genes, n_genes, fit, table);
   return hipGetLastError();
 }
 hipError_t launch_gather_kernel(const double* draws, long n_rows, int D, const int* cols, int n_cols, double* out, hipStream_t st) {

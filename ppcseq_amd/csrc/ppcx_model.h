@@ -28,6 +28,7 @@
 //     neither loop, and are left out of the sufficient statistics.
 #pragma once
 #include "ppcx_math.h"
+#include "ppcx_disp.h"
 
 namespace ppcx {
 
@@ -101,40 +102,26 @@ template <int CM>
 struct GeneParams {
   double coef[CM];              // intercept, alpha_sub_1, alpha_2...   (zero beyond K, .stan:133-135)
   double sigma_raw, phi, invphi;  // phi = exp(-sigma_raw) (.stan:203), invphi = 1/phi
-  double A, A1;                 // A = exp(intercept + sigma_raw), A1 = A exp(slope) (two-group designs)
-  double dlt, dps;              // Stirling excess of phi (ppcx_math.h stirling_excess)
 };
 
-// per-lane partial sums over the cells of one gene (see the header comment for the algebra)
+// per-lane partial sums over the cells of one gene (see the header comment for the algebra); l = ln w >= 0, q = 1/w
 template <int CM>
 struct CellAcc {
-  double SA;                    // sum y ln(arg); arg = rho for the cells of the row sweep (y >= 8), 1/w for the list cells
-  double SL;                    // sum ln(arg)
-  double TL;                    // sum lg_tail(1/x) over the cells of the row sweep (their - dlt is left to the gene's
-                                // epilogue, which knows their number)
-  double TD;                    // sum dg_tail(1/x) over the cells of the row sweep (- dps likewise)
-  double Px; int Pxe;           // running product of xf over the cells of the row sweep: mantissa and binary exponent
-  double Sr;                    // sum rho
-  double Tx[CM];                // sum X_sc rho  (paths with a per-cell design row only)
-  PPCX_HD void zero() { SA = SL = TL = TD = Sr = 0.0; Px = 1.0; Pxe = 0;
+  double SA;                    // sum y l
+  double SL;                    // sum l
+  double Sq;                    // sum q
+  double SYq;                   // sum y q   (sum rho = Sq + SYq / phi, rho = (1 + y/phi) q, is formed once per gene)
+  double Tx[CM];                // sum X_sc rho  (genes with slopes only)
+  PPCX_HD void zero() { SA = SL = Sq = SYq = 0.0;
 #pragma unroll
     for (int c = 0; c < CM; ++c) Tx[c] = 0.0; }
-  PPCX_HD void renorm() {       // keep the running product's exponent in range: called every few cells
-#if defined(__HIP_DEVICE_COMPILE__)
-    Pxe += __builtin_amdgcn_frexp_exp(Px);
-    Px = __builtin_amdgcn_frexp_mant(Px);
-#else
-    int e; Px = frexp(Px, &e); Pxe += e;
-#endif
-  }
 };
-constexpr int kRenormEvery = 8;  // cells between renormalisations: a factor stays below 2^120 for phi > 2^-89
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PPCX_WAVE_ANY(p) (__any(p) != 0)
 #define PPCX_WAVE_ALL(p) (__all(p) != 0)
 // placed in the rarely taken side of a wave-uniform branch: keeps hipcc from turning the branch into selects that
-// execute both sides for every cell (it does so for short bodies: the renormalisation, the longer Stirling tails)
+// execute both sides for every cell
 #define PPCX_KEEP_BRANCH() asm volatile("" ::: "memory")
 // makes a value opaque at this point, so that what is computed from it in a rarely taken branch stays in that branch
 // instead of being hoisted into registers that the hot loop then has to carry
@@ -146,188 +133,97 @@ constexpr int kRenormEvery = 8;  // cells between renormalisations: a factor sta
 #define PPCX_OPAQUE(x) ((void)0)
 #endif
 
+// One cell with e^t = e A: the sample part of the NB2-log likelihood -- w = 1 + e A, q = 1/w (one v_rcp_f64 + Newton step),
+// l = ln w (table-driven: ppcx_math.h table_log) -- and its four accumulations. Everything that depends on the count and the
+// dispersion only comes from the gene's table (ppcx_disp.h). SLOPES: the pass holds genes with slope coordinates: rho is
+// also formed per cell and returned (the caller weights it with the sample's design row); sum rho itself is formed once per
+// gene from sum q and sum y q on every route, so that a gene's sums do not depend on the genes it shares a pass with.
+// In two halves, so that the row sweep can run the first halves of a trip's four cells -- which end with the request of the
+// table entries -- before the second halves, which need them: four LDS round trips in flight behind sixty instructions instead
+// of one behind two.
+//   cell_front: w, q, the accumulations of q, the table index and its two reads;   cell_back: ln w and its accumulations.
+// On the device both are register-only blocks of gfx950 instructions (no memory operation and no wait inside: the table reads
+// between them are the compiler's): hipcc's own code for the same C++ spends a register copy per Horner step (v_fmac) and
+// joins; here a Horner step is one v_fma with the coefficient in an SGPR pair (a VOP3 instruction may read one SGPR operand).
+// v_rcp_f64 is a transcendental-unit instruction: the instruction after it must not read its result, hence the two v_frexp
+// behind it. 21 vector instructions per cell (rounds 2-4: 41).
+struct CellMid { double yd, m, cinv, logc; int ex; };
+template <int CM, bool SLOPES>
+PPCX_HD double cell_front(int y, double e, double A, const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& a, CellMid& c) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PPCX_NO_ASM_CELL)
-// The common regime of cell_eval on the device, written as three register-only blocks of gfx950 instructions (no
-// memory operation and no wait inside: the table reads between them are the compiler's). hipcc's own code for the same
-// C++ (cell_eval below, which the host emulation runs) spends 62 vector issue slots on it -- every Horner step of the
-// polynomials becomes a register copy plus v_fmac, and the joins of the regime branches add more copies; this is 41:
-// one v_fma per Horner step with the coefficient in an SGPR pair (a VOP3 instruction may read one SGPR operand, so the
-// first step's second coefficient sits in a VGPR). v_rcp_f64 is a transcendental-unit instruction: the instruction after it
-// must not read its result (one wait state on gfx940-class chips), hence the independent product update there.
-template <int CM, int TAIL>
-__device__ __forceinline__ double cell_big_dev(int y, double e, double A, const GeneParams<CM>& gp, const double* tab,
-                                               CellAcc<CM>& a) {
-  double yd, w, xf, r2, rx, rho;
+  double w, q, t;
   asm("v_cvt_f64_u32_e32 %[yd], %[y]\n\t"
       "v_fma_f64 %[w], %[e], %[A], 1.0\n\t"
-      "v_fma_f64 %[xf], %[yd], %[ip], 1.0\n\t"
-      "v_mul_f64 %[r2], %[w], %[xf]\n\t"             // m = w xf
-      "v_rcp_f64_e32 %[rx], %[r2]\n\t"               // q ~ 1/m
-      "s_nop 0\n\t"                                  // transcendental result: one wait state before its first reader
-      "v_fma_f64 %[r2], -%[r2], %[rx], 1.0\n\t"      // 1 - m q
-      "v_fma_f64 %[rx], %[rx], %[r2], %[rx]\n\t"     // q (one Newton step)
-      "v_mul_f64 %[r2], %[rx], %[xf]\n\t"            // 1/w = q xf
-      "v_mul_f64 %[rx], %[rx], %[w]\n\t"             // 1/xf = q w
-      "v_mul_f64 %[rho], %[xf], %[r2]\n\t"           // rho = xf/w
-      "v_mul_f64 %[rx], %[rx], %[ip]\n\t"            // 1/x = (1/xf)(1/phi)
-      "v_mul_f64 %[r2], %[rx], %[rx]"
-      : [yd] "=&v"(yd), [w] "=&v"(w), [xf] "=&v"(xf), [r2] "=&v"(r2), [rx] "=&v"(rx), [rho] "=&v"(rho)
-      : [y] "v"(y), [e] "v"(e), [A] "v"(A), [ip] "v"(gp.invphi));
-  const int j = (int)(dbl_bits(rho) >> (52 - kLogTabBits)) & (kLogTabSize - 1);
-  const double cinv = tab[j], logc = tab[kLogTabSize + j];
-  __builtin_amdgcn_sched_barrier(0);     // the table reads are issued here, before the tails: their latency hides behind those
-  a.Sr += rho;
-  a.Px *= xf;
-  double t, d;
-  if (TAIL == 4) {                       // every x >= 8
-    const double F3 = -5.94317590856362882e-04, G3 = -4.15672846375406482e-03;
-    asm("v_fma_f64 %[t], %[r2], %[F4], %[F3]\n\t"
-        "v_fma_f64 %[d], %[r2], %[G4], %[G3]\n\t"
-        "v_fma_f64 %[t], %[r2], %[t], %[F2]\n\t"
-        "v_fma_f64 %[d], %[r2], %[d], %[G2]\n\t"
-        "v_fma_f64 %[t], %[r2], %[t], %[F1]\n\t"
-        "v_fma_f64 %[d], %[r2], %[d], %[G1]\n\t"
-        "v_fma_f64 %[t], %[r2], %[t], %[F0]\n\t"
-        "v_fma_f64 %[d], %[r2], %[d], %[G0]"
-        : [t] "=&v"(t), [d] "=&v"(d)
-        : [r2] "v"(r2), [F3] "v"(F3), [G3] "v"(G3),
-          [F4] "s"(7.72651446721163817e-04), [F2] "s"(7.93645716111539040e-04), [F1] "s"(-2.77777776791245188e-03),
-          [F0] "s"(8.33333333333302478e-02), [G4] "s"(6.82627523986508236e-03), [G2] "s"(3.96819926156938719e-03),
-          [G1] "s"(-8.33333322714054948e-03), [G0] "s"(8.33333333333001886e-02));
-  } else if (TAIL == 2) {                // x >= kTailX2: degree 2 (ppcx_math.h stirling_tails_short)
-    const double F1 = kStirlingF2[1], G1 = kStirlingG2[1];
-    asm("v_fma_f64 %[t], %[r2], %[F2], %[F1]\n\t"
-        "v_fma_f64 %[d], %[r2], %[G2], %[G1]\n\t"
-        "v_fma_f64 %[t], %[r2], %[t], %[F0]\n\t"
-        "v_fma_f64 %[d], %[r2], %[d], %[G0]"
-        : [t] "=&v"(t), [d] "=&v"(d)
-        : [r2] "v"(r2), [F1] "v"(F1), [G1] "v"(G1),
-          [F2] "s"(kStirlingF2[2]), [F0] "s"(kStirlingF2[0]), [G2] "s"(kStirlingG2[2]), [G0] "s"(kStirlingG2[0]));
-  } else {                               // x >= kTailX1: degree 1
-    const double F0 = kStirlingF1[0], G0 = kStirlingG1[0];
-    asm("v_fma_f64 %[t], %[r2], %[F1], %[F0]\n\t"
-        "v_fma_f64 %[d], %[r2], %[G1], %[G0]"
-        : [t] "=&v"(t), [d] "=&v"(d)
-        : [r2] "v"(r2), [F0] "v"(F0), [G0] "v"(G0), [F1] "s"(kStirlingF1[1]), [G1] "s"(kStirlingG1[1]));
-  }
-  a.TL = fma(rx, t, a.TL);
-  a.TD = fma(r2, d, a.TD);
-  a.TD = fma(0.5, rx, a.TD);
-  double l;
-  {
-    double m, ed; int ex;
-    const double L4 = -0.25;
-    asm("v_frexp_mant_f64_e32 %[m], %[rho]\n\t"
-        "v_frexp_exp_i32_f64_e32 %[ex], %[rho]\n\t"
-        "v_fma_f64 %[m], %[m], %[cinv], -1.0\n\t"      // r = m/c - 1
-        "v_cvt_f64_i32_e32 %[ed], %[ex]\n\t"
-        "v_fma_f64 %[p], %[m], %[L5], %[L4]\n\t"       // log1p(r) = r (1 - r/2 + r^2/3 - r^3/4 + r^4/5)
-        "v_fma_f64 %[p], %[m], %[p], %[L3]\n\t"
-        "v_fma_f64 %[p], %[m], %[p], -0.5\n\t"
-        "v_fma_f64 %[p], %[m], %[p], 1.0\n\t"
-        "v_fma_f64 %[p], %[m], %[p], %[logc]\n\t"
-        "v_fma_f64 %[p], %[ed], %[LN2], %[p]"            // l = ln rho
-        : [m] "=&v"(m), [ex] "=&v"(ex), [ed] "=&v"(ed), [p] "=&v"(l)
-        : [rho] "v"(rho), [cinv] "v"(cinv), [logc] "v"(logc), [L4] "v"(L4),
-          [L5] "s"(0.2), [L3] "s"(1.0 / 3.0), [LN2] "s"(6.93147180559945286227e-01));
-  }
-  a.SA = fma(yd, l, a.SA);
-  a.SL += l;
-  return rho;
-}
-#endif
-
-// One cell of the row sweep (count y >= 8, hence x = y + phi >= 8 for every phi) with e^t = e A: adds the cell to the
-// sums and returns rho = x/(phi w). Straight-line code: one logarithm, one reciprocal, the two tails.
-// TAIL: degree of the Stirling-tail polynomials -- 4 for every x >= 8; 2 / 1 for cells known to have x >= kTailX2 / kTailX1
-// (whole passes of genes whose smallest row-sweep count is that large: the host orders the genes accordingly)
-template <int CM, int TAIL = 4>
-PPCX_HD double cell_eval(int y, double e, double A, const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& a) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PPCX_NO_ASM_CELL)
-  return cell_big_dev<CM, TAIL>(y, e, A, gp, tab, a);
+      "v_rcp_f64_e32 %[q], %[w]\n\t"
+      "v_frexp_mant_f64_e32 %[m], %[w]\n\t"
+      "v_frexp_exp_i32_f64_e32 %[ex], %[w]\n\t"
+      "v_fma_f64 %[t], -%[w], %[q], 1.0\n\t"         // 1 - w q
+      "v_fma_f64 %[q], %[q], %[t], %[q]"             // q (one Newton step)
+      : [yd] "=&v"(c.yd), [w] "=&v"(w), [q] "=&v"(q), [t] "=&v"(t), [m] "=&v"(c.m), [ex] "=&v"(c.ex)
+      : [y] "v"(y), [e] "v"(e), [A] "v"(A));
 #else
-  const double yd = (double)y;
-  const double w = fma(e, A, 1.0);
-  const double xf = fma(yd, gp.invphi, 1.0);
-  // 1/w and 1/xf from ONE hardware reciprocal: q = 1/(w xf), 1/w = q xf, 1/xf = q w (v_rcp_f64 is quarter rate)
-  const double q = fast_rcp(w * xf), rw = q * xf, rx = (q * w) * gp.invphi;
-  const double rho = xf * rw;
-  const double l = table_log(rho, tab);
-  a.SA = fma(yd, l, a.SA);
-  a.SL += l;
-  a.Sr += rho;
-  a.Px *= xf;
-  const double r2 = rx * rx;
-  double t, dd;
-  if (TAIL == 4) {
-    t = fma(r2, 7.72651446721163817e-04, -5.94317590856362882e-04);     // stirling_tails (ppcx_math.h), fused with the sums
-    t = fma(r2, t, 7.93645716111539040e-04);
-    t = fma(r2, t, -2.77777776791245188e-03);
-    t = fma(r2, t, 8.33333333333302478e-02);
-    dd = fma(r2, 6.82627523986508236e-03, -4.15672846375406482e-03);
-    dd = fma(r2, dd, 3.96819926156938719e-03);
-    dd = fma(r2, dd, -8.33333322714054948e-03);
-    dd = fma(r2, dd, 8.33333333333001886e-02);
-  } else if (TAIL == 2) {
-    t = fma(r2, fma(r2, kStirlingF2[2], kStirlingF2[1]), kStirlingF2[0]);
-    dd = fma(r2, fma(r2, kStirlingG2[2], kStirlingG2[1]), kStirlingG2[0]);
-  } else {
-    t = fma(r2, kStirlingF1[1], kStirlingF1[0]);
-    dd = fma(r2, kStirlingG1[1], kStirlingG1[0]);
-  }
-  a.TL = fma(rx, t, a.TL);
-  a.TD = fma(0.5, rx, fma(r2, dd, a.TD));
-  return rho;
-#endif
-}
-
-// One cell of the low-count list (0 <= y <= 7). lgamma(y + phi) - lgamma(phi) = sum_{k<y} ln(phi + k) depends on the
-// count and on phi, not on the sample: the gene adds it once per value of k, weighted by the number of its list
-// cells with y > k (low_terms below). What is left per cell is the sample part,
-//   - (y + phi) ln w   and   rho = (1 + y/phi)/w :
-// one reciprocal, one logarithm (of 1/w), no product, no tails.
-template <int CM>
-PPCX_HD double cell_eval_low(int y, double e, double A, const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& a) {
-  const double yd = (double)y;
+  c.yd = (double)y;
   const double w = fma(e, A, 1.0);
   const double q = fast_rcp(w);
-  const double l = table_log(q, tab);                    // - ln w
-  a.SA = fma(yd, l, a.SA);
-  a.SL += l;
-  const double rho = fma(yd, gp.invphi, 1.0) * q;
-  a.Sr += rho;
-  return rho;
+  c.m = frexp(w, &c.ex);
+#endif
+  const int j = (int)(dbl_bits(w) >> (52 - kLogTabBits)) & (kLogTabSize - 1);
+  c.cinv = tab[j]; c.logc = tab[kLogTabSize + j];
+  a.Sq += q; a.SYq = fma(c.yd, q, a.SYq);
+  return SLOPES ? fma(c.yd, gp.invphi, 1.0) * q : 0.0;
 }
-// The count part of the gene's list cells, term k = 0..6 (M = number of list cells with y > k):
-//   sum over the cells of [lgamma(y + phi) - lgamma(phi) + y sigma_raw + y] = sum_k M_k [ln(1 + k/phi) + 1]
-//   (sigma_raw = - ln phi; the "+ y" undoes the "- y" that gene_close subtracts for every cell, a Stirling term)
-//   sum over the cells of [psi(y + phi) - psi(phi)]                        = sum_k M_k (1/phi) / (1 + k/phi)
-PPCX_HD void low_terms(int k, double M, double invphi, const double* tab, double* lik, double* dph) {
-  const double z = fma((double)k, invphi, 1.0);
-  *lik = fma(M, table_log(z, tab) + 1.0, *lik);
-  *dph = fma(M * invphi, fast_rcp(z), *dph);
+template <int CM>
+PPCX_HD void cell_back(const CellMid& c, CellAcc<CM>& a) {
+  double l;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PPCX_NO_ASM_CELL)
+  double ed, r;
+  const double L4 = -0.25;
+  asm("v_fma_f64 %[r], %[m], %[cinv], -1.0\n\t"      // r = m/c - 1
+      "v_cvt_f64_i32_e32 %[ed], %[ex]\n\t"
+      "v_fma_f64 %[p], %[r], %[L5], %[L4]\n\t"       // log1p(r) = r (1 - r/2 + r^2/3 - r^3/4 + r^4/5)
+      "v_fma_f64 %[p], %[r], %[p], %[L3]\n\t"
+      "v_fma_f64 %[p], %[r], %[p], -0.5\n\t"
+      "v_fma_f64 %[p], %[r], %[p], 1.0\n\t"
+      "v_fma_f64 %[p], %[r], %[p], %[logc]\n\t"
+      "v_fma_f64 %[p], %[ed], %[LN2], %[p]"            // l = ln w
+      : [r] "=&v"(r), [ed] "=&v"(ed), [p] "=&v"(l)
+      : [m] "v"(c.m), [ex] "v"(c.ex), [cinv] "v"(c.cinv), [logc] "v"(c.logc), [L4] "v"(L4),
+        [L5] "s"(0.2), [L3] "s"(1.0 / 3.0), [LN2] "s"(6.93147180559945286227e-01));
+#else
+  const double r = fma(c.m, c.cinv, -1.0);             // table_log (ppcx_math.h) on the parts cell_front has taken
+  double p = fma(r, 0.2, -0.25);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -0.5);
+  p = fma(r, p, 1.0);
+  l = fma((double)c.ex, 6.93147180559945286227e-01, fma(r, p, c.logc));
+#endif
+  a.SA = fma(c.yd, l, a.SA);
+  a.SL += l;
+}
+// the whole cell (partial trips, passes with excluded cells, per-cell linear predictors)
+template <int CM, bool SLOPES>
+PPCX_HD double cell_eval(int y, double e, double A, const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& a) {
+  CellMid c;
+  const double rho = cell_front<CM, SLOPES>(y, e, A, gp, tab, a, c);
+  cell_back<CM>(c, a);
+  return rho;
 }
 
 // What the log-likelihood kernel hands to the close kernel per gene (sums over the gene's non-excluded cells):
-//   lik = sum [ (y + phi) ln rho - 1/2 ln xf + lg_tail - dlt ]   (the exact-recurrence cells accordingly)
-//   dph = sum [ ln rho - dg_tail + dps ]  = sum [ psi(x) - psi(phi) - ln w ]
-//   Sr  = sum rho,  Tx[c] = sum X_sc rho
+//   lik = sum [ - (y + phi) ln w ] + Fh_g(sigma_raw)         (Fh, Dh: the gene's table, ppcx_disp.h)
+//   dph = sum [ - ln w ] + Dh_g(sigma_raw)  = sum [ psi(y + phi) - psi(phi) - ln w ]
+//   Sr  = sum rho,  Tx[c] = sum X_sc rho,   rho = (1 + y/phi)/w
 template <int CM>
 struct GeneSumsV { double lik, dph, Sr, Tx[CM]; };
 template <int CM> struct GeneSums { static constexpr int N = 3 + CM; };
 
-// a lane's share of the gene: fold the accumulators of its cells into the hand-over sums. The Stirling excess of phi
-// that every cell of the row sweep owes (n_hi = their number in the whole gene) is added by ONE lane of the gene.
+// a lane's share of the gene: fold the accumulators of its cells into the hand-over sums (the table's part is added by
+// the lanes that evaluate it, ppcx_gene.h lane_gene_sums)
 template <int CM>
-PPCX_HD void cell_acc_close(const GeneParams<CM>& gp, CellAcc<CM>& a, const double* tab, double n_hi_if_first_lane,
-                            double low_lik, double low_dph, GeneSumsV<CM>* o) {
-  a.renorm();
-  a.TL = fma(-n_hi_if_first_lane, gp.dlt, a.TL);
-  a.TD = fma(-n_hi_if_first_lane, gp.dps, a.TD);
-  const double lPx = fma((double)a.Pxe, 6.93147180559945286227e-01, table_log(a.Px, tab));
-  o->lik = ((a.SA + gp.phi * a.SL) - 0.5 * lPx + a.TL) + low_lik;
-  o->dph = (a.SL - a.TD) + low_dph;
-  o->Sr = a.Sr;
+PPCX_HD void cell_acc_close(const GeneParams<CM>& gp, const CellAcc<CM>& a, GeneSumsV<CM>* o) {
+  o->lik = -fma(gp.phi, a.SL, a.SA);
+  o->dph = -a.SL;
+  o->Sr = fma(gp.invphi, a.SYq, a.Sq);
 #pragma unroll
   for (int c = 0; c < CM; ++c) o->Tx[c] = a.Tx[c];
 }

@@ -10,7 +10,7 @@ extern "C" {
 #endif
 /* keys: "fail_at_round" (a rank of a gene-sharded run reports a failure once it has issued that many rounds),
  * "fail_rank" (-1: every rank), "force_generic" (genes with slopes form eta per cell even in a factor design; applies to
- * models created afterwards), "no_tail_tiers", "plan_ignore_tiers" (timing experiments; models created afterwards),
+ * models created afterwards),
  * "slope_cost_permille", "trim_slack_permille", "trim_extra_passes" (the launch plan's cost of a pass with slopes / slack of
  * a chain group's trimmed launch, per mille / passes per wavefront of such a launch beyond the fewest possible; -1 or 0:
  * built-in; plans made afterwards). */

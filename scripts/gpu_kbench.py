@@ -23,7 +23,7 @@ for r in range(int(os.environ.get("ROUNDS", 5))):
     for cfg in cfgs:
         chains, lanes, wgs = cfg
         m.set_launch(lanes, wgs)
-        ms, t = m.bench_kernel(0, chains, 10 if r else 40, reps, 1)
+        ms, t = m.bench_kernel(0, chains, int(os.environ.get("WARM", 10 if r else 40)), reps, 1)
         res[cfg].append((ms, m.get_launch(), t))
 for cfg in cfgs:
     chains, lanes, wgs = cfg

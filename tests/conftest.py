@@ -49,7 +49,7 @@ def emul():
     here = os.path.join(ROOT, "tests", "emul")
     lib = os.path.join(here, "libppcx_emul.so")
     src = os.path.join(here, "ppcx_emul.cpp")
-    hdrs = [os.path.join(ROOT, "ppcseq_amd", "csrc", h) for h in ("ppcx_math.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h")]
+    hdrs = [os.path.join(ROOT, "ppcseq_amd", "csrc", h) for h in ("ppcx_math.h", "ppcx_disp.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h")]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(p) for p in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-o", lib, src])
     return C.CDLL(lib)

@@ -15,7 +15,7 @@ static const double* log_table() { static double t[2 * kLogTabSize]; static bool
 struct EmulModel {
   Dims d; int CM;
   std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, SX, ncell, Lg1;
-  std::vector<unsigned> low; std::vector<int> low_start, nhi; std::vector<unsigned short> low_m;
+  std::vector<double> disp; std::vector<unsigned char> gflags;     // dispersion tables (ppcx_disp.h), bit 0: excluded cells
 };
 
 static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, const double* X, const double* expo,
@@ -32,15 +32,13 @@ static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, c
   for (size_t i = (size_t)S; i < (size_t)S * C && x1b; ++i) if (X[i] != 0.0 && X[i] != 1.0) x1b = 0;
   m.d.x1_binary = x1b;
   m.Sy.assign(G, 0); m.SyE.assign(G, 0); m.SyX.assign((size_t)C * G, 0); m.SX.assign((size_t)C * G, 0); m.ncell.assign(G, 0); m.Lg1.assign(G, 0);
-  m.low_start.assign(G + 1, 0); m.nhi.assign(G, 0); m.low_m.assign((size_t)G * 8, 0);
-  for (int g = 0; g < G; ++g) { int ymin = 2147483647; m.low_start[g] = (int)m.low.size(); for (int s = 0; s < S; ++s) {
-    int y = m.counts[(size_t)g * S + s]; if (y < 0) continue;
-    if (y < kLowCount) { m.low.push_back(((unsigned)y << 16) | (unsigned)s); for (int k = 0; k < y; ++k) m.low_m[(size_t)g * 8 + k]++; } else { m.nhi[g]++; if (y < ymin) ymin = y; }
+  m.gflags.assign(G, 0); m.disp.assign((size_t)G * kDispGeneDoubles, 0.0);
+  DispFit fit; disp_fit_init(fit);
+  for (int g = 0; g < G; ++g) { for (int s = 0; s < S; ++s) {
+    int y = m.counts[(size_t)g * S + s]; if (y < 0) { m.gflags[g] |= 1; continue; }
     m.Sy[g] += y; m.SyE[g] += (double)y * expo[s]; m.ncell[g] += 1; m.Lg1[g] += lgamma((double)y + 1.0);
     for (int c = 0; c < C; ++c) { m.SyX[(size_t)c * G + g] += (double)y * X[(size_t)c * S + s]; m.SX[(size_t)c * G + g] += X[(size_t)c * S + s]; }
-  } m.nhi[g] |= gene_tier(ymin, m.nhi[g], S) << 28; }
-  m.low_start[G] = (int)m.low.size();
-  m.low.resize(m.low.size() + 64, 0u);
+  } disp_build_gene_host(fit, m.counts.data() + (size_t)g * S, S, m.disp.data() + (size_t)g * kDispGeneDoubles); }
   return m;
 }
 
@@ -52,7 +50,7 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
   if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
   for (int g = 0; g < d.G; ++g) {
     // log-likelihood kernel (one lane per gene here)
-    CellData cd; cd.counts = m.counts.data(); cd.low = m.low.data(); cd.low_start = m.low_start.data(); cd.n_hi = m.nhi.data(); cd.low_m = m.low_m.data();
+    CellData cd; cd.counts = m.counts.data(); cd.disp = m.disp.data(); cd.gflags = m.gflags.data();
     GeneSumsV<CM> o;
     lane_gene_sums<CM, 1>(d, c, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), o);
     // close kernel
@@ -85,7 +83,7 @@ static double update_pass(const EmulModel& m, ChainState& st, const Cmd& ex, con
   chain_step(SerialLanes{}, m.d, st.sc, st.ta, ex, r2.data(), have_parts, h, io, rd, nc);
   double T0 = 0.0;
   if (nc.type != CMD_DONE)
-    for (int i = 3; i < m.d.off_tail; ++i) coord_update(m.d, nc, v, i, io.draws, &T0, log_table());
+    for (int i = 3; i < m.d.off_tail; ++i) coord_update(m.d, nc, v, i, io.draws, &T0);
   return T0;
 }
 
@@ -159,7 +157,7 @@ template <int CM>
 static void pipelined_loglik(const EmulModel& m, const Cmd& x, const VecRef& v, std::vector<GeneSumsV<CM>>& sums) {
   if (x.type == CMD_DONE || x.type == CMD_FLUSH) return;
   if (x.evaluated && x.type != CMD_LEAF) return;               // closed, and nothing was anticipated after it
-  CellData cd; cd.counts = m.counts.data(); cd.low = m.low.data(); cd.low_start = m.low_start.data(); cd.n_hi = m.nhi.data(); cd.low_m = m.low_m.data();
+  CellData cd; cd.counts = m.counts.data(); cd.disp = m.disp.data(); cd.gflags = m.gflags.data();
   for (int g = 0; g < m.d.G; ++g)
     lane_gene_sums<CM, 1>(m.d, x, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), sums[g]);
 }
@@ -175,7 +173,7 @@ static void pipelined_gene(const EmulModel& m, const Cmd& y, const VecRef& v, do
   for (int g = 0; g < d.G; ++g) {
     GeneCtx<CM> x;
     gene_index<CM>(d, g, x);
-    if (do_update) gene_coord_update<CM>(d, y, v, x, draws, &T0, log_table(), !do_close);
+    if (do_update) gene_coord_update<CM>(d, y, v, x, draws, &T0, !do_close);
     if (!do_close) continue;
     if (do_update) gene_params<CM>(d, v, x); else gene_load<CM>(d, y, v, g, x);
     double pn[NCM], minv[NCM], gn[NCM], part[10];
@@ -189,7 +187,7 @@ static void pipelined_gene(const EmulModel& m, const Cmd& y, const VecRef& v, do
         for (int j = 0; j < x.ncoord; ++j) coord_merge_dots(v, x.idx[j], lev, pn[j], minv[j], &nv[j], red + PT_DOTS + 6 * lev);
       if (!y.subtree_complete) { for (int j = 0; j < x.ncoord; ++j) coord_store_slot(v, x.idx[j], y.n_merge, pn[j], nv[j]); }
       else for (int j = 0; j < x.ncoord; ++j) coord_top_dots(v, x.idx[j], y.dir, pn[j], minv[j], nv[j], red + PT_TOP);
-      if (spec) gene_spec_consts<CM>(d, y, v, x, pn, gn, minv, log_table());
+      if (spec) gene_spec_consts<CM>(d, y, v, x, pn, gn, minv);
     }
   }
   if (do_update) red[PT_T0] = T0;
@@ -245,6 +243,26 @@ int emul_fit_nuts_pipelined(int G, int S, int C, int K, const int32_t* counts, c
     if (r != 0) rc = r;
   }
   return rc;
+}
+
+// the dispersion table of one row (ppcx_disp.h): Fh and Dh at the given sigma_raw -- by table lookup (in[i] = 1) or, outside
+// the tabulated range, by the direct evaluation that also builds the table; direct[] always holds the direct evaluation
+extern "C" __attribute__((visibility("default")))
+int emul_disp_table(const int32_t* row, int S, int n, const double* sigma, double* F, double* D, double* F_direct, double* D_direct, int* in) {
+  DispFit fit; disp_fit_init(fit);
+  std::vector<double> t(kDispGeneDoubles);
+  disp_build_gene_host(fit, row, S, t.data());
+  for (int i = 0; i < n; ++i) {
+    const DispRef r = disp_ref(sigma[i]);
+    const DispPoint pt = disp_point(sigma[i]);
+    disp_row(row, S, 0, 1, pt, &F_direct[i], &D_direct[i]);
+    in[i] = r.in ? 1 : 0;
+    if (r.in) {
+      const double* pc = t.data() + (long)r.panel * 2 * kDispStride;
+      F[i] = disp_horner(pc, r.x); D[i] = disp_horner(pc + kDispStride, r.x);
+    } else { F[i] = F_direct[i]; D[i] = D_direct[i]; }
+  }
+  return 0;
 }
 
 extern "C" __attribute__((visibility("default")))

@@ -47,6 +47,35 @@ def test_factor_designs_take_the_factorised_cells(oracle, emul, levels, G, S, K,
     assert np.max(np.abs(g - g2) / (1 + np.abs(g))) < 1e-10
 
 
+def _out_of_range_case(seed):
+    """sigma_raw beyond both ends of the genes' dispersion tables (ppcx_disp.h: [-8, 8)) -- phi = exp(-sigma_raw) above 2981 and
+    below 3.4e-4, where a warm-up trajectory can stray -- beside positions inside, at a panel edge and at the ends themselves;
+    counts on both sides of the y = 8 switch of the direct evaluation, a two-group design, excluded cells."""
+    rng = np.random.default_rng(seed)
+    G, S, K = 24, 13, 5
+    counts = rng.poisson(rng.choice([0.5, 5.0, 40.0, 3000.0], size=(G, 1)), size=(G, S)).astype(np.int32)
+    X = np.stack([np.ones(S), (np.arange(S) % 2).astype(float)], axis=1)
+    expo = rng.normal(0, 0.2, S)
+    u = rng.uniform(-1, 1, 2 * G + K + 6)
+    u[3:3 + G] = np.log(counts.mean(1) + 0.5) + rng.normal(0, 0.3, G)
+    sr = rng.uniform(-7.9, 7.9, G)
+    sr[:10] = [-12.5, -8.000001, -8.0, 8.0, 8.3, 11.0, 7.999999, 0.5, -0.5, 16.0]
+    u[3 + G + K:3 + G + K + G] = sr
+    excl = np.array([2, 3 * S + 1, 5 * S + 4, 9 * S], dtype=np.int32)
+    return counts, X, expo, K, u, excl
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_positions_outside_the_tabulated_dispersion_range(oracle, emul, seed):
+    counts, X, expo, K, u, excl = _out_of_range_case(seed)
+    for ex in (None, excl):
+        m = oracle.model(counts, X, expo, K, excl=ex)
+        lp, g = oracle.log_prob_grad(m, u)
+        lp2, g2 = emul_lp(emul, counts, X, expo, K, u, ex)
+        assert abs(lp2 - lp) <= 1e-11 * max(1.0, abs(lp))
+        assert np.max(np.abs(g - g2) / (1 + np.abs(g))) < 1e-10
+
+
 def _low_count_case(seed):
     """Counts 0..40 around the regime boundaries of the cell loop (y + phi < 8: exact recurrences; < 32: 7-term tails;
     else 4-term) with phi from 0.01 to 100, some rows all zero, some cells excluded."""
