@@ -10,7 +10,7 @@ P[1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU S
 P[2]="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD"
 P[3]="GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_IFETCH SQ_ACTIVE_INST_FLAT SQ_VALU_MFMA_BUSY_CYCLES"
 for i in $PASSES; do
-  rocprofv3 --pmc ${P[$i]} --kernel-trace --output-format csv -d $OUT/p$i -- python3 ${SCRIPT:-scripts/gpu_kbench.py} > $OUT/p$i.log 2> $OUT/p$i.err || echo "pass $i failed"
+  rocprofv3 --pmc ${P[$i]} --kernel-include-regex "${KERNEL_RE:-loglik}" --kernel-trace --output-format csv -d $OUT/p$i -- python3 ${SCRIPT:-scripts/gpu_kbench.py} > $OUT/p$i.log 2> $OUT/p$i.err || echo "pass $i failed"
 done
 python3 - $OUT <<'PY'
 import csv, glob, collections, sys, os
