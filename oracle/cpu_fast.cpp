@@ -21,8 +21,8 @@ using namespace ppcx;
 
 struct FastModel {
   Dims d; int CM;
-  std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, SX, ncell, Lg1, tab;
-  std::vector<double> disp; std::vector<unsigned char> gflags;     // dispersion tables (ppcx_disp.h), bit 0: excluded cells
+  std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, SX, ncell, Lg1, tab, wtab;
+  std::vector<double> disp; std::vector<unsigned char> gflags; double e_min = 1.0, e_max = 1.0;     // dispersion tables (ppcx_disp.h), bit 0: excluded cells
   std::vector<double> vecs, hv;
   int threads = 1;                 // of ppcf_lp_callback
 };
@@ -35,6 +35,8 @@ void* ppcf_model_create(int G, int S, int C, int K, const int32_t* counts, const
   m->X.assign(X, X + (size_t)S * C); m->X.resize((size_t)S * C + 64, 0.0); m->expo.assign(expo, expo + S); m->E.assign(S + 64, 0.0);
   int x0 = 1;
   for (int s = 0; s < S; ++s) { m->E[s] = exp(expo[s]); if (X[s] != 1.0) x0 = 0; }
+  m->e_min = m->e_max = m->E[0];
+  for (int s = 1; s < S; ++s) { if (m->E[s] < m->e_min) m->e_min = m->E[s]; if (m->E[s] > m->e_max) m->e_max = m->E[s]; }
   m->d.x0_is_one = x0;
   int x1b = (C >= 2);
   for (size_t i = (size_t)S; i < (size_t)S * C && x1b; ++i) if (X[i] != 0.0 && X[i] != 1.0) x1b = 0;
@@ -52,6 +54,7 @@ void* ppcf_model_create(int G, int S, int C, int K, const int32_t* counts, const
     disp_build_gene_host(fit, m->counts.data() + (size_t)g * S, S, m->disp.data() + (size_t)g * kDispGeneDoubles);
   }
   m->tab.resize(2 * kLogTabSize); fill_log_table(m->tab.data());
+  m->wtab.resize(2 * kWinTabSize); fill_window_log_table(m->wtab.data());
   m->vecs.assign((size_t)V_COUNT * m->d.D, 0.0); m->hv.assign((size_t)V_COUNT * 8, 0.0);
   return m;
 }
@@ -67,7 +70,7 @@ static double eval(FastModel& m, const double* u, double* grad, int threads) {
   for (int k = 0; k < 6; ++k) c.hyp_q[k] = u[hyper_index(d, k)];
   c.hy = make_hyper(c.hyp_q, d.lambda_mu_mu);
   const double* tab = m.tab.data();
-  CellData cd; cd.counts = m.counts.data(); cd.disp = m.disp.data(); cd.gflags = m.gflags.data();
+  CellData cd; cd.counts = m.counts.data(); cd.disp = m.disp.data(); cd.gflags = m.gflags.data(); cd.Sy = m.Sy.data(); cd.ncell = m.ncell.data(); cd.e_min = m.e_min; cd.e_max = m.e_max;
   double lp = 0.0, h[6] = {0, 0, 0, 0, 0, 0};
 #pragma omp parallel for schedule(static) num_threads(threads) reduction(+ : lp, h[:6])
   for (int g = 0; g < d.G; ++g) {
@@ -79,7 +82,7 @@ static double eval(FastModel& m, const double* u, double* grad, int threads) {
       coord_consts(d, v, i, u[i]);
     }
     GeneSumsV<CM> o;
-    lane_gene_sums<CM, 1>(d, c, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), tab, o);
+    lane_gene_sums<CM, 1>(d, c, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), tab, m.wtab.data(), o);
     gene_load<CM>(d, c, v, g, x);
     double pn[NCM], minv[NCM], gn[NCM], part[10];
     gene_finish<CM>(d, c, v, x, o, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.SX.data(), m.ncell.data(), m.Lg1.data(), part, pn, minv, gn);

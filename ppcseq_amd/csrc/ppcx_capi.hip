@@ -70,7 +70,8 @@ struct ppcx_model {
   double* d_disp = nullptr;                    // [G][kDispGeneDoubles] the genes' dispersion tables (ppcx_disp.h)
   unsigned char* d_gflags = nullptr;           // [G] bit 0: the gene has excluded cells
   DispFit fit;                                 // nodes and transforms of the table build
-  double* d_logtab = nullptr;
+  double *d_logtab = nullptr, *d_wintab = nullptr;
+  double e_min = 1.0, e_max = 1.0;             // smallest and largest exp(exposure_s)
   int* d_order = nullptr;        // gene_order: position in the log-likelihood kernel's launch -> gene
   hipStream_t stream = nullptr;
   int live_fits = 0;             // fits that still point at this model: ppcx_model_destroy defers until the last one is freed
@@ -383,6 +384,10 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   MHIP(hipMalloc(&m->d_Lg1, sizeof(double) * G));
   MHIP(hipMalloc(&m->d_logtab, sizeof(double) * 2 * kLogTabSize));
   { double tab[2 * kLogTabSize]; fill_log_table(tab); MHIP(hipMemcpy(m->d_logtab, tab, sizeof(tab), hipMemcpyHostToDevice)); }
+  MHIP(hipMalloc(&m->d_wintab, sizeof(double) * 2 * kWinTabSize));
+  { std::vector<double> wt(2 * kWinTabSize); fill_window_log_table(wt.data()); MHIP(hipMemcpy(m->d_wintab, wt.data(), sizeof(double) * wt.size(), hipMemcpyHostToDevice)); }
+  m->e_min = m->e_max = E[0];
+  for (int s = 1; s < S; ++s) { if (E[s] < m->e_min) m->e_min = E[s]; if (E[s] > m->e_max) m->e_max = E[s]; }
   MHIP(hipMalloc(&m->d_order, sizeof(int) * (size_t)G));
   MHIP(hipMemcpy(m->d_E, E.data(), sizeof(double) * S, hipMemcpyHostToDevice));
   MHIP(hipMemcpy(m->d_expo, exposure, sizeof(double) * S, hipMemcpyHostToDevice));
@@ -470,7 +475,7 @@ extern "C" void ppcx_model_destroy(ppcx_model* m) {
   (void)hipSetDevice(m->device);
   drop_plans(m);
   (void)hipFree(m->d_counts); (void)hipFree(m->d_E); (void)hipFree(m->d_expo); (void)hipFree(m->d_X);
-  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_SX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_disp); (void)hipFree(m->d_gflags); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_order);
+  (void)hipFree(m->d_Sy); (void)hipFree(m->d_SyE); (void)hipFree(m->d_SyX); (void)hipFree(m->d_SX); (void)hipFree(m->d_ncell); (void)hipFree(m->d_disp); (void)hipFree(m->d_gflags); (void)hipFree(m->d_Lg1); (void)hipFree(m->d_logtab); (void)hipFree(m->d_wintab); (void)hipFree(m->d_order);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -604,8 +609,8 @@ static int loglik_args(ppcx_model* m, Work& w, int nchains, int reserve, LoglikA
   int rc = plan_launch(m, nact, reserve, &pl, w.shared_chip);
   if (rc != PPCX_OK) return rc;
   LoglikArgs& la = *out;
-  la.d = m->d; la.cd.counts = m->d_counts; la.cd.disp = m->d_disp; la.cd.gflags = m->d_gflags; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
-  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.order = m->d_order;
+  la.d = m->d; la.cd.counts = m->d_counts; la.cd.disp = m->d_disp; la.cd.gflags = m->d_gflags; la.cd.Sy = m->d_Sy; la.cd.ncell = m->d_ncell; la.cd.e_min = m->e_min; la.cd.e_max = m->e_max; la.sampleE = m->d_E; la.exposure = m->d_expo; la.X = m->d_X;
+  la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.wintab = m->d_wintab; la.order = m->d_order;
   la.lgL = 0; while ((1 << la.lgL) < m->L) ++la.lgL;
   la.nchains = nact; la.active = w.n_active > 0 ? w.active : nullptr; la.nbpc = pl.nbpc; la.bounds = pl.d_bounds;
   return PPCX_OK;

@@ -91,13 +91,18 @@ struct CellData {                // the chain-independent inputs of the log-like
   const int* counts;             // G x S gene-major, excluded cells = -1
   const double* disp;            // [G][kDispPanels][2][kDispStride] the genes' dispersion tables (ppcx_disp.h)
   const unsigned char* gflags;   // [G] bit 0: the gene has excluded cells
+  const double* Sy;              // [G] sum of the gene's non-excluded counts   } what a gene's window (ppcx_model.h GeneWindow)
+  const double* ncell;           // [G] number of its non-excluded cells        } owes the sums once per gene
+  double e_min, e_max;           // smallest and largest exp(exposure_s): the window's bounds
 };
 
 // MODE 0: plain gene (e^t = E_s A); 1: two-group design (A or A1 by the sample's group, sX1 = the group column);
 // 2: more indicator columns (C > 2; sX1 = column 1 of X in LDS, column c at sX1 + (c - 1) S; ec[c] = exp(slope_c)):
 // A times the ec of the sample's columns
-template <int CM, int L, int MODE, bool MASKED>
-PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* sX1, int sub, double A, double A1,
+// WIN: the windowed cell (ppcx_model.h GeneWindow): A, A1 arrive scaled by 2^-k, one = 2^-k, tab = the window table; else the
+// general cell: one = 1 (not used), tab = the mantissa table
+template <int CM, int L, int MODE, bool MASKED, bool WIN>
+PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* sX1, int sub, double A, double A1, double one,
                          const GeneParams<CM>& gp, const double* tab, CellAcc<CM>& acc, const double* ec = nullptr, int C = 2) {
   const int nmin = S / L;                                  // cells every lane of the gene has
   const int nlane = nmin + (sub < S - nmin * L ? 1 : 0);
@@ -108,15 +113,17 @@ PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* 
   int k = 0;
 #define PPCX_SWEEP_CELL(Y, E, XB, OFF, COND)                                                    \
   if ((COND) && (!MASKED || (Y) >= 0)) {                                                        \
-    if (MODE == 1) { const double rho_ = cell_eval<CM, true>(Y, E, (XB) != 0.0 ? A1 : A, gp, tab, acc); \
+    if (MODE == 1) { const double a1_ = (XB) != 0.0 ? A1 : A;                                   \
+                     const double rho_ = WIN ? cell_eval_win<CM, true>(Y, E, a1_, one, gp, tab, acc) : cell_eval<CM, true>(Y, E, a1_, gp, tab, acc); \
                      acc.Tx[1] = fma(XB, rho_, acc.Tx[1]); }                                    \
     else if (MODE == 2) {                                                                       \
       double a_ = (XB) != 0.0 ? A1 : A; double xk_[CM];                                         \
       _Pragma("unroll") for (int cc = 2; cc < CM; ++cc) { xk_[cc] = cc < C ? qx[(cc - 1) * S + (OFF)] : 0.0; a_ = xk_[cc] != 0.0 ? a_ * ec[cc] : a_; } \
-      const double rho_ = cell_eval<CM, true>(Y, E, a_, gp, tab, acc);                          \
+      const double rho_ = WIN ? cell_eval_win<CM, true>(Y, E, a_, one, gp, tab, acc) : cell_eval<CM, true>(Y, E, a_, gp, tab, acc); \
       acc.Tx[1] = fma(XB, rho_, acc.Tx[1]);                                                     \
       _Pragma("unroll") for (int cc = 2; cc < CM; ++cc) acc.Tx[cc] = fma(xk_[cc], rho_, acc.Tx[cc]); \
     }                                                                                           \
+    else if (WIN) (void)cell_eval_win<CM, false>(Y, E, A, one, gp, tab, acc);                   \
     else (void)cell_eval<CM, false>(Y, E, A, gp, tab, acc);                                     \
   }
   for (; k + 4 <= nmin; k += 4) {
@@ -125,8 +132,18 @@ PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* 
     if (MODE != 0) { x0 = qx[0]; x1 = qx[L]; x2 = qx[2 * L]; x3 = qx[3 * L]; }
     p += 4 * L; q += 4 * L; qx += 4 * L;
     const int n0 = p[0], n1 = p[L], n2 = p[2 * L], n3 = p[3 * L];
-    if (MODE == 0 && !MASKED) {
-      // the common trip: the four first halves, then the four second halves (cell_front / cell_back, ppcx_model.h)
+    if (MODE == 0 && !MASKED && WIN) {
+      // the common trip: the four first halves, then the four second halves (cell_front_win / cell_back_win, ppcx_model.h)
+      CellMidWin c0, c1, c2, c3;
+      (void)cell_front_win<CM, false>(y0, e0, A, one, gp, tab, acc, c0);
+      (void)cell_front_win<CM, false>(y1, e1, A, one, gp, tab, acc, c1);
+      (void)cell_front_win<CM, false>(y2, e2, A, one, gp, tab, acc, c2);
+      (void)cell_front_win<CM, false>(y3, e3, A, one, gp, tab, acc, c3);
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      cell_back_win<CM>(c0, acc); cell_back_win<CM>(c1, acc); cell_back_win<CM>(c2, acc); cell_back_win<CM>(c3, acc);
+    } else if (MODE == 0 && !MASKED) {
       CellMid c0, c1, c2, c3;
       (void)cell_front<CM, false>(y0, e0, A, gp, tab, acc, c0);
       (void)cell_front<CM, false>(y1, e1, A, gp, tab, acc, c1);
@@ -185,7 +202,7 @@ PPCX_HD void generic_cells(const Dims& d, const Cmd& c, const VecRef& v, int g, 
 // per-cell-eta path is not compiled in, which leaves the registers to the sweep
 template <int CM, int L, bool GEN = true>
 PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const CellData& m, int g, int sub,
-                            const double* sE, const double* sExpo, const double* sX, const double* tab,
+                            const double* sE, const double* sExpo, const double* sX, const double* tab, const double* wtab,
                             GeneSumsV<CM>& o) {
   const int S = d.S;
   const int i_sr = d.off_sigma_raw + g;
@@ -214,28 +231,48 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
       if (generic) generic_cells<CM, L>(d, c, v, g, has_slopes, row, sExpo, sX, sub, gp, tab, acc);
     }
   }
+  GeneWindow gw; gw.k = 0; gw.ok = false; gw.scale = 1.0;
+  bool win = false;
   if (!GEN || PPCX_WAVE_ANY(!generic)) {
     if (!generic) {
       const bool any_masked = PPCX_WAVE_ANY(masked);
+      // the pass runs the windowed cell if every gene of it has a window (and none has excluded cells: those passes are few,
+      // they keep the one general sweep that tests the counts' sign)
+#define PPCX_SWEEP(MODE, A_LO, A_HI, A_, A1_, X1_, ...)                                                                  \
+      gw = gene_window(fma(m.e_min, A_LO, 1.0), fma(m.e_max, A_HI, 1.0));                                                 \
+      win = !any_masked && PPCX_WAVE_ALL(gw.ok);                                                                          \
+      if (any_masked) sweep_cells<CM, L, MODE, true, false>(S, row, sE, X1_, sub, A_, A1_, 1.0, gp, tab, acc, ##__VA_ARGS__);   \
+      else if (win) sweep_cells<CM, L, MODE, false, true>(S, row, sE, X1_, sub, (A_) * gw.scale, (A1_) * gw.scale, gw.scale, gp, wtab, acc, ##__VA_ARGS__); \
+      else sweep_cells<CM, L, MODE, false, false>(S, row, sE, X1_, sub, A_, A1_, 1.0, gp, tab, acc, ##__VA_ARGS__);
       if (CM > 2 && d.C > 2 && PPCX_WAVE_ANY(two)) {       // indicator columns, C > 2 (factor designs): e^t = E_s A times the
         double ec[CM];                                     // exp(slope_c) of the sample's columns; a plain gene of the same
         ec[0] = 1.0;                                       // pass (the host puts genes with slopes first) runs it with ec = 1
+        double a_lo = A, a_hi = A;
 #pragma unroll
-        for (int cc = 1; cc < CM; ++cc) ec[cc] = (two && cc < d.C) ? v.at(V_C0, coef_index(d, cc, g)) : 1.0;
+        for (int cc = 1; cc < CM; ++cc) {
+          ec[cc] = (two && cc < d.C) ? v.at(V_C0, coef_index(d, cc, g)) : 1.0;
+          a_lo = ec[cc] < 1.0 ? a_lo * ec[cc] : a_lo; a_hi = ec[cc] > 1.0 ? a_hi * ec[cc] : a_hi;
+        }
         const double A1 = A * ec[1];
-        if (any_masked) sweep_cells<CM, L, 2, true>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc, ec, d.C);
-        else sweep_cells<CM, L, 2, false>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc, ec, d.C);
+        PPCX_SWEEP(2, a_lo, a_hi, A, A1, sX + S, ec, d.C)
       } else if (PPCX_WAVE_ANY(two)) {                     // e^t = E_s A or E_s A1 by the sample's group (X[,2] is 0 or 1)
         const double A1 = two ? A * v.at(V_C0, coef_index(d, 1, g)) : A;
-        if (any_masked) sweep_cells<CM, L, 1, true>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc);
-        else sweep_cells<CM, L, 1, false>(S, row, sE, sX + S, sub, A, A1, gp, tab, acc);
+        PPCX_SWEEP(1, (A1 < A ? A1 : A), (A1 > A ? A1 : A), A, A1, sX + S)
       } else {
-        if (any_masked) sweep_cells<CM, L, 0, true>(S, row, sE, sX, sub, A, A, gp, tab, acc);
-        else sweep_cells<CM, L, 0, false>(S, row, sE, sX, sub, A, A, gp, tab, acc);
+        PPCX_SWEEP(0, A, A, A, A, sX)
       }
+#undef PPCX_SWEEP
     }
   }
-  cell_acc_close<CM>(gp, acc, &o);
+  if (!win) gw.scale = 1.0;
+  cell_acc_close<CM>(gp, acc, gw.scale, &o);
+  if (win && sub == 0 && gw.k != 0) {                       // the cells' logarithms were those of 2^-k w: k ln 2 per cell, once per gene
+    const double kd = (double)gw.k;
+    const double klog2 = fma(kd, 6.93147180369123816490e-01, kd * 1.90821492927058770002e-10);
+    const double n = m.ncell[g];
+    o.lik -= klog2 * fma(gp.phi, n, m.Sy[g]);
+    o.dph -= klog2 * n;
+  }
   if (tab_lane) {
     if (L > 1) {
       double p = cf_last;

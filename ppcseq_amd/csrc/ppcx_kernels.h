@@ -17,6 +17,7 @@ struct LoglikArgs {
   const Cmd* cmds;              // [chains]
   double* sums;                 // [chains][3+CM][G] (GeneSumsV)
   const double* logtab;         // 2 x 256 doubles (device), ppcx_math.h table_log
+  const double* wintab;         // 2 x 1024 doubles (device), ppcx_math.h window table
   const int* order;             // [G] launch position -> gene (host: gene_order)
   int lgL;                      // log2 of the lanes per gene
   int nchains;                  // chains of this launch

@@ -55,7 +55,7 @@ __device__ __forceinline__ double wave_xor_add_rt(double v, int lane_xor_mask) {
 // Wavefronts are independent after the LDS fill (no barrier, no atomic), and a gene's sums depend on L only.
 template <int CM, int LG, bool GEN>
 __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c, const VecRef& v, double* sums, int p0, int p1,
-                                              const double* stab, const double* sE, const double* sExpo, const double* sX,
+                                              const double* stab, const double* swin, const double* sE, const double* sExpo, const double* sX,
                                               int lane, bool any_generic) {
   constexpr int L = 1 << LG, GPW = 64 >> LG;     // lanes per gene, genes per wavefront and pass
   const Dims& d = a.d;
@@ -79,7 +79,7 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
       // (its accumulators carry two slope sums, not CM: the registers the wider one needs cost the row sweep spills), and
       // the three sums of a plain gene
       GeneSumsV<2> o2;
-      lane_gene_sums<2, L, false>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, o2);
+      lane_gene_sums<2, L, false>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, swin, o2);
 #pragma unroll
       for (int msk = 1; msk < L; msk <<= 1) {
         o2.lik = wave_xor_add_rt(o2.lik, msk); o2.dph = wave_xor_add_rt(o2.dph, msk); o2.Sr = wave_xor_add_rt(o2.Sr, msk);
@@ -88,7 +88,7 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
       continue;
     }
     GeneSumsV<CM> o;
-    lane_gene_sums<CM, L, GEN>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, o);
+    lane_gene_sums<CM, L, GEN>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, swin, o);
     // sum X_sc rho is needed of genes with slopes only (and of every gene when X[,1] != 1): a pass without such genes
     // neither reduces nor stores it (the close kernel does not use those entries of a plain gene)
     const bool with_tx = any_generic && (!d.x0_is_one || PPCX_WAVE_ANY(g < d.K));
@@ -132,6 +132,10 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
   const bool evenS = (S & 1) == 0;             // then exp(exposure) is 16-byte aligned on both sides
   const int p0 = a.bounds[jb * 4 + wave], p1 = a.bounds[jb * 4 + wave + 1];
   const double2 f_tab = reinterpret_cast<const dpair_t*>(a.logtab)[tid];
+  static_assert(2 * kWinTabSize == 4 * 2 * 256, "four 16-byte requests per thread fill the window table");
+  double2 f_win[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) f_win[k] = reinterpret_cast<const dpair_t*>(a.wintab)[tid + 256 * k];
   double2 f_e = {0.0, 0.0};
   if (evenS) { if (tid < S / 2) f_e = reinterpret_cast<const dpair_t*>(a.sampleE)[tid]; }
   else if (tid < S) f_e.x = a.sampleE[tid];
@@ -147,7 +151,8 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
     if (c.evaluated && c.type != CMD_LEAF) return;
   }
   double* stab = lds;                          // log table: 256 x 1/c then 256 x log c (4 KB)
-  double* sE = lds + 2 * kLogTabSize;          // exp(exposure_s), readable kLdsPad entries past S (sweep_cells)
+  double* swin = lds + 2 * kLogTabSize;        // window table: 1024 x 1/c then 1024 x log c (16 KB)
+  double* sE = swin + 2 * kWinTabSize;         // exp(exposure_s), readable kLdsPad entries past S (sweep_cells)
   double* sExpo = sE + S + kLdsPad;
   double* sX = sExpo + S;                      // S x C column-major, readable kLdsPad entries past its end
   const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
@@ -155,6 +160,8 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
   // the fill: every workgroup of the launch reads the same few KB at the same time, so as few requests as possible -- 16 bytes
   // per lane where the alignment allows
   reinterpret_cast<dpair_t*>(stab)[tid] = f_tab;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) reinterpret_cast<dpair_t*>(swin)[tid + 256 * k] = f_win[k];
   if (evenS) {
     if (tid < S / 2) reinterpret_cast<dpair_t*>(sE)[tid] = f_e;
     for (int i = tid + 256; i < S / 2; i += 256) reinterpret_cast<dpair_t*>(sE)[i] = reinterpret_cast<const dpair_t*>(a.sampleE)[i];
@@ -175,13 +182,13 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
   __syncthreads();
   if (p0 >= p1) return;
   switch (a.lgL) {
-    case 0: loglik_passes<CM, 0, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    case 1: loglik_passes<CM, 1, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    case 2: loglik_passes<CM, 2, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    case 3: loglik_passes<CM, 3, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    case 4: loglik_passes<CM, 4, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    case 5: loglik_passes<CM, 5, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
-    default: loglik_passes<CM, 6, GEN>(a, c, v, sums, p0, p1, stab, sE, sExpo, sX, lane, any_generic); break;
+    case 0: loglik_passes<CM, 0, GEN>(a, c, v, sums, p0, p1, stab, swin, sE, sExpo, sX, lane, any_generic); break;
+    case 1: loglik_passes<CM, 1, GEN>(a, c, v, sums, p0, p1, stab, swin, sE, sExpo, sX, lane, any_generic); break;
+    case 2: loglik_passes<CM, 2, GEN>(a, c, v, sums, p0, p1, stab, swin, sE, sExpo, sX, lane, any_generic); break;
+    case 3: loglik_passes<CM, 3, GEN>(a, c, v, sums, p0, p1, stab, swin, sE, sExpo, sX, lane, any_generic); break;
+    case 4: loglik_passes<CM, 4, GEN>(a, c, v, sums, p0, p1, stab, swin, sE, sExpo, sX, lane, any_generic); break;
+    case 5: loglik_passes<CM, 5, GEN>(a, c, v, sums, p0, p1, stab, swin, sE, sExpo, sX, lane, any_generic); break;
+    default: loglik_passes<CM, 6, GEN>(a, c, v, sums, p0, p1, stab, swin, sE, sExpo, sX, lane, any_generic); break;
   }
 }
 
@@ -1351,7 +1358,7 @@ __global__ void ppcx_fill_kernel(double* p, long n, double val) {
 // -----------------------------------------------------------------------------------------------------
 // launch helpers (host)
 // -----------------------------------------------------------------------------------------------------
-size_t loglik_lds_bytes(int S, int C) { return sizeof(double) * (2 * kLogTabSize + (size_t)S * (2 + C) + 2 * kLdsPad); }
+size_t loglik_lds_bytes(int S, int C) { return sizeof(double) * (2 * kLogTabSize + 2 * kWinTabSize + (size_t)S * (2 + C) + 2 * kLdsPad); }
 // the instantiation a model runs: CM design columns (2, 4 or 8) and whether any gene can need the per-cell-eta path
 static const void* loglik_kernel_ptr(int CM, bool gen) {
   if (CM <= 2) return gen ? (const void*)ppcx_loglik_kernel<2, true> : (const void*)ppcx_loglik_kernel<2, false>;

@@ -114,6 +114,33 @@ PPCX_HD double table_log(double x, const double* tab) {
   return fma((double)e, 6.93147180559945286227e-01, fma(r, p, logc));
 }
 
+// The WINDOWED table (round 5) for arguments known to lie in [1, 16) -- the cells of one gene after scaling by a power of two
+// (ppcx_model.h GeneWindow): the index is the two low bits of the exponent field and the top 8 mantissa bits, the entries
+// are 1/c and log c of the bin's centre c = 2^e (1 + (j + 1/2)/256), so that r = x/c - 1 comes from ONE multiply-add with x
+// itself and log x = log c + log1p(r): no v_frexp_mant / v_frexp_exp / conversion / exponent multiply-add per cell.
+// Two arrays of 1024 doubles (16 KB), wt[j] = 1/c_j and wt[1024 + j] = log c_j.
+constexpr int kWinTabBits = 10, kWinTabSize = 1 << kWinTabBits;
+constexpr int kWinBinades = 4;            // [1, 2), [2, 4), [4, 8), [8, 16)
+inline void fill_window_log_table(double* t /* 2 * kWinTabSize */) {    // host
+  for (int j = 0; j < kWinTabSize; ++j) {
+    const int e2 = j >> 8, m8 = j & 255;            // e2: exponent field & 3; field = 1023 + e  =>  e = (e2 + 1) & 3
+    const int e = (e2 + 1) & 3;
+    const long double c = ldexpl(1.0L + ((long double)m8 + 0.5L) / 256.0L, e);
+    t[j] = (double)(1.0L / c);
+    t[kWinTabSize + j] = (double)logl(1.0L / (long double)t[j]);      // log of the reciprocal actually stored
+  }
+}
+// log x for x in [1, 16) (the host's statement of the windowed cell's logarithm, ppcx_model.h cell_back_win)
+PPCX_HD double window_log(double x, const double* wt) {
+  const int j = (int)(dbl_bits(x) >> (52 - 8)) & (kWinTabSize - 1);
+  const double r = fma(x, wt[j], -1.0);
+  double p = fma(r, 0.2, -0.25);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -0.5);
+  p = fma(r, p, 1.0);
+  return fma(r, p, wt[kWinTabSize + j]);
+}
+
 // exp(x) for |x| < 700 by x = k ln2 + r, |r| <= ln2/2 and the rational form of Sun's fdlibm e_exp.c
 // (public domain algorithm; error < 1 ulp): c = r - r^2 P(r^2), exp(r) = 1 + r + r c / (2 - c).
 PPCX_HD double fast_exp(double x) {

@@ -209,6 +209,82 @@ PPCX_HD double cell_eval(int y, double e, double A, const GeneParams<CM>& gp, co
   return rho;
 }
 
+// ---- the windowed cell (round 5) --------------------------------------------------------------------------------------
+// All cells of a gene share A, so their w = 1 + E_s A lie within a factor max E / min E of each other (times exp |slope| for
+// a gene with slopes): with 2^k <= w_min and w_max < 2^(k + 4) -- GeneWindow::ok -- the cells are evaluated on w' = 2^-k w in
+// [1, 16): w' = fma(E_s, 2^-k A, 2^-k) costs the same multiply-add, the table index comes from the bits of w' (two exponent
+// bits + eight mantissa bits: ppcx_math.h window table), r = fma(w', 1/c, -1), ln w' = ln c + log1p(r) and q' = 1/w' = 2^k q.
+// The gene adds k ln 2 (sum y + phi n) once and scales the q-sums by 2^-k (exact). Per cell that removes v_frexp_mant,
+// v_frexp_exp, the conversion of the exponent and its multiply-add: 17 vector instructions instead of 21.
+// A gene whose cells span more than four binades (exposures more than a factor 8 apart, a large slope), and every gene with a
+// per-cell linear predictor, takes the general cell above.
+struct GeneWindow { int k; bool ok; double scale; };     // scale = 2^-k
+PPCX_HD GeneWindow gene_window(double w_min, double w_max) {
+  GeneWindow g;
+  const int e0 = (int)((dbl_bits(w_min) >> 52) & 0x7ff), e1 = (int)((dbl_bits(w_max) >> 52) & 0x7ff);
+  g.k = e0 - 1023;
+  g.ok = w_min >= 1.0 && e1 - e0 < kWinBinades && e1 < 0x7ff;          // (false for NaN / inf)
+  g.scale = bits_dbl((unsigned long long)(g.ok ? 2046 - e0 : 1023) << 52);
+  if (!g.ok) g.k = 0;
+  return g;
+}
+struct CellMidWin { double yd, w, cinv, logc; };
+// e^t 2^-k = e A with A already scaled; one = 2^-k
+template <int CM, bool SLOPES>
+PPCX_HD double cell_front_win(int y, double e, double A, double one, const GeneParams<CM>& gp, const double* wt, CellAcc<CM>& a, CellMidWin& c) {
+  double q;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PPCX_NO_ASM_CELL)
+  double t;
+  asm("v_fma_f64 %[w], %[e], %[A], %[one]\n\t"
+      "v_rcp_f64_e32 %[q], %[w]\n\t"
+      "v_cvt_f64_u32_e32 %[yd], %[y]\n\t"            // (the instruction behind v_rcp_f64 must not read its result)
+      "v_fma_f64 %[t], -%[w], %[q], 1.0\n\t"         // 1 - w q
+      "v_fma_f64 %[q], %[q], %[t], %[q]"             // q (one Newton step)
+      : [yd] "=&v"(c.yd), [w] "=&v"(c.w), [q] "=&v"(q), [t] "=&v"(t)
+      : [y] "v"(y), [e] "v"(e), [A] "v"(A), [one] "v"(one));
+#else
+  c.yd = (double)y;
+  c.w = fma(e, A, one);
+  q = fast_rcp(c.w);
+#endif
+  const int j = (int)(dbl_bits(c.w) >> (52 - 8)) & (kWinTabSize - 1);
+  c.cinv = wt[j]; c.logc = wt[kWinTabSize + j];
+  a.Sq += q; a.SYq = fma(c.yd, q, a.SYq);
+  return SLOPES ? fma(c.yd, gp.invphi, 1.0) * q : 0.0;
+}
+template <int CM>
+PPCX_HD void cell_back_win(const CellMidWin& c, CellAcc<CM>& a) {
+  double l;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PPCX_NO_ASM_CELL)
+  double r;
+  const double L4 = -0.25;
+  asm("v_fma_f64 %[r], %[w], %[cinv], -1.0\n\t"      // r = w/c - 1
+      "v_fma_f64 %[p], %[r], %[L5], %[L4]\n\t"       // log1p(r) = r (1 - r/2 + r^2/3 - r^3/4 + r^4/5)
+      "v_fma_f64 %[p], %[r], %[p], %[L3]\n\t"
+      "v_fma_f64 %[p], %[r], %[p], -0.5\n\t"
+      "v_fma_f64 %[p], %[r], %[p], 1.0\n\t"
+      "v_fma_f64 %[p], %[r], %[p], %[logc]"          // l = ln w'
+      : [r] "=&v"(r), [p] "=&v"(l)
+      : [w] "v"(c.w), [cinv] "v"(c.cinv), [logc] "v"(c.logc), [L4] "v"(L4), [L5] "s"(0.2), [L3] "s"(1.0 / 3.0));
+#else
+  const double r = fma(c.w, c.cinv, -1.0);
+  double p = fma(r, 0.2, -0.25);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -0.5);
+  p = fma(r, p, 1.0);
+  l = fma(r, p, c.logc);
+#endif
+  a.SA = fma(c.yd, l, a.SA);
+  a.SL += l;
+}
+template <int CM, bool SLOPES>
+PPCX_HD double cell_eval_win(int y, double e, double A, double one, const GeneParams<CM>& gp, const double* wt, CellAcc<CM>& a) {
+  CellMidWin c;
+  const double rho = cell_front_win<CM, SLOPES>(y, e, A, one, gp, wt, a, c);
+  cell_back_win<CM>(c, a);
+  return rho;
+}
+
 // What the log-likelihood kernel hands to the close kernel per gene (sums over the gene's non-excluded cells):
 //   lik = sum [ - (y + phi) ln w ] + Fh_g(sigma_raw)         (Fh, Dh: the gene's table, ppcx_disp.h)
 //   dph = sum [ - ln w ] + Dh_g(sigma_raw)  = sum [ psi(y + phi) - psi(phi) - ln w ]
@@ -218,14 +294,15 @@ struct GeneSumsV { double lik, dph, Sr, Tx[CM]; };
 template <int CM> struct GeneSums { static constexpr int N = 3 + CM; };
 
 // a lane's share of the gene: fold the accumulators of its cells into the hand-over sums (the table's part is added by
-// the lanes that evaluate it, ppcx_gene.h lane_gene_sums)
+// the lanes that evaluate it, ppcx_gene.h lane_gene_sums). scale: 2^-k of the gene's window (1 for the general cell): the cells'
+// q and rho were those of w' = 2^-k w, 2^k times too large (the logarithms' k ln 2 per cell is added once per gene by the caller).
 template <int CM>
-PPCX_HD void cell_acc_close(const GeneParams<CM>& gp, const CellAcc<CM>& a, GeneSumsV<CM>* o) {
+PPCX_HD void cell_acc_close(const GeneParams<CM>& gp, const CellAcc<CM>& a, double scale, GeneSumsV<CM>* o) {
   o->lik = -fma(gp.phi, a.SL, a.SA);
   o->dph = -a.SL;
-  o->Sr = fma(gp.invphi, a.SYq, a.Sq);
+  o->Sr = scale * fma(gp.invphi, a.SYq, a.Sq);
 #pragma unroll
-  for (int c = 0; c < CM; ++c) o->Tx[c] = a.Tx[c];
+  for (int c = 0; c < CM; ++c) o->Tx[c] = scale * a.Tx[c];
 }
 
 // Result of closing one gene: its log-density contribution, the gradient of its own coordinates and

@@ -10,12 +10,13 @@
 
 using namespace ppcx;
 
+static const double* window_table() { static double t[2 * kWinTabSize]; static bool init = false; if (!init) { fill_window_log_table(t); init = true; } return t; }
 static const double* log_table() { static double t[2 * kLogTabSize]; static bool init = false; if (!init) { fill_log_table(t); init = true; } return t; }
 
 struct EmulModel {
   Dims d; int CM;
   std::vector<int> counts; std::vector<double> E, expo, X, Sy, SyE, SyX, SX, ncell, Lg1;
-  std::vector<double> disp; std::vector<unsigned char> gflags;     // dispersion tables (ppcx_disp.h), bit 0: excluded cells
+  std::vector<double> disp; std::vector<unsigned char> gflags; double e_min = 1.0, e_max = 1.0;     // dispersion tables (ppcx_disp.h), bit 0: excluded cells
 };
 
 static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, const double* X, const double* expo,
@@ -27,6 +28,8 @@ static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, c
   m.X.assign(X, X + (size_t)S * C); m.X.resize((size_t)S * C + 64, 0.0); m.expo.assign(expo, expo + S); m.E.assign(S + 64, 0.0);
   int x0 = 1;
   for (int s = 0; s < S; ++s) { m.E[s] = exp(expo[s]); if (X[s] != 1.0) x0 = 0; }
+  m.e_min = m.e_max = m.E[0];
+  for (int s = 1; s < S; ++s) { if (m.E[s] < m.e_min) m.e_min = m.E[s]; if (m.E[s] > m.e_max) m.e_max = m.E[s]; }
   m.d.x0_is_one = x0;
   int x1b = (C >= 2);
   for (size_t i = (size_t)S; i < (size_t)S * C && x1b; ++i) if (X[i] != 0.0 && X[i] != 1.0) x1b = 0;
@@ -50,9 +53,9 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
   if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
   for (int g = 0; g < d.G; ++g) {
     // log-likelihood kernel (one lane per gene here)
-    CellData cd; cd.counts = m.counts.data(); cd.disp = m.disp.data(); cd.gflags = m.gflags.data();
+    CellData cd; cd.counts = m.counts.data(); cd.disp = m.disp.data(); cd.gflags = m.gflags.data(); cd.Sy = m.Sy.data(); cd.ncell = m.ncell.data(); cd.e_min = m.e_min; cd.e_max = m.e_max;
     GeneSumsV<CM> o;
-    lane_gene_sums<CM, 1>(d, c, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), o);
+    lane_gene_sums<CM, 1>(d, c, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), window_table(), o);
     // close kernel
     GeneCtx<CM> x2;
     gene_load<CM>(d, c, v, g, x2);
@@ -157,9 +160,9 @@ template <int CM>
 static void pipelined_loglik(const EmulModel& m, const Cmd& x, const VecRef& v, std::vector<GeneSumsV<CM>>& sums) {
   if (x.type == CMD_DONE || x.type == CMD_FLUSH) return;
   if (x.evaluated && x.type != CMD_LEAF) return;               // closed, and nothing was anticipated after it
-  CellData cd; cd.counts = m.counts.data(); cd.disp = m.disp.data(); cd.gflags = m.gflags.data();
+  CellData cd; cd.counts = m.counts.data(); cd.disp = m.disp.data(); cd.gflags = m.gflags.data(); cd.Sy = m.Sy.data(); cd.ncell = m.ncell.data(); cd.e_min = m.e_min; cd.e_max = m.e_max;
   for (int g = 0; g < m.d.G; ++g)
-    lane_gene_sums<CM, 1>(m.d, x, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), sums[g]);
+    lane_gene_sums<CM, 1>(m.d, x, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), window_table(), sums[g]);
 }
 template <int CM>
 static void pipelined_gene(const EmulModel& m, const Cmd& y, const VecRef& v, double* draws, bool spec,
