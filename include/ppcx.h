@@ -66,9 +66,10 @@ PPCX_API int ppcx_model_set_exclusions(ppcx_model* m, int n_excl, const int32_t*
 PPCX_API int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int workgroups); /* 0 = automatic; lanes: power of two <= 64 */
 PPCX_API int ppcx_model_get_launch(const ppcx_model* m, int* lanes_per_gene, int* nblocks);
 /* round structure of the NUTS fits of this model. pipelined: -1 = two launches per leapfrog wherever the model allows it
-   (default), 0 = always the three-launch round; stream_groups: 0 = by the number of chains (default), n = the chains run in
-   n groups on their own streams. A chain's draws do not depend on stream_groups. The initial values come from the
-   environment variables PPCX_PIPELINE / PPCX_STREAM_GROUPS, read once when the model is created. */
+   (default), 0 = always the three-launch round, -2 = leave the setting as it is; stream_groups: 0 = by the number of chains
+   (default), n = the chains run in n groups on their own streams, -1 = leave the setting as it is. A chain's draws do not
+   depend on stream_groups. The initial values come from the environment variables PPCX_PIPELINE / PPCX_STREAM_GROUPS, read
+   once when the model is created. */
 PPCX_API int ppcx_model_set_rounds(ppcx_model* m, int pipelined, int stream_groups);
 /* Progress of a running NUTS fit (rstan prints the chains' iterations; a fit of minutes need not be silent, and a chain that left
    the reference's 150 warm-up iterations with a very small step size -- every transition at the maximum tree depth, DESIGN.md

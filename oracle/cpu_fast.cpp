@@ -82,7 +82,7 @@ static double eval(FastModel& m, const double* u, double* grad, int threads) {
       coord_consts(d, v, i, u[i]);
     }
     GeneSumsV<CM> o;
-    lane_gene_sums<CM, 1>(d, c, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), tab, m.wtab.data(), o);
+    lane_gene_sums<CM, 1>(d, c, v, cd, g, gene_pre_load(d, v, cd, g), 0, m.E.data(), m.expo.data(), m.X.data(), tab, m.wtab.data(), o);
     gene_load<CM>(d, c, v, g, x);
     double pn[NCM], minv[NCM], gn[NCM], part[10];
     gene_finish<CM>(d, c, v, x, o, m.Sy.data(), m.SyE.data(), m.SyX.data(), m.SX.data(), m.ncell.data(), m.Lg1.data(), part, pn, minv, gn);

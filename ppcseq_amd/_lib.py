@@ -277,9 +277,10 @@ class Model:
         _check(load().ppcx_fit_nuts_xchg(self._h, C.byref(cfg), xchg._h, C.byref(h)))
         return Fit(self, h)
 
-    def set_rounds(self, pipelined=-1, stream_groups=0):
-        """Round structure of this model's NUTS fits: pipelined -1 = wherever the model allows it (default), 0 = the
-        three-launch round; stream_groups 0 = by the number of chains, n = n chain groups on their own streams."""
+    def set_rounds(self, pipelined=-2, stream_groups=-1):
+        """Round structure of this model's NUTS fits: pipelined -1 = wherever the model allows it (the library's default), 0 = the
+        three-launch round; stream_groups 0 = by the number of chains (the library's default), n = n chain groups on their own
+        streams. An argument left out (-2 / -1) leaves that setting as it is."""
         _check(load().ppcx_model_set_rounds(self._h, int(pipelined), int(stream_groups)))
 
     def set_progress(self, fn=None, every_seconds=1.0):

@@ -44,6 +44,9 @@ struct TestHooks {
 static TestHooks g_test;
 #endif
 
+#ifdef PPCX_TRACE
+static unsigned long long* g_trace_dev = nullptr;    // development builds: stamps of the log-likelihood passes (ppcx_kernels.h)
+#endif
 struct ppcx_model {
   int device;
   Dims d;
@@ -416,8 +419,9 @@ extern "C" int ppcx_model_set_launch(ppcx_model* m, int lanes_per_gene, int work
 }
 extern "C" int ppcx_model_set_rounds(ppcx_model* m, int pipelined, int stream_groups) {
   if (!m) return fail(PPCX_ERR_ARG, "model is NULL");
-  if (pipelined < -1 || pipelined > 1 || stream_groups < 0 || stream_groups > 64) return fail(PPCX_ERR_ARG, "pipelined must be -1, 0 or 1 and stream_groups 0 .. 64");
-  m->opt_pipelined = pipelined; m->opt_stream_groups = stream_groups;
+  if (pipelined < -2 || pipelined > 1 || stream_groups < -1 || stream_groups > 64) return fail(PPCX_ERR_ARG, "pipelined must be -2 .. 1 and stream_groups -1 .. 64");
+  if (pipelined != -2) m->opt_pipelined = pipelined;           // -2 / -1: leave that setting as it is
+  if (stream_groups != -1) m->opt_stream_groups = stream_groups;
   return PPCX_OK;
 }
 static bool model_pipelines(const ppcx_model* m) {
@@ -613,6 +617,9 @@ static int loglik_args(ppcx_model* m, Work& w, int nchains, int reserve, LoglikA
   la.vecs = w.vecs; la.Dpad = w.Dpad; la.cmds = w.cmds[w.launches & 1]; la.sums = w.sums; la.logtab = m->d_logtab; la.wintab = m->d_wintab; la.order = m->d_order;
   la.lgL = 0; while ((1 << la.lgL) < m->L) ++la.lgL;
   la.nchains = nact; la.active = w.n_active > 0 ? w.active : nullptr; la.nbpc = pl.nbpc; la.bounds = pl.d_bounds;
+#ifdef PPCX_TRACE
+  la.trace = g_trace_dev;
+#endif
   return PPCX_OK;
 }
 static int launch_loglik(ppcx_model* m, Work& w, int nchains) {
@@ -1048,6 +1055,20 @@ extern "C" int ppcx_testing_bench_kernel(ppcx_model* m, int which, int nchains, 
   HIPCHK(hipStreamSynchronize(st));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   *ms_per_launch = (double)ms / reps;
+#ifdef PPCX_TRACE
+  if (const char* path = getenv("PPCX_TRACE_FILE")) {       // one more launch, stamped; the stamps go to the file as raw uint64
+    const size_t n = (size_t)kTraceBlocks * 4 * kTracePasses * kTraceStamps;
+    HIPCHK(hipMalloc(&g_trace_dev, sizeof(unsigned long long) * n));
+    HIPCHK(hipMemset(g_trace_dev, 0, sizeof(unsigned long long) * n));
+    rc = one();
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h(n);
+    HIPCHK(hipMemcpy(h.data(), g_trace_dev, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(g_trace_dev); g_trace_dev = nullptr;
+    if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), n, f); fclose(f); }
+    if (rc != PPCX_OK) return rc;
+  }
+#endif
   return PPCX_OK;
 }
 #endif
@@ -1174,7 +1195,38 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
   HIPCHK(hipSetDevice(m->device));
   const int nch = cfg->chains, D = m->d.D, iter = cfg->iter, n_keep = cfg->iter - cfg->warmup;
   choose_launch(m, nch);
-  ppcx_fit* f = new ppcx_fit();
+  // Round structure. Pipelined (default where it applies): two launches per leapfrog, the state machine beside the
+  // log-likelihood workgroups (ppcx_kernels.hip, "Pipelined rounds"). It needs a model whose cells read the anticipated
+  // constants only (no per-cell linear predictor). The choice must not depend on the number of chains: the two round
+  // structures sum the kinetic energy of fresh momenta in different orders, and a chain's draws may not depend on its
+  // company. (With more chains than the chip holds workgroups the state machines simply run ahead of the log-likelihood
+  // workgroups instead of beside them.) ppcx_model_set_rounds(m, 0, ...) selects the three-launch round.
+  const bool piped = model_pipelines(m);
+  // The exchange group is looked at BEFORE anything is allocated (a refused call leaves nothing behind), and the group's fit
+  // counter -- the epoch in every sequence number -- moves before anything that can fail on one rank alone: a rank whose
+  // allocation fails has then counted this fit like its peers, and it tells them that it has left (leave() below) instead of
+  // letting them wait for the timeout, now and in every later fit of the group.
+  XchgArgs xa;
+  bool xa_live = false;
+  if (xg) {
+    if (!xg->connected) return fail(PPCX_ERR_ARG, "the exchange group is not connected");
+    if (xg->device != m->device) return fail(PPCX_ERR_ARG, "the exchange group lives on another device than the shard");
+    if (cfg->chains > xg->max_chains) return fail(PPCX_ERR_ARG, "more chains than the exchange group was created for");
+    if (!piped) return fail(PPCX_ERR_LIMIT, "the direct exchange runs inside pipelined rounds, which this model (a per-cell linear predictor) "
+                                             "or ppcx_model_set_rounds rules out: use ppcx_fit_nuts_comm");
+    xg->epoch += 1;                             // every rank counts the fits of the group: sequence numbers of earlier fits never match
+    xchg_fill(xg, &xa);
+    xa_live = xg->nranks > 1;
+  }
+  ppcx_fit* f = nullptr;
+  auto leave = [&](int rc) {                    // every failure from here on: the peers' state machines are told, the fit is freed
+    const std::string msg = g_err;
+    if (xa_live) { (void)launch_xchg_abort_kernel(xa, m->stream); (void)hipStreamSynchronize(m->stream); }
+    if (f) ppcx_fit_free(f);
+    g_err = msg;
+    return rc;
+  };
+  f = new ppcx_fit();
   fit_attach(f, m); f->chains = nch; f->n_keep = n_keep; f->iter = iter;
   NutsConfig nc;
   nc.chains = nch; nc.iter = iter; nc.warmup = cfg->warmup; nc.seed = cfg->seed; nc.adapt_delta = cfg->adapt_delta;
@@ -1182,7 +1234,7 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
   nc.init_buffer = cfg->init_buffer; nc.term_buffer = cfg->term_buffer; nc.window = cfg->window;
   nc.chain_id_offset = cfg->chain_id_offset;
   f->cfg = nc;
-#define FHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ppcx_fit_free(f); return fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+#define FHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return leave(fail(PPCX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } while (0)
   if (n_keep > 0) FHIP(hipMalloc(&f->d_draws, sizeof(double) * (size_t)nch * n_keep * D));
   if (n_keep > 0) FHIP(hipMalloc(&f->d_lp, sizeof(double) * (size_t)nch * n_keep));
   FHIP(hipMalloc(&f->d_stepsize, sizeof(double) * (size_t)nch * iter));
@@ -1198,23 +1250,6 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
   FHIP(hipMemsetAsync(f->d_nleap, 0, sizeof(int) * (size_t)nch * iter, m->stream));
   FHIP(hipMemsetAsync(f->d_div, 0, sizeof(int) * (size_t)nch * iter, m->stream));
   FHIP(hipStreamSynchronize(m->stream));
-  // Round structure. Pipelined (default where it applies): two launches per leapfrog, the state machine beside the
-  // log-likelihood workgroups (ppcx_kernels.hip, "Pipelined rounds"). It needs a model whose cells read the anticipated
-  // constants only (no per-cell linear predictor). The choice must not depend on the number of chains: the two round
-  // structures sum the kinetic energy of fresh momenta in different orders, and a chain's draws may not depend on its
-  // company. (With more chains than the chip holds workgroups the state machines simply run ahead of the log-likelihood
-  // workgroups instead of beside them.) ppcx_model_set_rounds(m, 0, ...) selects the three-launch round.
-  const bool piped = model_pipelines(m);
-  XchgArgs xa;
-  if (xg) {
-    if (!xg->connected) return fail(PPCX_ERR_ARG, "the exchange group is not connected");
-    if (xg->device != m->device) return fail(PPCX_ERR_ARG, "the exchange group lives on another device than the shard");
-    if (cfg->chains > xg->max_chains) return fail(PPCX_ERR_ARG, "more chains than the exchange group was created for");
-    if (!piped) return fail(PPCX_ERR_LIMIT, "the direct exchange runs inside pipelined rounds, which this model (a per-cell linear predictor) "
-                                             "or ppcx_model_set_rounds rules out: use ppcx_fit_nuts_comm");
-    xg->epoch += 1;                             // every rank counts the fits of the group: sequence numbers of earlier fits never match
-    xchg_fill(xg, &xa);
-  }
   // Chains can also be split into groups that run on their own streams from their own host threads
   // (ppcx_model_set_rounds): while one group sits in its memory-bound gene kernel another group's log-likelihood
   // workgroups have the CUs: measured at cfg3 / 8 chains, pipelined rounds (final kernels of round 3, mean of two fits):
@@ -1238,7 +1273,7 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
     if (xg && xg->nranks > 1) G.w.xchg = &xa;
     if (g > 0) { FHIP(hipStreamCreateWithFlags(&G.w.stream, hipStreamNonBlocking)); G.w.own_stream = true; }
     int rc = work_alloc(G.w, m, G.n);
-    if (rc != PPCX_OK) { ppcx_fit_free(f); return rc; }
+    if (rc != PPCX_OK) return leave(rc);
     std::vector<ChainState> states(G.n);
     NutsConfig ncg = nc; ncg.chain_id_offset = nc.chain_id_offset + G.c0;
     for (int c = 0; c < G.n; ++c) state_init(states[c], ncg, c, 0);
@@ -1272,12 +1307,7 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
   const auto t1 = std::chrono::steady_clock::now();
   for (int g = 0; g < ngrp; ++g) if (grp[g].rc != PPCX_OK) {
     const int rc = grp[g].rc; const std::string e = grp[g].err;
-    if (xg && xg->nranks > 1) {                  // the peers' state machines wait for this rank: tell them it has left
-      (void)launch_xchg_abort_kernel(xa, m->stream);
-      (void)hipStreamSynchronize(m->stream);
-    }
-    ppcx_fit_free(f);
-    return fail(rc, e);
+    return leave(fail(rc, e));                   // (the peers' state machines wait for this rank: leave() tells them it has left)
   }
   f->seconds = std::chrono::duration<double>(t1 - t0).count();
   f->grad_evals = 0;

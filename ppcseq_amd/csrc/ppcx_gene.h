@@ -96,6 +96,30 @@ struct CellData {                // the chain-independent inputs of the log-like
   double e_min, e_max;           // smallest and largest exp(exposure_s): the window's bounds
 };
 
+// What a pass needs of a gene before its sweep, all of it addressed by the gene alone: the log-likelihood kernel requests it a
+// whole pass ahead (ppcx_kernels.hip loglik_passes), so that a pass starts with its constants in registers. (Every wavefront of
+// the launch starts and ends its passes at the same time -- equal costs since round 5 -- so a round trip at the start of a pass is
+// hidden by nobody; with the 17-instruction cell the sweep of 25 cells no longer dwarfs it.)
+struct GenePre { double phi, sigma, a0, Sy, n; int flags; };
+PPCX_HD GenePre gene_pre_load(const Dims& d, const VecRef& v, const CellData& m, int g) {
+  GenePre r;
+  r.phi = v.at(V_C0, d.off_sigma_raw + g);       // phi = exp(-sigma_raw) and sigma_raw of the position being evaluated (coord_consts)
+  r.sigma = v.at(V_C2, d.off_sigma_raw + g);
+  r.a0 = v.at(V_C0, d.off_intercept + g);        // exp(intercept)
+  r.Sy = m.Sy[g]; r.n = m.ncell[g]; r.flags = m.gflags[g];
+  return r;
+}
+// how the 2 x kDispStride coefficients of a gene's panel are dealt to its lanes: NL lanes per function, CH coefficients each
+// (L >= 8: lanes 0-3 take Fh's chunks, lanes 4-7 Dh's, three coefficients each; L = 4: two lanes of six; L = 2: one lane per
+// function; a lone lane both). A lane evaluates its chunk times x^(CH chunk) and adds it to its own partial sum: the gene's
+// L-lane reduction, which follows anyway, adds the chunks up. Three coefficients per lane can be requested BEFORE the sweep and
+// held across it (six registers); the eleven of a whole function could not (round 5 first form: requested after the sweep, a
+// round trip per pass in the open).
+template <int L> struct DispDeal {
+  static constexpr int NL = L >= 8 ? 4 : (L >= 4 ? 2 : 1);
+  static constexpr int CH = kDispStride / NL;
+};
+
 // MODE 0: plain gene (e^t = E_s A); 1: two-group design (A or A1 by the sample's group, sX1 = the group column);
 // 2: more indicator columns (C > 2; sX1 = column 1 of X in LDS, column c at sX1 + (c - 1) S; ec[c] = exp(slope_c)):
 // A times the ec of the sample's columns
@@ -201,31 +225,50 @@ PPCX_HD void generic_cells(const Dims& d, const Cmd& c, const VecRef& v, int g, 
 // GEN = false: a model in which every gene factorises (X[,1] == 1 and slopes only on indicator columns) -- the
 // per-cell-eta path is not compiled in, which leaves the registers to the sweep
 template <int CM, int L, bool GEN = true>
-PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const CellData& m, int g, int sub,
+PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const CellData& m, int g, const GenePre& pre, int sub,
                             const double* sE, const double* sExpo, const double* sX, const double* tab, const double* wtab,
-                            GeneSumsV<CM>& o) {
+                            GeneSumsV<CM>& o
+#ifdef PPCX_TRACE
+                            , unsigned long long* trace_stamps = nullptr
+#endif
+                            ) {
+#if defined(PPCX_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+#define PPCX_GSTAMP(k) do { if (trace_stamps) trace_stamps[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PPCX_GSTAMP(k) ((void)0)
+#endif
   const int S = d.S;
-  const int i_sr = d.off_sigma_raw + g;
   const bool has_slopes = g < d.K && d.C >= 2;
   const bool two = has_slopes && d.x0_is_one && d.x1_binary;
   const bool generic = GEN && (!d.x0_is_one || (has_slopes && !two));
   GeneParams<CM> gp;
-  gp.phi = v.at(V_C0, i_sr);
-  const double sigma = v.at(V_C2, i_sr);
+  gp.phi = pre.phi;
+  const double sigma = pre.sigma;
   gp.sigma_raw = sigma;
   gp.invphi = fast_rcp(gp.phi);                             // once per gene and pass: cheaper than another constant in memory
-  const double A = v.at(V_C0, d.off_intercept + g) * gp.invphi;       // exp(intercept + sigma_raw)
-  const bool masked = (m.gflags[g] & 1) != 0;
+  const double A = pre.a0 * gp.invphi;                      // exp(intercept + sigma_raw)
+  const bool masked = (pre.flags & 1) != 0;
   const int* row = m.counts + (long)g * S;
-  // the gene's table: lane 0 takes the panel's Fh coefficients, lane 1 its Dh coefficients (a lone lane both). Their first and
-  // last ones are requested here, ahead of the sweep -- that brings the panel's cache lines in -- and the others after it: held
-  // across the sweep they would cost it 18 registers
+  // the gene's table: the lane's chunk of the panel's coefficients (DispDeal), requested here, ahead of the sweep
+  constexpr int NL = DispDeal<L>::NL, CH = DispDeal<L>::CH;
   const DispRef dr = disp_ref(sigma);
-  const bool tab_lane = dr.in && sub < 2;
-  const double* pc = m.disp + (((long)g * kDispPanels + dr.panel) * 2 + (L > 1 && sub == 1 ? 1 : 0)) * kDispStride;
-  double cf_first = 0.0, cf_last = 0.0;
-  if (tab_lane) { cf_first = pc[0]; cf_last = pc[L > 1 ? kDispDeg : kDispStride + kDispDeg]; }
+  const int fn = L == 1 ? 0 : sub / NL, jch = L == 1 ? 0 : sub - fn * NL;       // function (0: Fh, 1: Dh; >= 2: none), chunk
+  const bool tab_lane = dr.in && (L == 1 || fn < 2);
+  const double* pc = m.disp + (((long)g * kDispPanels + dr.panel) * 2 + (fn & 1)) * kDispStride + jch * CH;
+  double cf[CH], cf2[L == 1 ? CH : 1];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) cf[k] = 0.0;
+  cf2[0] = 0.0;
+  if (tab_lane) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k) cf[k] = pc[k];
+    if (L == 1) {
+#pragma unroll
+      for (int k = 0; k < CH; ++k) cf2[k] = pc[kDispStride + k];
+    }
+  }
   CellAcc<CM> acc; acc.zero();
+  PPCX_GSTAMP(5);
   if (GEN) {
     if (PPCX_WAVE_ANY(generic)) {
       if (generic) generic_cells<CM, L>(d, c, v, g, has_slopes, row, sExpo, sX, sub, gp, tab, acc);
@@ -264,28 +307,32 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
 #undef PPCX_SWEEP
     }
   }
+  PPCX_GSTAMP(6);
   if (!win) gw.scale = 1.0;
   cell_acc_close<CM>(gp, acc, gw.scale, &o);
   if (win && sub == 0 && gw.k != 0) {                       // the cells' logarithms were those of 2^-k w: k ln 2 per cell, once per gene
     const double kd = (double)gw.k;
     const double klog2 = fma(kd, 6.93147180369123816490e-01, kd * 1.90821492927058770002e-10);
-    const double n = m.ncell[g];
-    o.lik -= klog2 * fma(gp.phi, n, m.Sy[g]);
-    o.dph -= klog2 * n;
+    o.lik -= klog2 * fma(gp.phi, pre.n, pre.Sy);
+    o.dph -= klog2 * pre.n;
   }
   if (tab_lane) {
-    if (L > 1) {
-      double p = cf_last;
+    double hv = cf[CH - 1];
 #pragma unroll
-      for (int k = kDispDeg - 1; k >= 1; --k) p = fma(p, dr.x, pc[k]);
-      p = fma(p, dr.x, cf_first);
-      if (sub == 0) o.lik += p; else o.dph += p;
-    } else {
-      double p = pc[kDispDeg], p2 = cf_last;
-#pragma unroll
-      for (int k = kDispDeg - 1; k >= 1; --k) { p = fma(p, dr.x, pc[k]); p2 = fma(p2, dr.x, pc[kDispStride + k]); }
-      o.lik += fma(p, dr.x, cf_first); o.dph += fma(p2, dr.x, pc[kDispStride]);
+    for (int k = CH - 2; k >= 0; --k) hv = fma(hv, dr.x, cf[k]);
+    if (NL > 1) {                                           // times x^(CH chunk): chunk 0 .. NL - 1
+      const double x3 = dr.x * dr.x * dr.x, xc = CH == 3 ? x3 : x3 * x3;
+      double xp = (jch & 1) ? xc : 1.0;
+      if (NL > 2) xp = (jch & 2) ? xp * (xc * xc) : xp;
+      hv *= xp;
     }
+    if (L == 1) {
+      double h2 = cf2[CH - 1];
+#pragma unroll
+      for (int k = CH - 2; k >= 0; --k) h2 = fma(h2, dr.x, cf2[k]);
+      o.lik += hv; o.dph += h2;
+    } else if (fn == 0) o.lik += hv;
+    else o.dph += hv;
   }
   if (PPCX_WAVE_ANY(!dr.in)) {                              // outside the tabulated range: the functions themselves, from the row
     PPCX_KEEP_BRANCH();

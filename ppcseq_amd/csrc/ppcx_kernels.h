@@ -24,7 +24,13 @@ struct LoglikArgs {
   const int* active;            // [nchains] their indices in cmds / vecs / sums (null: 0 .. nchains - 1)
   int nbpc;                     // workgroups per chain; wavefront j = 0 .. 4 nbpc - 1 of a chain takes the gene positions
   const int* bounds;            // [4 nbpc + 1]  bounds[j] .. bounds[j + 1] - 1 (host: plan_launch, balanced by cost)
+#ifdef PPCX_TRACE               // development builds only (scripts/gpu_pass_trace.py): clock stamps of the passes' phases
+  unsigned long long* trace;    // [kTraceBlocks][4 waves][kTracePasses][kTraceStamps] or null
+#endif
 };
+#ifdef PPCX_TRACE
+constexpr int kTraceBlocks = 64, kTracePasses = 8, kTraceStamps = 8;
+#endif
 
 struct CloseArgs {
   Dims d;

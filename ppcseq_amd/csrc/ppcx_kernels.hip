@@ -48,6 +48,27 @@ __device__ __forceinline__ double wave_xor_add_rt(double v, int lane_xor_mask) {
   const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
   return v + __hiloint2double(hi, lo);
 }
+// v of lane i moved by a DPP control word (data-parallel primitives: a VALU move, no LDS round trip); lanes the
+// control leaves without a source, or outside row_mask, receive 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over the L lanes that share a gene, every lane ending with the total: inside a row of 16 lanes by DPP moves (neighbours,
+// pairs, the other quad by row_half_mirror, the other half-row by row_mirror -- vector-unit moves, no LDS round trips: nine
+// dependent ds_bpermute round trips per pass were half a microsecond of nothing but latency), across rows by ds_bpermute
+template <int L>
+__device__ __forceinline__ double group_sum(double v) {
+  if (L >= 2) v += dpp_take<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+  if (L >= 4) v += dpp_take<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+  if (L >= 8) v += dpp_take<0x141, 0xf>(v);    // row_half_mirror
+  if (L >= 16) v += dpp_take<0x140, 0xf>(v);   // row_mirror
+  if (L >= 32) v = wave_xor_add_rt(v, 16);
+  if (L >= 64) v = wave_xor_add_rt(v, 32);
+  return v;
+}
 // A resident launch (host: plan_launch): as many workgroups as the chip holds at once (4 per CU at 128 VGPRs), divided
 // among the chains; every wavefront owns a contiguous range of the host's gene order -- bounds[j] .. bounds[j + 1] --
 // chosen on the host so that all ranges cost the same, and walks it 64 / L genes at a time. All wavefronts start
@@ -60,46 +81,70 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
   constexpr int L = 1 << LG, GPW = 64 >> LG;     // lanes per gene, genes per wavefront and pass
   const Dims& d = a.d;
   const int sub = lane & (L - 1), gl = lane >> LG;
-  int g_next = a.order[p0 + gl < p1 ? p0 + gl : p1 - 1];
+  // One pass ahead: while pass p is swept, the constants of pass p + 1's genes (gene_pre_load) and the gene indices of pass
+  // p + 2 are on their way.
+  int g_cur = a.order[p0 + gl < p1 ? p0 + gl : p1 - 1];
+  int g_next = a.order[p0 + GPW + gl < p1 ? p0 + GPW + gl : p1 - 1];
+  GenePre pre_cur = gene_pre_load(d, v, a.cd, g_cur);
+#ifdef PPCX_TRACE
+  unsigned long long* tr = nullptr;
+  if (a.trace && lane == 0 && (blockIdx.x % 16) == 0 && blockIdx.x / 16 < kTraceBlocks)
+    tr = a.trace + (((long)(blockIdx.x / 16) * 4 + (threadIdx.x >> 6)) * kTracePasses) * kTraceStamps;
+  int tpass = 0;
+#define PPCX_STAMP(k) do { if (tr && tpass < kTracePasses) tr[tpass * kTraceStamps + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PPCX_STAMP(k) ((void)0)
+#endif
   for (int p = p0; p < p1; p += GPW) {
+    PPCX_STAMP(0);
+#ifdef PPCX_TRACE
+    if (tr && tpass < kTracePasses) tr[tpass * kTraceStamps + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef PPCX_PRIO_BALANCE
-    // the SIMD serves its oldest wavefront first, so its four wavefronts finish one after the other and the last runs
-    // alone, at half the issue rate of dependent fp64 code: a wavefront with more passes left goes first instead
+    // the SIMD serves its oldest wavefront first, so its four wavefronts (one from each quarter of the launch's workgroups)
+    // finish one after the other and the last ones run alone, at a fraction of the issue rate: a wavefront with more passes
+    // left goes first instead
     {
       const int rem = (p1 - p + GPW - 1) / GPW;
       if (rem >= 4) __builtin_amdgcn_s_setprio(3); else if (rem == 3) __builtin_amdgcn_s_setprio(2); else if (rem == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     }
 #endif
     const bool act = p + gl < p1;                // lanes past the end of the range repeat its last gene and store nothing
-    const int g = g_next;
-    const int pn = p + GPW + gl;
-    if (p + GPW < p1) g_next = a.order[pn < p1 ? pn : p1 - 1];
+    const int g = g_cur;
+    const GenePre pre = pre_cur;
+    if (p + GPW < p1) {
+      g_cur = g_next;
+      pre_cur = gene_pre_load(d, v, a.cd, g_next);
+      const int pn = p + 2 * GPW + gl;
+      g_next = a.order[pn < p1 ? pn : p1 - 1];
+    }
     if (CM > 2 && d.x0_is_one && !PPCX_WAVE_ANY(g < d.K)) {
       // a pass of plain genes in a model with more than two design columns: the two-column instantiation of the gene's work
       // (its accumulators carry two slope sums, not CM: the registers the wider one needs cost the row sweep spills), and
       // the three sums of a plain gene
       GeneSumsV<2> o2;
-      lane_gene_sums<2, L, false>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, swin, o2);
-#pragma unroll
-      for (int msk = 1; msk < L; msk <<= 1) {
-        o2.lik = wave_xor_add_rt(o2.lik, msk); o2.dph = wave_xor_add_rt(o2.dph, msk); o2.Sr = wave_xor_add_rt(o2.Sr, msk);
-      }
+      lane_gene_sums<2, L, false>(d, c, v, a.cd, g, pre, sub, sE, sExpo, sX, stab, swin, o2);
+      o2.lik = group_sum<L>(o2.lik); o2.dph = group_sum<L>(o2.dph); o2.Sr = group_sum<L>(o2.Sr);
       if (act && sub == 0) { const long G = d.G; sums[0 * G + g] = o2.lik; sums[1 * G + g] = o2.dph; sums[2 * G + g] = o2.Sr; }
       continue;
     }
     GeneSumsV<CM> o;
-    lane_gene_sums<CM, L, GEN>(d, c, v, a.cd, g, sub, sE, sExpo, sX, stab, swin, o);
+    PPCX_STAMP(1);
+#ifdef PPCX_TRACE
+    lane_gene_sums<CM, L, GEN>(d, c, v, a.cd, g, pre, sub, sE, sExpo, sX, stab, swin, o, (tr && tpass < kTracePasses) ? tr + tpass * kTraceStamps : nullptr);
+#else
+    lane_gene_sums<CM, L, GEN>(d, c, v, a.cd, g, pre, sub, sE, sExpo, sX, stab, swin, o);
+#endif
+    PPCX_STAMP(2);
     // sum X_sc rho is needed of genes with slopes only (and of every gene when X[,1] != 1): a pass without such genes
     // neither reduces nor stores it (the close kernel does not use those entries of a plain gene)
     const bool with_tx = any_generic && (!d.x0_is_one || PPCX_WAVE_ANY(g < d.K));
-    // L-lane butterfly: every lane of the gene ends with the gene totals
+    // every lane of the gene ends with the gene totals
+    o.lik = group_sum<L>(o.lik); o.dph = group_sum<L>(o.dph); o.Sr = group_sum<L>(o.Sr);
+    PPCX_STAMP(3);
+    if (with_tx) {
 #pragma unroll
-    for (int msk = 1; msk < L; msk <<= 1) {
-      o.lik = wave_xor_add_rt(o.lik, msk); o.dph = wave_xor_add_rt(o.dph, msk); o.Sr = wave_xor_add_rt(o.Sr, msk);
-      if (with_tx) {
-#pragma unroll
-        for (int cc = 0; cc < CM; ++cc) if (cc < d.C) o.Tx[cc] = wave_xor_add_rt(o.Tx[cc], msk);
-      }
+      for (int cc = 0; cc < CM; ++cc) if (cc < d.C) o.Tx[cc] = group_sum<L>(o.Tx[cc]);
     }
     if (act && sub == 0) {
       const long G = d.G;
@@ -109,7 +154,12 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
         for (int cc = 0; cc < CM; ++cc) if (cc < d.C) sums[(3 + cc) * G + g] = o.Tx[cc];
       }
     }
+    PPCX_STAMP(4);
+#ifdef PPCX_TRACE
+    ++tpass;
+#endif
   }
+#undef PPCX_STAMP
 }
 
 // the body of a log-likelihood workgroup: range block jb of the chain in column `col` of the launch.
@@ -206,14 +256,6 @@ __global__ __launch_bounds__(256, GEN ? PPCX_LOGLIK_OCC : PPCX_LOGLIK_OCC_FAST) 
 // kernel A2: one thread per gene closes it -- priors, gradient, second half kick of the gene's coordinates,
 // U-turn dot products and subtree slots -- and the workgroup leaves its partial sums in a slab.
 // -----------------------------------------------------------------------------------------------------
-// v of lane i moved by a DPP control word (data-parallel primitives: a VALU move, no LDS round trip); lanes the
-// control leaves without a source, or outside row_mask, receive 0
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_take(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
 // sum over the wavefront, left in lane 63: inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the
 // row totals travel to the next row (row_bcast:15 into rows 1 and 3) and to the upper half (row_bcast:31 into rows 2, 3)
 __device__ __forceinline__ double wave_sum_to_lane63(double v) {

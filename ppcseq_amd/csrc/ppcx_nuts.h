@@ -370,7 +370,9 @@ PPCX_HD void issue_eps_try(ChainScalars& st, Cmd& nc) {
   // path of PH_EPS in ppcx_step_kernel. Round 4 traced it: the optimised LLVM IR is correct, the AMDGPU backend drops the
   // copy on one of the two predecessor paths after AMDGPUCodeGenPrepare has broken the SLP-made <2 x i32> phi of
   // (rng_c1, rng_c3) into scalars; the library is built without SLP vectorisation -- ppcseq_amd/build.py, DESIGN.md
-  // section 3, profiles/r04_miscompile/.)
+  // section 3, profiles/r04_miscompile/. Round 5 keeps the barrier as well: it costs nothing measurable, and a build of these
+  // sources with other flags -- a packager's Makefile, an R package build -- must not get the wrong Philox streams silently.)
+  PPCX_OPAQUE(st.eps_attempt);
   nc.rng_c1 = (unsigned)st.eps_call; nc.rng_c3 = (unsigned)st.eps_attempt;
   st.eps_attempt++;
   st.phase = PH_EPS;

@@ -55,7 +55,7 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
     // log-likelihood kernel (one lane per gene here)
     CellData cd; cd.counts = m.counts.data(); cd.disp = m.disp.data(); cd.gflags = m.gflags.data(); cd.Sy = m.Sy.data(); cd.ncell = m.ncell.data(); cd.e_min = m.e_min; cd.e_max = m.e_max;
     GeneSumsV<CM> o;
-    lane_gene_sums<CM, 1>(d, c, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), window_table(), o);
+    lane_gene_sums<CM, 1>(d, c, v, cd, g, gene_pre_load(d, v, cd, g), 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), window_table(), o);
     // close kernel
     GeneCtx<CM> x2;
     gene_load<CM>(d, c, v, g, x2);
@@ -162,7 +162,7 @@ static void pipelined_loglik(const EmulModel& m, const Cmd& x, const VecRef& v, 
   if (x.evaluated && x.type != CMD_LEAF) return;               // closed, and nothing was anticipated after it
   CellData cd; cd.counts = m.counts.data(); cd.disp = m.disp.data(); cd.gflags = m.gflags.data(); cd.Sy = m.Sy.data(); cd.ncell = m.ncell.data(); cd.e_min = m.e_min; cd.e_max = m.e_max;
   for (int g = 0; g < m.d.G; ++g)
-    lane_gene_sums<CM, 1>(m.d, x, v, cd, g, 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), window_table(), sums[g]);
+    lane_gene_sums<CM, 1>(m.d, x, v, cd, g, gene_pre_load(m.d, v, cd, g), 0, m.E.data(), m.expo.data(), m.X.data(), log_table(), window_table(), sums[g]);
 }
 template <int CM>
 static void pipelined_gene(const EmulModel& m, const Cmd& y, const VecRef& v, double* draws, bool spec,

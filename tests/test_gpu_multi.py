@@ -450,3 +450,25 @@ def test_do_inference_with_the_genes_sharded_over_two_ranks():
     assert np.max(np.abs(slope - one.slope)) < 0.25
     assert np.median(np.abs(upper - one.upper) / (1 + one.upper)) < 0.06 and np.max(np.abs(upper - one.upper) / (1 + one.upper)) < 0.5
     assert np.median(np.abs(lower - one.lower) / (1 + one.lower)) < 0.1
+
+
+def test_a_refused_exchange_fit_leaves_nothing_on_the_device(L):
+    """ppcx_fit_nuts_xchg looks at its exchange group before it allocates anything: the direct exchange needs pipelined rounds,
+    which a model with a continuous covariate does not run -- a documented, expected refusal (PPCX_ERR_LIMIT: use
+    ppcx_fit_nuts_comm) -- and a refused call must leave no draws buffer behind and no reference that would keep the model's
+    count matrix on the device after Model.close()."""
+    d = ind.synth(300, 40, K=20, seed=31, C=2)
+    X = d["X"].copy(); X[:, 1] = np.linspace(-1.0, 1.0, 40)                 # a continuous covariate: per-cell linear predictor
+    free0, _ = L.device_memory(0)
+    m = L.Model(d["counts"], X, d["exposure"], 20)
+    xg = L.Xchg(1, 0, 4)
+    try:
+        for _ in range(3):
+            with pytest.raises(L.PpcxError, match="ppcx error -6"):          # PPCX_ERR_LIMIT
+                m.fit_nuts_xchg(xg, chains=4, iter=2000, warmup=100, seed=1)   # would hold 4 x 1900 x D doubles of draws
+        free1, _ = L.device_memory(0)
+    finally:
+        xg.close(); m.close()
+    free2, _ = L.device_memory(0)
+    assert free0 - free1 < 64 << 20, "the refused fits left their draws on the device"   # the model itself is a few MB
+    assert abs(free2 - free0) < 16 << 20, "Model.close() was deferred by a fit that was never handed out"
