@@ -118,7 +118,9 @@ PPCX_HD double table_log(double x, const double* tab) {
 // (ppcx_model.h GeneWindow): the index is the two low bits of the exponent field and the top 8 mantissa bits, the entries
 // are 1/c and log c of the bin's centre c = 2^e (1 + (j + 1/2)/256), so that r = x/c - 1 comes from ONE multiply-add with x
 // itself and log x = log c + log1p(r): no v_frexp_mant / v_frexp_exp / conversion / exponent multiply-add per cell.
-// Two arrays of 1024 doubles (16 KB), wt[j] = 1/c_j and wt[1024 + j] = log c_j.
+// 1024 pairs of doubles (16 KB), wt[2 j] = 1/c_j and wt[2 j + 1] = log c_j: ONE 16-byte LDS read per cell. (A random gather of
+// the lanes' entries costs 11 LDS cycles per wave-instruction as one ds_read_b128 or as two ds_read_b64, and 19.5 as the
+// ds_read2st64_b64 that hipcc makes of two arrays: scripts/micro/lds_gather.hip.)
 constexpr int kWinTabBits = 10, kWinTabSize = 1 << kWinTabBits;
 constexpr int kWinBinades = 4;            // [1, 2), [2, 4), [4, 8), [8, 16)
 inline void fill_window_log_table(double* t /* 2 * kWinTabSize */) {    // host
@@ -126,19 +128,30 @@ inline void fill_window_log_table(double* t /* 2 * kWinTabSize */) {    // host
     const int e2 = j >> 8, m8 = j & 255;            // e2: exponent field & 3; field = 1023 + e  =>  e = (e2 + 1) & 3
     const int e = (e2 + 1) & 3;
     const long double c = ldexpl(1.0L + ((long double)m8 + 0.5L) / 256.0L, e);
-    t[j] = (double)(1.0L / c);
-    t[kWinTabSize + j] = (double)logl(1.0L / (long double)t[j]);      // log of the reciprocal actually stored
+    t[2 * j] = (double)(1.0L / c);
+    t[2 * j + 1] = (double)logl(1.0L / (long double)t[2 * j]);        // log of the reciprocal actually stored
   }
+}
+struct WinEntry { double cinv, logc; };
+PPCX_HD WinEntry window_entry(const double* wt, int j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  const v2d_t e = *reinterpret_cast<const v2d_t*>(wt + 2 * j);         // 16-byte aligned: one ds_read_b128
+  return WinEntry{e.x, e.y};
+#else
+  return WinEntry{wt[2 * j], wt[2 * j + 1]};
+#endif
 }
 // log x for x in [1, 16) (the host's statement of the windowed cell's logarithm, ppcx_model.h cell_back_win)
 PPCX_HD double window_log(double x, const double* wt) {
   const int j = (int)(dbl_bits(x) >> (52 - 8)) & (kWinTabSize - 1);
-  const double r = fma(x, wt[j], -1.0);
+  const WinEntry e = window_entry(wt, j);
+  const double r = fma(x, e.cinv, -1.0);
   double p = fma(r, 0.2, -0.25);
   p = fma(r, p, 1.0 / 3.0);
   p = fma(r, p, -0.5);
   p = fma(r, p, 1.0);
-  return fma(r, p, wt[kWinTabSize + j]);
+  return fma(r, p, e.logc);
 }
 
 // exp(x) for |x| < 700 by x = k ln2 + r, |r| <= ln2/2 and the rational form of Sun's fdlibm e_exp.c

@@ -248,7 +248,8 @@ PPCX_HD double cell_front_win(int y, double e, double A, double one, const GeneP
   q = fast_rcp(c.w);
 #endif
   const int j = (int)(dbl_bits(c.w) >> (52 - 8)) & (kWinTabSize - 1);
-  c.cinv = wt[j]; c.logc = wt[kWinTabSize + j];
+  const WinEntry we = window_entry(wt, j);
+  c.cinv = we.cinv; c.logc = we.logc;
   a.Sq += q; a.SYq = fma(c.yd, q, a.SYq);
   return SLOPES ? fma(c.yd, gp.invphi, 1.0) * q : 0.0;
 }
