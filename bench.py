@@ -49,10 +49,10 @@ def main():
                          "all-reduce between the launches of the three-launch round")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--cpu-full-cfg2", action="store_true",
-                    help="also time ONE WHOLE fit of BASELINE cfg2 (5 000 x 50, 4 chains, 150 + 250) on the host's cores -- the "
-                         "optimised CPU comparator under the oracle's NUTS driver, same seed -- beside the same fit on the GPU "
-                         "(about a minute of CPU time; off by default)")
+    ap.add_argument("--no-cpu-full-cfg2", action="store_true",
+                    help="skip `cpu_baseline.measured`: ONE WHOLE fit of BASELINE cfg2 (5 000 x 50, 4 chains, 150 + 250) timed end to "
+                         "end on the host's cores -- the optimised CPU comparator under the oracle's NUTS driver, same seed -- beside "
+                         "the same fit on the GPU (about 20 s of CPU time; part of the default run since round 5)")
     ap.add_argument("--stream-groups", type=int, default=0,
                     help="chain groups on their own streams for the timed fits (0 = the library's default: 3 from eight chains on, 2 from four)")
     ap.add_argument("--single-stream-steps", type=int, default=1,
@@ -319,8 +319,15 @@ def main():
             "roofline": roof, "ppc": ppc_obj, "cpu_baseline": cpu, "as_named_cfg3_one_chain_per_gpu": as_named, "single_stream": single,
             "concordance": None if (args.no_cpu_baseline or world > 1) else outlier_concordance(),
         }
-        if args.cpu_full_cfg2 and world == 1:
-            out["cpu_full_cfg2"] = cpu_full_cfg2(dev_index)
+        if cpu is not None and not args.no_cpu_full_cfg2 and world == 1:
+            # the one CPU / GPU pair that is MEASURED end to end (whole fits of cfg2), beside the extrapolated cfg3 figure
+            full = cpu_full_cfg2(dev_index)
+            cpu["measured"] = {"config": "cfg2", "workload": full["workload"], "cpu_s": full["cpu"]["seconds"], "gpu_s": full["gpu"]["seconds"],
+                               "cpu_ess_per_s": full["cpu"]["ess_per_s"], "gpu_ess_per_s": full["gpu"]["ess_per_s"],
+                               "gpu_over_cpu_ess_per_s": full["gpu_over_cpu_ess_per_s"], "cores": full["cpu"]["cores"],
+                               "threads": full["cpu"]["threads"], "cpu_grad_evals": full["cpu"]["grad_evals"],
+                               "gpu_grad_evals": full["gpu"]["grad_evals"], "same_first_trees": full["same_first_trees"],
+                               "kind": full["cpu"]["kind"], "extrapolated": False}
         print(json.dumps(out))
     model.close()
     if dist_on:

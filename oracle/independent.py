@@ -158,3 +158,124 @@ def synth_factor(G, S, K, levels=(3,), seed=0):
     lam = rng.gamma(phi[:, None], mu / phi[:, None])
     counts = np.minimum(rng.poisson(np.minimum(lam, 1e9)), 2**31 - 2).astype(np.int32)
     return dict(counts=counts, X=X, exposure=exposure, K=K, truth=dict(intercept=intercept, sigma_raw=sigma_raw, alpha=alpha))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Host rules of the path, restated a SECOND time for the oracle side (tests/test_oracle_reference_cases.py drives the oracle
+# through identify_outliers() with THESE, not with the product's ppcseq_amd.inference / ppcseq_amd.methods functions): plain
+# loops over cells, written from the reference's R statements, sharing no code with the product's array expressions.
+# ---------------------------------------------------------------------------------------------------------------------
+class Flags:
+    """Per checked cell (K x S lists of bool / None)."""
+    def __init__(self, K, S):
+        self.ppc = np.zeros((K, S), bool)
+        self.is_higher_than_mean = np.zeros((K, S), bool)
+        self.is_group_high = None
+        self.deleterious_outliers = None
+        self.lower = self.upper = self.mean = None
+
+
+def flags_reference(counts_checked, mean, lower, upper, slope, X):
+    """check_if_within_posterior (R/utilities.R:651-663): ppc = between(count, .lower, .upper) (dplyr::between: both ends
+    inclusive); `is higher than mean` = !ppc & count > mean. add_deleterious_if_covariate_exists (:493-513), only when X has a
+    second column: is_group_right = X[,2] > mean(X[,2]); `is group high` = (slope > 0 & is_group_right) | (slope < 0 &
+    !is_group_right); deleterious_outliers = !ppc & (`is higher than mean` == `is group high`)."""
+    K, S = np.asarray(counts_checked).shape
+    X = np.asarray(X, float).reshape(S, -1)
+    f = Flags(K, S)
+    f.lower, f.upper, f.mean = np.asarray(lower, float), np.asarray(upper, float), np.asarray(mean, float)
+    has_cov = X.shape[1] > 1
+    if has_cov:
+        col = [float(X[s, 1]) for s in range(S)]
+        m = sum(col) / S
+        right = [c > m for c in col]
+        f.is_group_high = np.zeros((K, S), bool)
+        f.deleterious_outliers = np.zeros((K, S), bool)
+    for g in range(K):
+        for s in range(S):
+            y = float(counts_checked[g][s])
+            inside = (y >= float(lower[g][s])) and (y <= float(upper[g][s]))
+            f.ppc[g, s] = inside
+            f.is_higher_than_mean[g, s] = (not inside) and (y > float(mean[g][s]))
+            if has_cov:
+                gh = (slope[g] > 0 and right[s]) or (slope[g] < 0 and not right[s])
+                f.is_group_high[g, s] = gh
+                f.deleterious_outliers[g, s] = (not inside) and (bool(f.is_higher_than_mean[g, s]) == bool(gh))
+    return f
+
+
+def optimal_number_of_chains(how_many_posterior_draws, max_number_to_check=100, warmup=150):
+    """find_optimal_number_of_chains (R/utilities.R:291-303): over chains = 2 .. max_number_to_check,
+    tot = how_many_posterior_draws / chains + 150 * chains; the chains of the smallest tot (the reference returns every
+    minimiser, `filter(tot == min(tot))`; a tie does not occur for the draw counts of the path, the first one is returned)."""
+    tots = {c: how_many_posterior_draws / c + warmup * c for c in range(2, int(max_number_to_check) + 1)}
+    lo = min(tots.values())
+    return [c for c in sorted(tots) if tots[c] == lo][0]
+
+
+def _average_ranks(x):
+    """rank(x) of R (ties = "average"), 1-based."""
+    order = sorted(range(len(x)), key=lambda i: x[i])
+    r = [0.0] * len(x)
+    i = 0
+    while i < len(order):
+        j = i
+        while j + 1 < len(order) and x[order[j + 1]] == x[order[i]]:
+            j += 1
+        avg = 0.5 * (i + j) + 1.0
+        for k in range(i, j + 1):
+            r[order[k]] = avg
+        i = j + 1
+    return r
+
+
+def tmm_reference(mat, ref_col, logratio_trim=0.3, sum_trim=0.05, a_cutoff=-1e10):
+    """edgeR::calcNormFactors(method = "TMM") (Robinson & Oshlack 2010; edgeR's documented procedure, doWeighting = TRUE):
+    per sample against the reference column -- M = log2 ratio of the library-scaled counts, A = their mean log2, asymptotic
+    variance v; genes with a zero count on either side (non-finite M or A) dropped; trimmed by the ranks of M (30 % each side)
+    and of A (5 % each side); factor = 2^(sum(M / v) / sum(1 / v)); finally scaled to a geometric mean of one."""
+    mat = [[float(v) for v in row] for row in np.asarray(mat)]
+    n_genes, n_samp = len(mat), len(mat[0])
+    lib = [sum(mat[g][j] for g in range(n_genes)) for j in range(n_samp)]
+    fac = []
+    for j in range(n_samp):
+        M, A, V = [], [], []
+        for g in range(n_genes):
+            o, r = mat[g][j], mat[g][ref_col]
+            if o <= 0.0 or r <= 0.0:
+                continue
+            po, pr = o / lib[j], r / lib[ref_col]
+            a = 0.5 * (math.log2(po) + math.log2(pr))
+            if not a > a_cutoff:
+                continue
+            M.append(math.log2(po / pr)); A.append(a)
+            V.append((lib[j] - o) / lib[j] / o + (lib[ref_col] - r) / lib[ref_col] / r)
+        if not M or max(abs(m) for m in M) < 1e-6:
+            fac.append(1.0)
+            continue
+        n = len(M)
+        loL = math.floor(n * logratio_trim) + 1; hiL = n + 1 - loL
+        loS = math.floor(n * sum_trim) + 1; hiS = n + 1 - loS
+        rM, rA = _average_ranks(M), _average_ranks(A)
+        num = den = 0.0
+        for i in range(n):
+            if loL <= rM[i] <= hiL and loS <= rA[i] <= hiS:
+                num += M[i] / V[i]; den += 1.0 / V[i]
+        val = num / den if den > 0 else float("nan")
+        fac.append(2.0 ** (val if math.isfinite(val) else 0.0))
+    gm = math.exp(sum(math.log(f) for f in fac) / n_samp)
+    return [f / gm for f in fac]
+
+
+def scaled_multipliers_reference(mat):
+    """get_scaled_counts_bulk (R/tidybulk.R:150-241) on a genes x samples matrix of the selected genes: the reference sample is
+    the one whose median count is closest to the largest median (:181-196, the first such sample), the factors are TMM against
+    it, and multiplier_s = tot_ref / (tot_s * nf_s) (:220-225); exposure_rate = -log(multiplier) (R/methods.R:222-238)."""
+    mat = np.asarray(mat, float)
+    n_samp = mat.shape[1]
+    med = [float(np.median(mat[:, j])) for j in range(n_samp)]
+    top = max(med)
+    ref = min(range(n_samp), key=lambda j: (abs(med[j] - top), j))
+    nf = tmm_reference(mat, ref)
+    tot = [float(mat[:, j].sum()) for j in range(n_samp)]
+    return [tot[ref] / (tot[j] * nf[j]) for j in range(n_samp)], nf

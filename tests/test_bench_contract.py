@@ -42,6 +42,13 @@ def test_recorded_bench_line_has_every_contract_field():
         assert lit["seconds_sampled"] < 12 and opt["seconds_sampled"] < 12
     # the comparator is this repository's own port on a bounded sample: it must say so, and its rate must be consistent
     assert c.get("extrapolated") is True and "not rstan" in c["sample"]
+    # ... and beside the extrapolated cfg3 figure the line carries ONE measured pair: whole fits of cfg2 on the host's cores and
+    # on the GPU, same seeds and estimator (round 5: part of the default run)
+    if int(os.path.basename(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))[-1])[1:3]) >= 5:
+        ms = c["measured"]
+        assert ms["config"] == "cfg2" and ms["extrapolated"] is False and ms["cores"] >= 1
+        assert ms["cpu_s"] > ms["gpu_s"] > 0 and ms["cpu_ess_per_s"] > 0 and ms["gpu_ess_per_s"] > ms["cpu_ess_per_s"]
+        assert abs(ms["gpu_over_cpu_ess_per_s"] - ms["gpu_ess_per_s"] / ms["cpu_ess_per_s"]) < 0.06 * ms["gpu_over_cpu_ess_per_s"]
     cells = 20000 * 200
     assert abs(c["ns_per_cell_per_thread"] - 1e9 * c["cores"] / (c["grad_evals_per_s"] * cells)) < 0.02 * c["ns_per_cell_per_thread"]
     # whole-job consistency: the gradient evaluations of the run at the algorithmic bytes each cannot exceed the HBM peak,

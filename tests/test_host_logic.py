@@ -51,6 +51,50 @@ def test_flags_follow_reference_rules():
     assert r2.deleterious_outliers.tolist() == [[False, True, True, False]]
 
 
+def test_host_rules_equal_their_oracle_side_restatements(bundled):
+    """The product's flag rules, chain arithmetic and TMM exposures (ppcseq_amd.inference / ppcseq_amd.methods: array
+    expressions) against the oracle side's own restatements of the same R statements (oracle/independent.py: loops over cells),
+    which is what pins the oracle on the reference's known answers (tests/test_oracle_reference_cases.py). Random cells --
+    including counts exactly on an interval's end (dplyr::between is inclusive) and on the mean, zero and negative slopes,
+    designs with and without a covariate -- and the bundled data for the exposures."""
+    from oracle import independent as ind
+    from ppcseq_amd import methods
+    rng = np.random.default_rng(12)
+    for trial in range(20):
+        K, S = int(rng.integers(1, 7)), int(rng.integers(2, 12))
+        lower = rng.integers(0, 40, (K, S)).astype(float)
+        upper = lower + rng.integers(0, 60, (K, S))
+        mean = lower + (upper - lower) * rng.random((K, S))
+        counts = rng.integers(0, 120, (K, S))
+        pick = rng.random((K, S))
+        counts = np.where(pick < 0.15, lower, np.where(pick < 0.3, upper, np.where(pick < 0.4, np.floor(mean), counts))).astype(np.int64)
+        slope = rng.normal(0, 1, K); slope[rng.random(K) < 0.2] = 0.0
+        X = np.stack([np.ones(S), rng.integers(0, 2, S).astype(float)], 1) if trial % 3 else np.ones((S, 1))
+        if trial % 5 == 4:
+            X = np.stack([np.ones(S), rng.normal(0, 1, S)], 1)            # a continuous covariate: the split is at its mean
+        ci = np.stack([mean, np.zeros((K, S)), lower, upper], -1)
+        a = inf._post_process(counts, ci, slope, X)
+        b = ind.flags_reference(counts, mean, lower, upper, slope, X)
+        assert np.array_equal(a.ppc, b.ppc) and np.array_equal(a.is_higher_than_mean, b.is_higher_than_mean)
+        if X.shape[1] > 1:
+            assert np.array_equal(a.is_group_high, b.is_group_high) and np.array_equal(a.deleterious_outliers, b.deleterious_outliers)
+        else:
+            assert a.deleterious_outliers is None and b.deleterious_outliers is None
+    for draws in (200, 1000, 1001, 4000, 10500, 100000):
+        assert inf.find_optimal_number_of_chains(draws) == ind.optimal_number_of_chains(draws)
+    assert ind.optimal_number_of_chains(1000) == 3 and ind.optimal_number_of_chains(10500) == 8      # SURVEY App. C
+    from tests.conftest import bundled_test_config
+    counts, _, _, _ = bundled_test_config(bundled)
+    mult, nf = methods.get_scaled_counts_bulk(counts, list(range(counts.shape[1])))
+    mult2, nf2 = ind.scaled_multipliers_reference(counts)
+    assert np.allclose([mult[s] for s in range(counts.shape[1])], mult2, rtol=1e-12, atol=0)
+    assert np.allclose([nf[s] for s in range(counts.shape[1])], nf2, rtol=1e-12, atol=0)
+    m2 = rng.poisson(rng.gamma(2.0, 50.0, (400, 1)) * rng.uniform(0.5, 2.0, (1, 9))).astype(np.int64)   # zeros and ties included
+    mult, nf = methods.get_scaled_counts_bulk(m2, list(range(9)))
+    mult2, nf2 = ind.scaled_multipliers_reference(m2)
+    assert np.allclose([mult[s] for s in range(9)], mult2, rtol=1e-12, atol=0)
+
+
 def test_threshold_arithmetic_of_identify_outliers():
     # R/methods.R:156-167 with 21 samples, pfp = 1, detrimental only
     thr2 = 1 / 100 / 21 * 2

@@ -16,9 +16,13 @@ import os
 import numpy as np
 import pytest
 
-from ppcseq_amd.inference import _post_process, find_optimal_number_of_chains
-from ppcseq_amd.methods import get_scaled_counts_bulk
+from oracle import independent as ind
 from tests.conftest import bundled_test_config
+
+# The flag rules, the chain arithmetic and the TMM exposures used HERE are the oracle side's own restatements
+# (oracle/independent.py: flags_reference, optimal_number_of_chains, scaled_multipliers_reference), not the product's
+# ppcseq_amd.inference / ppcseq_amd.methods functions: the known answers below pin the oracle without any product code.
+# tests/test_host_logic.py holds the product's functions against the same restatements.
 
 THREADS = min(8, os.cpu_count() or 1)
 
@@ -39,7 +43,7 @@ def _oracle_pass(O, counts, X, expo, K, p, draws, seed, *, vb, approx_analysis, 
         else:
             raise RuntimeError("ADVI failed five times")
     else:
-        chains = max(3, min(int(cores), find_optimal_number_of_chains(practical)))
+        chains = max(3, min(int(cores), ind.optimal_number_of_chains(practical)))
         n_iter = int(math.ceil(practical / chains)) + 150
         r = O.nuts_model(mo, O.cfg(chains=chains, iter=n_iter, warmup=150, seed=seed))
         dr = r.draws.reshape(-1, r.draws.shape[-1])
@@ -49,14 +53,14 @@ def _oracle_pass(O, counts, X, expo, K, p, draws, seed, *, vb, approx_analysis, 
         gq = O.generated_quantities(mo, dr, tc, seed=seed)
     ci = O.summarise(gq, p, 1 - p)
     off = 3 + counts.shape[0]
-    return _post_process(counts[:K], ci, dr[:, off:off + K].mean(0), X)
+    return ind.flags_reference(counts[:K], ci[..., 0], ci[..., 2], ci[..., 3], dr[:, off:off + K].mean(0), X)
 
 
 def _oracle_identify_outliers(O, counts, X, K, *, pfp, vb, approx_analysis, cores, seed, draws_after_tail=10):
     """identify_outliers() (R/methods.R:155-167, :222-238, :268-342) with both passes on the oracle."""
     S = counts.shape[1]
-    mult, _ = get_scaled_counts_bulk(counts, list(range(S)))             # R/methods.R:222-238
-    expo = -np.log(np.array([mult[s] for s in range(S)]))
+    mult, _ = ind.scaled_multipliers_reference(counts)                   # R/methods.R:222-238
+    expo = -np.log(np.array(mult))
     thr2 = pfp / 100 / S * 2                                             # do_check_only_on_detrimental (a covariate)
     thr1 = max(0.05, 2 * thr2)
     draws1, draws2 = max(draws_after_tail / thr1, 1000), max(draws_after_tail / thr2, 1000)
