@@ -97,7 +97,8 @@ def main():
     K = int(arrays["K"][0])
     comm, xchg = None, None
     if args.mode == "shards":
-        # contiguous gene ranges
+        # genes dealt to the ranks round-robin, as the reference deals them to its shards (R/utilities.R:125-136): every rank
+        # gets its share of the K checked genes (which come first) and with them an equal share of the work
         if args.exchange == "rccl":             # the communicator's id travels from rank 0 through torch.distributed
             uid = [_lib.Comm.unique_id() if rank == 0 else None]
             if dist_on:
@@ -112,15 +113,15 @@ def main():
                 dist.all_gather_object(handles, xchg.handle())
                 xchg.connect(handles)
                 dist.barrier()                  # nobody publishes before everybody has mapped everybody
-        g0, g1 = G * rank // world, G * (rank + 1) // world
-        model = _lib.Model(arrays["counts"][g0:g1], arrays["X"], arrays["exposure"], 0, device=dev_index,
-                           shard=(G, K, g0, g1))
+        mine = np.arange(rank, G, world)
+        model = _lib.Model(arrays["counts"][mine], arrays["X"], arrays["exposure"], 0, device=dev_index,
+                           shard=(G, K, rank, None, world))
     else:
         model = _lib.Model(arrays["counts"], arrays["X"], arrays["exposure"], K, device=dev_index)
     if args.lanes or args.workgroups:
         model.set_launch(args.lanes, args.workgroups)
     Dm = model.D
-    model_G = (g1 - g0) if args.mode == "shards" else G
+    model_G = len(mine) if args.mode == "shards" else G
     hyper_cols = [0, 1, 2, Dm - 3, Dm - 2, Dm - 1]
     nch = args.chains_per_gpu
     n_iter = args.nuts_warmup + args.draws_per_chain

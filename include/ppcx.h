@@ -177,7 +177,8 @@ PPCX_API int ppcx_fit_advi_iterative(ppcx_model* m, const ppcx_advi_config* cfg,
 PPCX_API int ppcx_fit_advi_info(const ppcx_fit* f, int* iterations, int* converged, double* elbo, double* eta);
 
 /* --- gene shards = the reference's map_rect over gene shards (inst/stan/negBinomial_MPI.stan:226-240;
- * round-robin gene->shard assignment R/utilities.R:130-136; here contiguous gene ranges). A shard model holds
+ * round-robin gene->shard assignment R/utilities.R:130-136; here contiguous gene ranges or the same round-robin deal,
+ * ppcx_model_create_shard_strided). A shard model holds
  * genes [g0, g1) of a G_total-gene problem whose first K_total genes are the checked ones; the six
  * hyper-parameters are replicated and every leapfrog exchanges one vector of <= 76 partial sums (log density,
  * 6 hyper-gradient sums, kinetic energies, U-turn dot products).
@@ -185,6 +186,14 @@ PPCX_API int ppcx_fit_advi_info(const ppcx_fit* f, int* iterations, int* converg
  *   ppcx_fit_nuts_comm   : one shard per process / GPU, sums all-reduced with RCCL over xGMI              */
 typedef struct ppcx_comm ppcx_comm;
 PPCX_API int ppcx_model_create_shard(int device, int G_total, int S, int C, int K_total, int g0, int g1,
+                            const int32_t* counts_shard, const double* X, const double* exposure_rate,
+                            double lambda_mu_mu, int n_excl, const int32_t* excl_local, ppcx_model** out);
+/* ... or every gene_stride-th gene from g0 on: genes g0, g0 + gene_stride, ..., n_genes of them (counts_shard holds their rows in
+   that order). Shard r of N with g0 = r, gene_stride = N is the reference's round-robin deal (R/utilities.R:125-136): every shard
+   gets its share of the K_total checked genes, which come first in the whole problem -- and with them an equal share of the work
+   (a contiguous split gives the first shard every gene with a slope). Philox streams are addressed by the coordinate's index in
+   the whole problem either way: a sharded run draws what the unsharded run draws. */
+PPCX_API int ppcx_model_create_shard_strided(int device, int G_total, int S, int C, int K_total, int g0, int gene_stride, int n_genes,
                             const int32_t* counts_shard, const double* X, const double* exposure_rate,
                             double lambda_mu_mu, int n_excl, const int32_t* excl_local, ppcx_model** out);
 PPCX_API int ppcx_fit_nuts_shards(ppcx_model** shards, int n_shards, const ppcx_nuts_config* cfg, ppcx_fit** fits);

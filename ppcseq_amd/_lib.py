@@ -19,7 +19,7 @@ EXPORTS = [
     "ppcx_model_set_launch", "ppcx_model_get_launch", "ppcx_model_get_plan", "ppcx_model_dim", "ppcx_model_destroy", "ppcx_log_prob_grad",
     "ppcx_nuts_config_default", "ppcx_fit_nuts", "ppcx_fit_info", "ppcx_fit_from_draws", "ppcx_fit_get_draws", "ppcx_fit_get_columns",
     "ppcx_fit_get_diagnostics", "ppcx_fit_get_timing", "ppcx_fit_get_kernel_times", "ppcx_fit_ppc", "ppcx_fit_free", "ppcx_do_inference_C", "ppcx_model_set_rounds", "ppcx_model_get_rounds", "ppcx_model_set_progress",
-    "ppcx_model_create_shard", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
+    "ppcx_model_create_shard", "ppcx_model_create_shard_strided", "ppcx_fit_nuts_shards", "ppcx_comm_unique_id", "ppcx_comm_create", "ppcx_comm_destroy",
     "ppcx_fit_nuts_comm", "ppcx_advi_config_default", "ppcx_fit_advi", "ppcx_fit_advi_info", "ppcx_fit_advi_iterative",
     "ppcx_guard_decision", "ppcx_device_memory", "ppcx_fit_get_ppc_timing",
     "ppcx_xchg_create", "ppcx_xchg_handle", "ppcx_xchg_connect", "ppcx_xchg_connect_local", "ppcx_xchg_set_timeout", "ppcx_xchg_destroy",
@@ -120,6 +120,7 @@ def load() -> C.CDLL:
     lib.ppcx_fit_advi_iterative.argtypes = [C.c_void_p, C.POINTER(AdviConfig), C.c_int, C.POINTER(C.c_void_p)]
     lib.ppcx_fit_advi_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ppcx_model_create_shard.argtypes = [C.c_int] * 7 + [ip, dp, dp, C.c_double, C.c_int, ip, C.POINTER(C.c_void_p)]
+    lib.ppcx_model_create_shard_strided.argtypes = [C.c_int] * 8 + [ip, dp, dp, C.c_double, C.c_int, ip, C.POINTER(C.c_void_p)]
     lib.ppcx_fit_nuts_shards.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(NutsConfig), C.POINTER(C.c_void_p)]
     lib.ppcx_comm_unique_id.argtypes = [C.c_char_p]
     lib.ppcx_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
@@ -165,12 +166,19 @@ def device_memory(device=0):
     return int(f.value), int(t.value)
 
 
+def shard_genes(G_total, g0, stride):
+    """The genes of a strided shard (ppcx_model_create_shard_strided): g0, g0 + stride, ... below G_total."""
+    return list(range(int(g0), int(G_total), int(stride)))
+
+
 class Model:
     """Device-resident model inputs (Stan data block in logical form, include/ppcx.h)."""
 
     def __init__(self, counts, X, exposure_rate, K, lambda_mu_mu=5.612671, excl=None, device=0, shard=None):
         """shard = (G_total, K_total, g0, g1): `counts` then holds only genes [g0, g1) of the whole problem and K is
-        ignored (the shard's checked genes are those of the first K_total that fall in its range)."""
+        ignored (the shard's checked genes are those of the first K_total that fall in its range). shard = (G_total, K_total,
+        g0, None, stride): the genes g0, g0 + stride, ... of the whole problem -- rank r of N with (r, None, N) is the
+        reference's round-robin deal of genes to shards (R/utilities.R:125-136; shard_genes() picks the rows)."""
         lib = load()
         counts = np.ascontiguousarray(counts, dtype=np.int32)
         if counts.ndim != 2:
@@ -191,13 +199,22 @@ class Model:
                                          _p(X, C.c_double), _p(exposure_rate, C.c_double), float(lambda_mu_mu),
                                          int(excl.size), _p(excl, C.c_int32), C.byref(h)))
         else:
-            Gt, Kt, g0, g1 = (int(v) for v in shard)
-            if g1 - g0 != self.G:
-                raise ValueError("counts must hold exactly the genes of the shard")
-            self.K = max(0, min(g1, Kt) - min(g0, Kt))
-            _check(lib.ppcx_model_create_shard(int(device), Gt, self.S, self.C, Kt, g0, g1, _p(counts, C.c_int32),
-                                               _p(X, C.c_double), _p(exposure_rate, C.c_double), float(lambda_mu_mu),
-                                               int(excl.size), _p(excl, C.c_int32), C.byref(h)))
+            if len(shard) == 5:
+                Gt, Kt, g0, stride = int(shard[0]), int(shard[1]), int(shard[2]), int(shard[4])
+                if len(shard_genes(Gt, g0, stride)) != self.G:
+                    raise ValueError("counts must hold exactly the genes of the shard")
+                self.K = len([g for g in shard_genes(Gt, g0, stride) if g < Kt])
+                _check(lib.ppcx_model_create_shard_strided(int(device), Gt, self.S, self.C, Kt, g0, stride, self.G, _p(counts, C.c_int32),
+                                                           _p(X, C.c_double), _p(exposure_rate, C.c_double), float(lambda_mu_mu),
+                                                           int(excl.size), _p(excl, C.c_int32), C.byref(h)))
+            else:
+                Gt, Kt, g0, g1 = (int(v) for v in shard)
+                if g1 - g0 != self.G:
+                    raise ValueError("counts must hold exactly the genes of the shard")
+                self.K = max(0, min(g1, Kt) - min(g0, Kt))
+                _check(lib.ppcx_model_create_shard(int(device), Gt, self.S, self.C, Kt, g0, g1, _p(counts, C.c_int32),
+                                                   _p(X, C.c_double), _p(exposure_rate, C.c_double), float(lambda_mu_mu),
+                                                   int(excl.size), _p(excl, C.c_int32), C.byref(h)))
         self._h = h
         self.D = int(lib.ppcx_model_dim(h))
 

@@ -1259,6 +1259,12 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
   // fit are only meaningful with one group (bench.py takes its roofline sample from a fit on one stream).
   int ngrp = default_stream_groups(nch);
   if (m->opt_stream_groups >= 1) ngrp = m->opt_stream_groups < nch ? m->opt_stream_groups : nch;
+  // Between ranks (direct exchange) the chains run as ONE group on one stream: a chain's state machine spins inside its merged
+  // launch until every peer's copy of that chain has published its sums, so the peers' launches of the SAME group must be running
+  // at the same time. With several groups a rank's launch of group A can sit in front of its launch of group B while the peer
+  // has them the other way round -- each state machine then waits for a launch that is queued behind the one it is waiting in,
+  // until the exchange's timeout ends the fit.
+  if (xa_live) ngrp = 1;
   struct Group { int c0 = 0, n = 0; Work w; RunIO io; PumpStats ps; int rc = PPCX_OK; std::string err; long long leap = 0, xticks = 0, xcount = 0; };
   std::vector<Group> grp(ngrp);
   std::atomic<int> stop{0};
@@ -1515,16 +1521,25 @@ extern "C" int ppcx_fit_advi_info(const ppcx_fit* f, int* iterations, int* conve
 }
 
 // ---- gene shards (second mode; the reference's map_rect over gene shards, .stan:226-240) ---------
+extern "C" int ppcx_model_create_shard_strided(int device, int G_total, int S, int C, int K_total, int g0, int gene_stride, int n_genes,
+                                               const int32_t* counts_shard, const double* X, const double* exposure,
+                                               double lambda_mu_mu, int n_excl, const int32_t* excl_local, ppcx_model** out) {
+  if (g0 < 0 || gene_stride < 1 || n_genes < 1 || K_total < 0 || K_total > G_total ||
+      (long long)g0 + (long long)gene_stride * (n_genes - 1) >= G_total) return fail(PPCX_ERR_ARG, "bad gene shard");
+  // the shard's checked genes: its genes among the first K_total of the whole problem (they come first in the shard too)
+  int kl = 0;
+  if (g0 < K_total) kl = (K_total - g0 + gene_stride - 1) / gene_stride;
+  if (kl > n_genes) kl = n_genes;
+  int rc = ppcx_model_create(device, n_genes, S, C, kl, counts_shard, X, exposure, lambda_mu_mu, n_excl, excl_local, out);
+  if (rc != PPCX_OK) return rc;
+  (*out)->d.Gt = G_total; (*out)->d.Kt = K_total; (*out)->d.g0 = g0; (*out)->d.k0 = g0 < K_total ? g0 : K_total; (*out)->d.gstride = gene_stride;
+  return PPCX_OK;
+}
 extern "C" int ppcx_model_create_shard(int device, int G_total, int S, int C, int K_total, int g0, int g1,
                                        const int32_t* counts_shard, const double* X, const double* exposure,
                                        double lambda_mu_mu, int n_excl, const int32_t* excl_local, ppcx_model** out) {
-  if (g0 < 0 || g1 <= g0 || g1 > G_total || K_total < 0 || K_total > G_total) return fail(PPCX_ERR_ARG, "bad gene range");
-  const int k0 = g0 < K_total ? g0 : K_total;
-  const int k1 = g1 < K_total ? g1 : K_total;
-  int rc = ppcx_model_create(device, g1 - g0, S, C, k1 - k0, counts_shard, X, exposure, lambda_mu_mu, n_excl, excl_local, out);
-  if (rc != PPCX_OK) return rc;
-  (*out)->d.Gt = G_total; (*out)->d.Kt = K_total; (*out)->d.g0 = g0; (*out)->d.k0 = k0;
-  return PPCX_OK;
+  if (g0 < 0 || g1 <= g0 || g1 > G_total) return fail(PPCX_ERR_ARG, "bad gene range");
+  return ppcx_model_create_shard_strided(device, G_total, S, C, K_total, g0, 1, g1 - g0, counts_shard, X, exposure, lambda_mu_mu, n_excl, excl_local, out);
 }
 
 static int fit_sharded(ppcx_model** models, int ns, const ppcx_nuts_config* cfg, ppcx_comm* comm, ppcx_fit** fits) {

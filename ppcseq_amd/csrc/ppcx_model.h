@@ -42,6 +42,8 @@ struct Dims {
                                 // factor, `~ a + b`): e^t of a gene with slopes is E_s A_g times exp(slope_c) of the sample's
                                 // columns -- no per-cell exp for the checked genes either (C == 2: A_g or A1_g by the group)
   int Gt, Kt, g0, k0;           // gene shard: totals of the whole problem and this shard's first gene / checked gene
+  int gstride;                  // ... and the distance of its consecutive genes in the whole problem: 1 = a contiguous range;
+                                // N = every N-th gene (the reference deals genes to its shards round-robin, R/utilities.R:125-136)
   double lambda_mu_mu;
 };
 
@@ -55,20 +57,23 @@ PPCX_HD Dims make_dims(int G, int S, int C, int K, double lambda_mu_mu) {
   d.off_tail = d.off_sigma_raw + G;
   d.D = d.off_tail + 3;
   d.x0_is_one = 1; d.x1_binary = 0; d.lambda_mu_mu = lambda_mu_mu;
-  d.Gt = G; d.Kt = K; d.g0 = 0; d.k0 = 0;
+  d.Gt = G; d.Kt = K; d.g0 = 0; d.k0 = 0; d.gstride = 1;
   return d;
 }
 // Index of local coordinate i in the unconstrained vector of the WHOLE problem (Stan order). Used only as
 // the Philox stream id, so that a gene-sharded run draws exactly what the unsharded run draws.
 PPCX_HD int global_flat(const Dims& d, int i) {
   if (d.Gt == d.G) return i;
-  const int n2 = d.C > 2 ? d.C - 2 : 0;
+  const int n2 = d.C > 2 ? d.C - 2 : 0, st = d.gstride;
   if (i < d.off_intercept) return i;
-  if (i < d.off_alpha1) return 3 + d.g0 + (i - d.off_intercept);
-  if (i < d.off_alpha2) return 3 + d.Gt + d.k0 + (i - d.off_alpha1);
-  if (i < d.off_sigma_raw) return 3 + d.Gt + d.Kt + n2 * d.k0 + (i - d.off_alpha2);
+  if (i < d.off_alpha1) return 3 + d.g0 + st * (i - d.off_intercept);
+  if (i < d.off_alpha2) return 3 + d.Gt + d.k0 + st * (i - d.off_alpha1);
+  if (i < d.off_sigma_raw) {                    // alpha_2: n2 entries per checked gene, gene-major
+    const int j = i - d.off_alpha2, kl = j / n2, c = j - kl * n2;
+    return 3 + d.Gt + d.Kt + n2 * (d.k0 + st * kl) + c;
+  }
   const int sr_t = 3 + d.Gt + d.Kt + n2 * d.Kt;
-  if (i < d.off_tail) return sr_t + d.g0 + (i - d.off_sigma_raw);
+  if (i < d.off_tail) return sr_t + d.g0 + st * (i - d.off_sigma_raw);
   return sr_t + d.Gt + (i - d.off_tail);
 }
 // flat index of the k-th hyper-parameter, k = 0..5 = lambda_mu, lambda_sigma, lambda_skew,

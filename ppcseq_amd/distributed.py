@@ -135,6 +135,7 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_
                                how_many_posterior_draws=how_many_posterior_draws, truncation_compensation=truncation_compensation,
                                seed=seed, device=device)
             r.chains, r.iter = chains, n_iter
+            r.diagnostics = diag
             res[0] = r
         except Exception as e:
             err = e
@@ -145,13 +146,15 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_
 
 def do_inference_shards(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_device="cpu", chains=None, cores=None,
                         approximate_posterior_analysis=False, lambda_mu_mu=5.612671, adj_prob_theshold=0.05,
-                        how_many_posterior_draws=1000, to_exclude=None, truncation_compensation=1.0, seed=1):
+                        how_many_posterior_draws=1000, to_exclude=None, truncation_compensation=1.0, seed=1, launch=None):
     """One inference pass with the GENES partitioned over the ranks (the reference's map_rect over gene shards,
-    inst/stan/negBinomial_MPI.stan:226-240; BASELINE cfg4): every rank holds a contiguous gene range and runs ALL the chains on
-    it, the six hyper-parameters and the chains' state machines are replicated, and the ranks' partial sums meet every leapfrog
+    inst/stan/negBinomial_MPI.stan:226-240; BASELINE cfg4): every rank holds every world-th gene (the reference's round-robin deal,
+    R/utilities.R:125-136: an equal share of the checked genes and of the work on every rank) and runs ALL the chains on them, the six hyper-parameters and the chains' state machines are replicated, and the ranks' partial sums meet every leapfrog
     through the direct exchange (include/ppcx.h ppcx_xchg_*: peer-mapped buffers, no collective call). The checked genes' draws
     are then gathered on rank 0, which computes the credible intervals from them exactly as the chains path does
-    (pooled_summary), and the result is broadcast. Needs a design that runs pipelined rounds (factor designs, `~ 1`)."""
+    (pooled_summary), and the result is broadcast (with the sampler's diagnostics, which are the same on every rank: the state
+    machines are replicated). Needs a design that runs pipelined rounds (factor designs, `~ 1`). `launch` = (lanes_per_gene,
+    workgroups) pins the log-likelihood launch as in do_inference."""
     import math
     from . import _lib
     from .inference import _to_cell_ids, find_optimal_number_of_chains, pooled_summary
@@ -168,15 +171,19 @@ def do_inference_shards(counts, X, exposure_rate, how_many_to_check, *, device=0
         chains = max(3, min(int(cores) if cores else 8, find_optimal_number_of_chains(practical)))
     n_iter = int(math.ceil(practical / chains)) + 150
     n_keep = n_iter - 150
-    g0, g1 = G * rank // world, G * (rank + 1) // world
+    # genes are dealt to the ranks round-robin, as the reference deals them to its shards (R/utilities.R:125-136): every rank gets
+    # its share of the K checked genes -- which come first -- and with them of the slope coordinates and the dearer passes
+    mine = np.arange(rank, G, world)
     excl = _to_cell_ids(to_exclude, S)
     if excl is not None and len(excl):
         excl = np.asarray(excl, np.int64)
-        excl = (excl[(excl // S >= g0) & (excl // S < g1)] - g0 * S).astype(np.int32)
-    part, err = None, None
+        eg, es = excl // S, excl % S
+        keep = (eg % world) == rank
+        excl = ((eg[keep] // world) * S + es[keep]).astype(np.int32)
+    part, err, diag = None, None, None
     m = xg = None
     try:
-        m = _lib.Model(counts[g0:g1], X, exposure_rate, 0, lambda_mu_mu=lambda_mu_mu, excl=excl, device=device, shard=(G, K, g0, g1))
+        m = _lib.Model(counts[mine], X, exposure_rate, 0, lambda_mu_mu=lambda_mu_mu, excl=excl, device=device, shard=(G, K, rank, None, world))
         xg = _lib.Xchg(world, rank, chains, device=device)
         handle = xg.handle()
     except Exception as e:                          # noqa: BLE001
@@ -191,9 +198,12 @@ def do_inference_shards(counts, X, exposure_rate, how_many_to_check, *, device=0
         err = e
     raise_if_any_rank_failed(err, device=coll_device, what="gene shards (exchange)")      # also the barrier before anybody publishes
     try:
+        if launch is not None:
+            m.set_launch(*launch)
         f = m.fit_nuts_xchg(xg, chains=chains, iter=n_iter, warmup=150, seed=seed)
         try:
-            Gl, Kl = g1 - g0, m.K                   # this shard's genes and checked genes (local unconstrained vector, Stan order)
+            diag = f.diagnostics()
+            Gl, Kl = len(mine), m.K                 # this shard's genes and checked genes (local unconstrained vector, Stan order)
             a1, a2 = 3 + Gl, 3 + Gl + Kl
             sr = a2 + n2 * Kl
             cols = np.concatenate([np.arange(3), 3 + np.arange(Kl), a1 + np.arange(Kl), a2 + np.arange(n2 * Kl),
@@ -217,20 +227,20 @@ def do_inference_shards(counts, X, exposure_rate, how_many_to_check, *, device=0
             pooled = np.zeros((chains, n_keep, 3 + K * (2 + max(C - 1, 1)) + 3))
             pooled[..., :3] = parts[0][1][..., :3]                           # hyper-parameters: replicated, rank 0's copy
             pooled[..., -3:] = parts[0][1][..., -3:]
-            k0 = 0
-            for Kl, dr in parts:                                             # the shards' checked genes, in gene order
+            for r, (Kl, dr) in enumerate(parts):                             # rank r's checked genes are r, r + world, ... of the K
                 if Kl:
-                    pooled[..., 3 + k0:3 + k0 + Kl] = dr[..., 3:3 + Kl]
-                    pooled[..., 3 + K + k0:3 + K + k0 + Kl] = dr[..., 3 + Kl:3 + 2 * Kl]
+                    gk = np.arange(r, K, world)                              # their places among the K checked genes
+                    pooled[..., 3 + gk] = dr[..., 3:3 + Kl]
+                    pooled[..., 3 + K + gk] = dr[..., 3 + Kl:3 + 2 * Kl]
                     for c in range(n2):                                      # alpha_2: (C - 2) entries per checked gene, gene-major
-                        pooled[..., 3 + 2 * K + n2 * k0 + c:3 + 2 * K + n2 * (k0 + Kl):n2] = dr[..., 3 + 2 * Kl + c:3 + 2 * Kl + n2 * Kl:n2]
-                    pooled[..., 3 + (2 + n2) * K + k0:3 + (2 + n2) * K + k0 + Kl] = dr[..., 3 + (2 + n2) * Kl:3 + (3 + n2) * Kl]
-                k0 += Kl
+                        pooled[..., 3 + 2 * K + n2 * gk + c] = dr[..., 3 + 2 * Kl + c:3 + 2 * Kl + n2 * Kl:n2]
+                    pooled[..., 3 + (2 + n2) * K + gk] = dr[..., 3 + (2 + n2) * Kl:3 + (3 + n2) * Kl]
             r = pooled_summary(counts, X, exposure_rate, K, pooled, lambda_mu_mu=lambda_mu_mu,
                                approximate_posterior_analysis=approximate_posterior_analysis, adj_prob_theshold=adj_prob_theshold,
                                how_many_posterior_draws=how_many_posterior_draws, truncation_compensation=truncation_compensation,
                                seed=seed, device=device)
             r.chains, r.iter = chains, n_iter
+            r.diagnostics = diag
             res[0] = r
         except Exception as e:                      # noqa: BLE001
             err = e

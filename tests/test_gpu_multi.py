@@ -349,8 +349,9 @@ def _xchg_worker(rank, conn, q, hooks):
             for k, v in hooks.items():
                 L.testing_set(k, v)
         d = ind.synth(XG, XS, K=XK, seed=4)
-        g0, g1 = XG * rank // 2, XG * (rank + 1) // 2
-        m = L.Model(d["counts"][g0:g1], d["X"], d["exposure"], 0, device=0, shard=(XG, XK, g0, g1))
+        # the round-robin deal of the reference (R/utilities.R:125-136): rank r holds genes r, r + 2, ... -- three of the six
+        # checked genes each (the in-process tests above split the genes contiguously: both forms run)
+        m = L.Model(d["counts"][rank::2], d["X"], d["exposure"], 0, device=0, shard=(XG, XK, rank, None, 2))
         x = L.Xchg(2, rank, XKW["chains"], device=0)
         x.set_timeout(30)
         mine = x.handle()
@@ -418,10 +419,10 @@ def _shards_rank_worker(rank, world, port, q):
     try:
         d = ind.synth_factor(90, 12, 7, (3,), 5)
         r = D.do_inference_shards(d["counts"], d["X"], d["exposure"], 7, device=0, coll_device="cpu", chains=4,
-                                  to_exclude=np.array([3, 14], np.int32), **KW)
-        q.put((rank, "ok", r.lower, r.upper, r.slope, r.deleterious_outliers))
+                                  to_exclude=np.array([3, 14], np.int32), launch=LAUNCH, **KW)
+        q.put((rank, "ok", r.lower, r.upper, r.slope, r.deleterious_outliers, r.diagnostics["n_leapfrog"], r.diagnostics["divergent"]))
     except Exception as e:                      # noqa: BLE001
-        q.put((rank, "crash: " + repr(e), None, None, None, None))
+        q.put((rank, "crash: " + repr(e), None, None, None, None, None, None))
     finally:
         dist.destroy_process_group()
 
@@ -433,7 +434,7 @@ def test_do_inference_with_the_genes_sharded_over_two_ranks():
     lets the chains coincide, so the intervals agree within Monte-Carlo error and the slopes closely."""
     from ppcseq_amd.inference import do_inference
     d = ind.synth_factor(90, 12, 7, (3,), 5)
-    one = do_inference(d["counts"], d["X"], d["exposure"], 7, chains=4, to_exclude=np.array([3, 14], np.int32), **KW)
+    one = do_inference(d["counts"], d["X"], d["exposure"], 7, chains=4, to_exclude=np.array([3, 14], np.int32), launch=LAUNCH, **KW)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -446,10 +447,22 @@ def test_do_inference_with_the_genes_sharded_over_two_ranks():
         assert p.exitcode == 0
     assert [r[1] for r in res] == ["ok", "ok"], [r[1] for r in res]
     assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][5], res[1][5])          # broadcast: the same on every rank
-    lower, upper, slope = res[0][2], res[0][3], res[0][4]
-    assert np.max(np.abs(slope - one.slope)) < 0.25
-    assert np.median(np.abs(upper - one.upper) / (1 + one.upper)) < 0.06 and np.max(np.abs(upper - one.upper) / (1 + one.upper)) < 0.5
-    assert np.median(np.abs(lower - one.lower) / (1 + one.lower)) < 0.1
+    lower, upper, slope, nl, div = res[0][2], res[0][3], res[0][4], res[0][6], res[0][7]
+    # the same launch geometry (lanes per gene pinned) and the same Philox streams: the sharded chains take the unsharded chains'
+    # decisions for the first iterations, until the different summation order of the shards' sums has grown into the trees
+    assert np.array_equal(nl[:, :10], one.diagnostics["n_leapfrog"][:, :10])
+    # ... and afterwards they are other draws of the same posterior: slopes and interval ends agree within Monte-Carlo error.
+    # The Monte-Carlo standard error of a posterior mean over n = 1200 draws of autocorrelated chains is about sd / sqrt(n / 4);
+    # the 1 % / 99 % ends of a predictive interval from 1200 draws move by several per cent of their value between runs.
+    nd = one.diagnostics["n_leapfrog"].shape[0] * (one.diagnostics["n_leapfrog"].shape[1] - 150)
+    assert np.max(np.abs(slope - one.slope)) < 6 * 0.35 / np.sqrt(nd / 4)          # posterior sd of a slope here: 0.2-0.35
+    assert np.median(np.abs(upper - one.upper) / (1 + one.upper)) < 0.05 and np.max(np.abs(upper - one.upper) / (1 + one.upper)) < 0.3
+    assert np.median(np.abs(lower - one.lower) / (1 + one.lower)) < 0.08
+    assert np.array_equal(res[0][5], one.deleterious_outliers)                                    # the same calls
+    # divergent transitions after warm-up are a property of this small problem (12 samples per gene, a three-level factor), not of
+    # the sharding: the unsharded fit and the oracle's sampler meet them at the same seed as well
+    # (tests/test_oracle_nuts.py::test_small_factor_problem_diverges_on_the_oracle_too)
+    assert int(div[:, 150:].sum()) <= 40 and int(one.diagnostics["divergent"][:, 150:].sum()) <= 40
 
 
 def test_a_refused_exchange_fit_leaves_nothing_on_the_device():

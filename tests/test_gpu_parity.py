@@ -616,6 +616,59 @@ def test_gene_shards_equal_the_unsharded_run(L, G, S, C, K, bounds):
             s_.close()
 
 
+def _assemble_strided(fits, N, G, K, C):
+    """The shards' kept draws put back into the unsharded unconstrained vector: shard r holds genes r, r + N, ..."""
+    nsl = max(C - 1, 1) if K else 0
+    n2 = max(C - 2, 0)
+    out = None
+    for r, f in enumerate(fits):
+        dr = f.draws()
+        if out is None:
+            out = np.zeros(dr.shape[:-1] + (2 * G + K * nsl + 6,))
+            out[..., :3] = dr[..., :3]
+        gl = np.arange(r, G, N); kl = gl[gl < K]
+        Gl, Kl = len(gl), len(kl)
+        out[..., 3 + gl] = dr[..., 3:3 + Gl]
+        out[..., 3 + G + kl] = dr[..., 3 + Gl:3 + Gl + Kl]
+        for c in range(n2):
+            out[..., 3 + G + K + n2 * kl + c] = dr[..., 3 + Gl + Kl + c:3 + Gl + Kl + n2 * Kl:n2]
+        sr_t, sr_l = 3 + G + K * nsl, 3 + Gl + Kl * nsl
+        out[..., sr_t + gl] = dr[..., sr_l:sr_l + Gl]
+        out[..., sr_t + G:] = dr[..., sr_l + Gl:]
+    return out
+
+
+@pytest.mark.parametrize("G,S,C,K,N", [(30, 8, 2, 7, 2), (25, 7, 3, 5, 3), (21, 6, 2, 2, 4), (16, 5, 1, 3, 2)])
+def test_round_robin_gene_shards_equal_the_unsharded_run(L, G, S, C, K, N):
+    """Genes dealt to the shards round-robin, as the reference deals them (R/utilities.R:125-136; ppcx_model_create_shard_strided):
+    shard r of N holds genes r, r + N, ..., hence every N-th checked gene. The Philox streams are addressed by the coordinate's
+    index in the whole problem, so the sharded run walks the path of the unsharded run -- also when a shard holds no checked gene
+    (K < N) and for designs with alpha_2 columns (C = 3: their global index interleaves genes and columns)."""
+    d = ind.synth(G, S, K=K, seed=4, C=C)
+    m = L.Model(d["counts"], d["X"], d["exposure"], K)
+    shards = [L.Model(d["counts"][r::N], d["X"], d["exposure"], 0, shard=(G, K, r, None, N)) for r in range(N)]
+    try:
+        assert [s_.K for s_ in shards] == [len([g for g in range(r, G, N) if g < K]) for r in range(N)]
+        kw = dict(chains=2, iter=30, warmup=20, seed=5)
+        f = m.fit_nuts(**kw)
+        fs = L.fit_nuts_shards(shards, **kw)
+        dg = f.diagnostics()
+        for fsk in fs:
+            dk = fsk.diagnostics()
+            assert np.array_equal(dk["n_leapfrog"][:, :10], dg["n_leapfrog"][:, :10])
+            assert np.max(np.abs(dk["stepsize"][:, :10] - dg["stepsize"][:, :10])) < 1e-9
+        f2 = m.fit_nuts(chains=2, iter=6, warmup=0, seed=5, max_treedepth=6)
+        fs2 = L.fit_nuts_shards(shards, chains=2, iter=6, warmup=0, seed=5, max_treedepth=6)
+        assert np.array_equal(fs2[0].diagnostics()["n_leapfrog"], f2.diagnostics()["n_leapfrog"])
+        assert np.max(np.abs(_assemble_strided(fs2, N, G, K, C) - f2.draws())) < 1e-7
+        for x in fs + fs2 + [f, f2]:
+            x.close()
+    finally:
+        m.close()
+        for s_ in shards:
+            s_.close()
+
+
 def test_rccl_communicator_single_rank(L, monkeypatch):
     """RCCL plumbing (dlopen, unique id, communicator, stream-ordered all-reduce between reduce and update) with one
     rank: must reproduce the plain run of the same round structure exactly (gene shards keep the three-launch round: their
