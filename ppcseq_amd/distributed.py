@@ -135,7 +135,6 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_
                                how_many_posterior_draws=how_many_posterior_draws, truncation_compensation=truncation_compensation,
                                seed=seed, device=device)
             r.chains, r.iter = chains, n_iter
-            r.diagnostics = diag
             res[0] = r
         except Exception as e:
             err = e
