@@ -46,7 +46,7 @@ typedef struct ppcx_fit ppcx_fit;
  * reals[6] / counts_rng + errbuf + errlen of ppcx_do_inference_C, ppcx_model_set_launch's second argument = workgroups);
  * 300 = this one: ppcx_do_inference_C takes the version its caller was written for as dims[0], so that a shim built for
  * another layout gets PPCX_ERR_ARG instead of reading past its arrays.                                                */
-#define PPCX_VERSION 300
+#define PPCX_VERSION 400
 PPCX_API int ppcx_version(void);
 PPCX_API int ppcx_device_count(void);
 /* free and total memory of a device in bytes (what R/methods.R:178-195 asks the host about before keeping all draws) */
@@ -148,11 +148,15 @@ PPCX_API void ppcx_fit_free(ppcx_fit* f);
 /* R .C() convention (all pointers, void return; character vectors arrive as char**): one do_inference() pass end to end --
  * what R/utilities.R:1482-1531 obtains from vb_iterative()/sampling(), summary(fit, "counts_rng"), extract() and
  * summary(fit, "alpha_sub_1").
- *   dims[16] = {PPCX_VERSION the caller was written for (anything else: status PPCX_ERR_ARG, nothing else is read),
+ *   dims[33] = {PPCX_VERSION the caller was written for (anything else: status PPCX_ERR_ARG, nothing else is read),
  *               device, G, S, C, K, n_excl, chains, iter, warmup, n_gen, resample,
  *               approximate_posterior_inference (0 = NUTS, R/utilities.R:1497-1512; 1 = ADVI through the bounded
  *               vb_iterative retry, :1487-1494), save_generated_quantities (counts_rng is filled, :796),
- *               vb_output_samples, vb_iter (0 = 50000)}
+ *               vb_output_samples, vb_iter (0 = 50000),
+ *               n_devices (0: the one `device` above), devices[16] (the first n_devices are read)}
+ *             With n_devices > 1 a NUTS pass deals its chains to those devices -- a host thread each, as rstan::sampling runs
+ *             its chains on `cores` workers (R/utilities.R:1500-1501) -- and summarises the pooled chains on the first one;
+ *             the result is that of one device running all the chains. A device may be named more than once.
  *   reals[6] = {lambda_mu_mu, truncation_compensation, p_lo, p_hi, seed, vb_tol_rel_obj (0 = 0.005, the value the
  *               reference hard-codes at :1492)}
  *   outputs  : ci [K*S*4] (mean, sd, .lower, .upper per checked cell), slope [K] (posterior mean of alpha_sub_1),

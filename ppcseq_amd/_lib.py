@@ -25,7 +25,7 @@ EXPORTS = [
     "ppcx_xchg_create", "ppcx_xchg_handle", "ppcx_xchg_connect", "ppcx_xchg_connect_local", "ppcx_xchg_set_timeout", "ppcx_xchg_destroy",
     "ppcx_fit_nuts_xchg", "ppcx_fit_get_xchg_timing",
 ]
-ABI_VERSION = 300           # include/ppcx.h PPCX_VERSION this binding was written for
+ABI_VERSION = 400           # include/ppcx.h PPCX_VERSION this binding was written for
 
 
 class PpcxError(RuntimeError):

@@ -1833,6 +1833,75 @@ extern "C" int ppcx_fit_advi_iterative(ppcx_model* m, const ppcx_advi_config* cf
   return fit_advi_iterative(m, *cfg, max_attempts, out);
 }
 
+// One NUTS pass with the CHAINS dealt to several devices of this process -- what rstan::sampling(chains, cores) does with its
+// worker processes (R/utilities.R:1497-1512, :1377-1386) -- behind the .C() entry: one host thread per device creates the model
+// there, runs its share of the chains (global chain ids: the chains' Philox streams do not depend on the device they run on) and
+// hands back the checked genes' columns of its kept draws; the first device then holds a model of the K checked genes and computes
+// the generated quantities from the pooled chains, as rstan::summary does over merged chains (:685-703). Lanes per gene are those a
+// single device would choose for ALL the chains, so the result does not depend on the number of devices.
+static int nuts_over_devices(const int* devs, int ndev, int G, int S, int C, int K, const int* counts, const double* X, const double* exposure,
+                             double lmm, int n_excl, const int* excl, const ppcx_nuts_config& cfg0, double tc, double p_lo, double p_hi,
+                             unsigned long long seed, int n_gen, int resample, double* ci, double* slope, int* counts_rng) {
+  const int chains = cfg0.chains, n_keep = cfg0.iter - cfg0.warmup;
+  if (n_keep < 1) return fail(PPCX_ERR_ARG, "no kept draws");
+  if (ndev > chains) ndev = chains;
+  const int per = (chains + ndev - 1) / ndev;
+  const int n2 = C > 2 ? C - 2 : 0, nsl = C - 1 > 1 ? C - 1 : 1;
+  const int Dk = 2 * K + K * nsl + 6;
+  std::vector<double> pooled((size_t)chains * n_keep * Dk, 0.0);
+  std::vector<int> rcs(ndev, PPCX_OK); std::vector<std::string> errs(ndev);
+  auto work = [&](int r) {
+    const int c0 = r * per, n = chains - c0 < per ? chains - c0 : per;
+    if (n <= 0) return;
+    ppcx_model* m = nullptr; ppcx_fit* f = nullptr;
+    int rc = ppcx_model_create(devs[r], G, S, C, K, counts, X, exposure, lmm, n_excl, excl, &m);
+    if (rc == PPCX_OK) {
+      choose_launch(m, chains);                  // the geometry of ONE fit of all the chains
+      m->L_override = m->L;
+      ppcx_nuts_config cfg = cfg0; cfg.chains = n; cfg.chain_id_offset = cfg0.chain_id_offset + c0;
+      rc = ppcx_fit_nuts(m, &cfg, &f);
+    }
+    if (rc == PPCX_OK) {
+      const Dims& d = m->d;
+      std::vector<int32_t> cols;
+      for (int k = 0; k < 3; ++k) cols.push_back(k);
+      for (int k = 0; k < K; ++k) cols.push_back(d.off_intercept + k);
+      for (int k = 0; k < K; ++k) cols.push_back(d.off_alpha1 + k);
+      for (int k = 0; k < n2 * K; ++k) cols.push_back(d.off_alpha2 + k);
+      for (int k = 0; k < K; ++k) cols.push_back(d.off_sigma_raw + k);
+      for (int k = 0; k < 3; ++k) cols.push_back(d.off_tail + k);
+      rc = (int)cols.size() == Dk ? ppcx_fit_get_columns(f, Dk, cols.data(), pooled.data() + (size_t)c0 * n_keep * Dk)
+                                  : fail(PPCX_ERR_ARG, "checked columns do not match the K-gene model");
+    }
+    if (rc != PPCX_OK) errs[r] = g_err;          // (g_err is per thread)
+    rcs[r] = rc;
+    ppcx_fit_free(f); ppcx_model_destroy(m);
+  };
+  {
+    std::vector<std::thread> th;
+    for (int r = 1; r < ndev; ++r) th.emplace_back(work, r);
+    work(0);
+    for (auto& t : th) t.join();
+  }
+  for (int r = 0; r < ndev; ++r) if (rcs[r] != PPCX_OK) return fail(rcs[r], "device " + std::to_string(devs[r]) + ": " + errs[r]);
+  // the K checked genes on the first device: cell ids g * S + s and draw indices are those of the full model
+  std::vector<int> ex_k;
+  for (int e = 0; e < n_excl; ++e) if (excl[e] / S < K) ex_k.push_back(excl[e]);
+  ppcx_model* mk = nullptr; ppcx_fit* fk = nullptr;
+  int rc = ppcx_model_create(devs[0], K, S, C, K, counts, X, exposure, lmm, (int)ex_k.size(), ex_k.data(), &mk);
+  if (rc == PPCX_OK) rc = ppcx_fit_from_draws(mk, chains, n_keep, pooled.data(), &fk);
+  if (rc == PPCX_OK) rc = ppcx_fit_ppc(fk, tc, p_lo, p_hi, seed, n_gen, resample, ci, counts_rng);
+  if (rc == PPCX_OK && slope) {
+    for (int k = 0; k < K; ++k) {
+      double s = 0;
+      for (long r = 0; r < (long)chains * n_keep; ++r) s += pooled[(size_t)r * Dk + 3 + K + k];
+      slope[k] = s / ((double)chains * n_keep);
+    }
+  }
+  ppcx_fit_free(fk); ppcx_model_destroy(mk);
+  return rc;
+}
+
 extern "C" void ppcx_do_inference_C(const int* dims, const int* counts, const double* X, const double* exposure,
                                     const int* excl, const double* reals, double* ci, double* slope, int* counts_rng,
                                     int* status, char** errbuf, const int* errlen) {
@@ -1854,8 +1923,17 @@ extern "C" void ppcx_do_inference_C(const int* dims, const int* counts, const do
   const int device = dims[0], G = dims[1], S = dims[2], C = dims[3], K = dims[4], n_excl = dims[5];
   const int vb = dims[11], save_rng = dims[12];
   if (save_rng && !counts_rng) { finish(fail(PPCX_ERR_ARG, "save_generated_quantities without a counts_rng buffer")); return; }
+  const int n_devices = dims[15];
+  if (n_devices < 0 || n_devices > 16) { finish(fail(PPCX_ERR_ARG, "n_devices must be 0 .. 16")); return; }
+  if (!vb && n_devices > 1 && K > 0) {          // the chains over several devices (ADVI is one chain: the first device)
+    ppcx_nuts_config cfg; ppcx_nuts_config_default(&cfg);
+    cfg.chains = dims[6]; cfg.iter = dims[7]; cfg.warmup = dims[8]; cfg.seed = (unsigned long long)reals[4];
+    finish(nuts_over_devices(dims + 16, n_devices, G, S, C, K, counts, X, exposure, reals[0], n_excl, excl, cfg, reals[1], reals[2], reals[3],
+                             (unsigned long long)reals[4], dims[9], dims[10], ci, slope, save_rng ? counts_rng : nullptr));
+    return;
+  }
   ppcx_model* m = nullptr; ppcx_fit* f = nullptr;
-  int rc = ppcx_model_create(device, G, S, C, K, counts, X, exposure, reals[0], n_excl, excl, &m);
+  int rc = ppcx_model_create(n_devices >= 1 ? dims[16] : device, G, S, C, K, counts, X, exposure, reals[0], n_excl, excl, &m);
   if (rc == PPCX_OK) {
     if (vb) {
       ppcx_advi_config ac; ppcx_advi_config_default(&ac);

@@ -246,3 +246,16 @@ def do_inference_shards(counts, X, exposure_rate, how_many_to_check, *, device=0
     raise_if_any_rank_failed(err, device=coll_device, what="pooled summary")
     dist.broadcast_object_list(res, src=0)
     return res[0]
+
+
+def identify_outliers(data, *, shards=False, device=0, coll_device="cpu", launch=None, **kw):
+    """ppcseq_amd.methods.identify_outliers -- thresholds, discovery pass, exclusion, test pass with truncation compensation,
+    flags and the tidy frame (R/methods.R:155-167,268-342) -- with BOTH passes run over the ranks of the initialised
+    torch.distributed job, one process per GPU: the chains of a pass dealt to the ranks (do_inference above; the reference's
+    chains / cores, R/utilities.R:1500-1501), or with shards=True its genes (do_inference_shards; the reference's map_rect over
+    gene shards). Every rank passes the same data and gets the same frame. NUTS only (approximate_posterior_inference = False)."""
+    import functools
+    from . import methods
+    kw.setdefault("approximate_posterior_inference", False)
+    one_pass = functools.partial(do_inference_shards if shards else do_inference, device=device, coll_device=coll_device, launch=launch)
+    return methods.identify_outliers(data, device=device, _pass=one_pass, **kw)

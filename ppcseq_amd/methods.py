@@ -116,7 +116,7 @@ def identify_outliers(data, formula="~ 1", sample="sample", transcript="transcri
                       approximate_posterior_inference=True, approximate_posterior_analysis=True,
                       draws_after_tail=10, save_generated_quantities=False, additional_parameters_to_save=(),
                       cores=None, pass_fit=False, do_check_only_on_detrimental=None, tol_rel_obj=0.01,
-                      just_discovery=False, seed=None, adj_prob_theshold_2=None, device=0):
+                      just_discovery=False, seed=None, adj_prob_theshold_2=None, device=0, devices=None, launch=None, _pass=None):
     """Mirror of ppcseq::identify_outliers (R/methods.R:74-367): same arguments, same defaults.
 
     data is a tidy pandas DataFrame (one row per transcript x sample); column arguments are strings. As in the
@@ -127,6 +127,13 @@ def identify_outliers(data, formula="~ 1", sample="sample", transcript="transcri
     (`detect_cores()`), which only bounds the number of chains. Pass `approximate_posterior_inference = False` for NUTS,
     this engine's headline path. Returns a DataFrame with one row per checked transcript: <transcript>,
     sample_wise_data (nested DataFrame), ppc_samples_failed, tot_deleterious_outliers (when do_check_only_on_detrimental).
+
+    `devices` = [...]: several HIP devices of this process. The chains of BOTH passes of a NUTS run (approximate_posterior_
+    inference = False) are dealt to them, a host thread each, as the reference's sampling(chains, cores) deals its chains to
+    `cores` workers in both of its passes (R/utilities.R:1500-1501, R/methods.R:268-342); the credible intervals come from the
+    pooled chains. Not with save_generated_quantities / pass_fit (the draws then live on several devices). One process per GPU
+    over torch.distributed: ppcseq_amd.distributed.identify_outliers. `launch` = (lanes_per_gene, workgroups) pins the
+    log-likelihood launch of both passes (results are bit-identical across device counts only at equal lanes per gene).
     """
     import os
     import pandas as pd
@@ -208,14 +215,27 @@ def identify_outliers(data, formula="~ 1", sample="sample", transcript="transcri
             warnings.warn("You don't have enough memory to model the posterior distribution with MCMC draws. "
                           "Therefore the parameter approximate_posterior_analysis was set to TRUE")
             approximate_posterior_analysis = True
-    model = _lib.Model(counts, X, exposure_rate, K, device=device)
+    multi = (devices is not None and len(devices) > 1 and not approximate_posterior_inference) or _pass is not None
+    if _pass is not None:
+        # one inference pass supplied by the caller -- ppcseq_amd.distributed.identify_outliers: the chains or the genes of a
+        # pass over the ranks of a torch.distributed job -- in place of inference.do_inference; same arguments, same result type
+        if approximate_posterior_inference:
+            raise ValueError("passes over several ranks are NUTS passes (approximate_posterior_inference = False)")
+    run_pass = _pass if _pass is not None else do_inference
+    if multi and (save_generated_quantities or pass_fit):
+        raise ValueError("devices=[...] deals the chains to several devices and pools their draws: not with save_generated_quantities / pass_fit")
+    if devices is not None and len(devices) >= 1:
+        device = devices[0]
+    model = None if multi else _lib.Model(counts, X, exposure_rate, K, device=device)
+    where = {} if _pass is not None else (dict(devices=list(devices)) if multi else dict(model=model))
+    if _pass is None:
+        where.update(approximate_posterior_inference=approximate_posterior_inference, pass_fit=pass_fit, launch=launch)
     try:
         # ---- pass 1: discovery (R/methods.R:268-286); always the full posterior analysis
-        res1 = do_inference(counts, X, exposure_rate, K,
-                            approximate_posterior_inference=approximate_posterior_inference,
+        res1 = run_pass(counts, X, exposure_rate, K,
                             approximate_posterior_analysis=False, cores=cores,
                             adj_prob_theshold=adj_prob_theshold_1, how_many_posterior_draws=draws_1,
-                            seed=seed, model=model, pass_fit=pass_fit)
+                            seed=seed, **where)
         if just_discovery:
             return res1.to_frame()
         # ---- cells to exclude (R/methods.R:292-300)
@@ -223,15 +243,16 @@ def identify_outliers(data, formula="~ 1", sample="sample", transcript="transcri
         gg, ss = np.nonzero(flag)
         to_exclude = (gg * S + ss).astype(np.int32)
         # ---- pass 2: test (R/methods.R:320-342)
-        res2 = do_inference(counts, X, exposure_rate, K,
-                            approximate_posterior_inference=approximate_posterior_inference,
+        if _pass is None:
+            where.update(save_generated_quantities=save_generated_quantities)
+        res2 = run_pass(counts, X, exposure_rate, K,
                             approximate_posterior_analysis=approximate_posterior_analysis, cores=cores,
                             adj_prob_theshold=adj_prob_theshold_2, how_many_posterior_draws=draws_2,
                             to_exclude=to_exclude, truncation_compensation=0.7352941,
-                            save_generated_quantities=save_generated_quantities, seed=seed, model=model,
-                            pass_fit=pass_fit)
+                            seed=seed, **where)
     finally:
-        model.close()
+        if model is not None:
+            model.close()
 
     # ---- merge_results / format_results (R/utilities.R:539-608)
     cov_by_sample = my_df[[sample] + covs].drop_duplicates().set_index(sample)

@@ -11,17 +11,21 @@ ppcx_do_inference <- function(counts_GS, X, exposure_rate, K, to_exclude_cells,
                               adj_prob_theshold, truncation_compensation,
                               how_many_posterior_draws, approximate_posterior_analysis,
                               save_generated_quantities = FALSE,
-                              lambda_mu_mu = 5.612671, device = 0L) {
+                              lambda_mu_mu = 5.612671, device = 0L,
+                              devices = integer(0)) {      # several GPUs: the chains of a NUTS pass are dealt to them, as
+                                                           # sampling(cores = ...) deals them to its workers (R/utilities.R:1500-1501)
   G <- nrow(counts_GS); S <- ncol(counts_GS); C <- ncol(X)
   draws_practical <- if (approximate_posterior_analysis) 1000L else as.integer(how_many_posterior_draws)  # R/utilities.R:1372
   n_gen <- if (approximate_posterior_analysis) as.integer(how_many_posterior_draws) else 0L
   n_draws_out <- if (n_gen > 0L) n_gen else if (approximate_posterior_inference) draws_practical else chains * (iter - warmup)
-  dims <- as.integer(c(300L,                               # PPCX_VERSION this shim was written for (checked by the library)
+  stopifnot(length(devices) <= 16L)
+  dims <- as.integer(c(400L,                               # PPCX_VERSION this shim was written for (checked by the library)
                        device, G, S, C, K, length(to_exclude_cells), chains, iter, warmup,
                        n_gen, as.integer(approximate_posterior_analysis),
                        as.integer(approximate_posterior_inference), as.integer(save_generated_quantities),
                        draws_practical,                   # vb output_samples (R/utilities.R:1490)
-                       50000L))                           # vb iter (R/utilities.R:1491)
+                       50000L,                            # vb iter (R/utilities.R:1491)
+                       length(devices), devices, rep(0L, 16L - length(devices))))   # n_devices, devices[16]
   reals <- c(lambda_mu_mu, truncation_compensation, adj_prob_theshold, 1 - adj_prob_theshold, seed,
              0.005)                                       # vb tol_rel_obj, hard-coded by the reference (R/utilities.R:1492)
   out <- .C("ppcx_do_inference_C",

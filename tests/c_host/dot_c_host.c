@@ -25,6 +25,8 @@ typedef void (*do_inference_fn)(const int* dims, const int* counts, const double
                                 const int* excl, const double* reals, double* ci, double* slope, int* counts_rng,
                                 int* status, char** errbuf, const int* errlen);
 
+static int g_n_devices = 0;     /* argv[5]: the chains of a NUTS pass dealt to that many devices (all of them device 0 on a one-GPU box) */
+
 /* find_optimal_number_of_chains, R/utilities.R:291-303 */
 static int optimal_chains(double draws) {
   int best = 2; double best_tot = 1e300;
@@ -42,7 +44,8 @@ static int pass(do_inference_fn f, const Data* d, int vb, int approx_analysis, d
   int chains = optimal_chains(draws_practical); if (chains < 3) chains = 3; if (chains > 4) chains = 4;  /* cores = 4 */
   const int iter = (int)ceil((double)draws_practical / chains) + 150;             /* :1502 */
   const int n_gen = approx_analysis ? (int)draws : 0;
-  int dims[16] = {300, 0, G, S, C, K, n_excl, chains, iter, 150, n_gen, approx_analysis, vb, 0, draws_practical, 50000};
+  int dims[33] = {400, 0, G, S, C, K, n_excl, chains, iter, 150, n_gen, approx_analysis, vb, 0, draws_practical, 50000,
+                  g_n_devices, 0};                                                /* n_devices, devices[16] (all device 0 here) */
   double reals[6] = {5.612671, trunc, thr, 1.0 - thr, seed, 0.005};
   double* ci = (double*)calloc((size_t)K * S * 4, sizeof(double));
   double* slope = (double*)calloc((size_t)K, sizeof(double));
@@ -69,7 +72,8 @@ static int pass(do_inference_fn f, const Data* d, int vb, int approx_analysis, d
 }
 
 int main(int argc, char** argv) {
-  if (argc < 3) { fprintf(stderr, "usage: %s <libppcx.so> <fixture.txt> [seed] [nuts]\n", argv[0]); return 2; }
+  if (argc < 3) { fprintf(stderr, "usage: %s <libppcx.so> <fixture.txt> [seed] [nuts] [n_devices]\n", argv[0]); return 2; }
+  if (argc > 5) g_n_devices = atoi(argv[5]);
   const double seed = argc > 3 ? atof(argv[3]) : 1.0;
   const int vb = !(argc > 4 && strcmp(argv[4], "nuts") == 0);
   void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), f"{name} declared in include/ppcx.h but not exported by libppcx.so"
     lib.ppcx_version.restype = ctypes.c_int
-    assert lib.ppcx_version() == 300          # include/ppcx.h PPCX_VERSION
+    assert lib.ppcx_version() == 400          # include/ppcx.h PPCX_VERSION
 
 
 def test_test_hooks_are_not_in_the_shipped_library():
@@ -112,4 +112,4 @@ def test_r_shim_is_a_source_file_written_for_this_abi_version():
     assert proto.count(",") + 1 == len(names)
     assert "dyn.load" in open(os.path.join(ROOT, "r", "zzz.R")).read()
     host = open(os.path.join(ROOT, "tests", "c_host", "dot_c_host.c")).read()
-    assert "int dims[16] = {%d," % version in host
+    assert "int dims[33] = {%d," % version in host

@@ -20,11 +20,13 @@ def _host():
     return exe
 
 
-@pytest.mark.parametrize("mode", ["vb", "nuts"])
+@pytest.mark.parametrize("mode", ["vb", "nuts", "nuts-2-devices"])
 def test_plain_c_host_reproduces_the_reference_known_answer(mode):
+    """mode nuts-2-devices: dims names two devices (device 0 twice on this box) -- the chains of both passes are dealt to two host
+    threads inside the library, as rstan::sampling deals them to `cores` workers (R/utilities.R:1500-1501)."""
     from ppcseq_amd import build
     lib = build.build()
-    args = [_host(), lib, os.path.join(HERE, "bundled_53x21.txt"), "1"] + (["nuts"] if mode == "nuts" else [])
+    args = [_host(), lib, os.path.join(HERE, "bundled_53x21.txt"), "1"] + (["nuts"] if mode != "vb" else []) + (["2"] if mode == "nuts-2-devices" else [])
     p = subprocess.run(args, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr
     lines = p.stdout.strip().splitlines()
@@ -37,7 +39,7 @@ def test_c_host_reports_a_stale_abi_version_instead_of_reading_on():
     import ctypes as C
     from ppcseq_amd import build
     lib = C.CDLL(build.build())
-    dims = (C.c_int * 16)(200, *([0] * 15))
+    dims = (C.c_int * 33)(300, *([0] * 32))
     reals = (C.c_double * 6)()
     ci = (C.c_double * 4)()
     status, errlen = (C.c_int * 1)(7), (C.c_int * 1)(128)

@@ -488,3 +488,76 @@ def test_a_refused_exchange_fit_leaves_nothing_on_the_device():
     free2, _ = L.device_memory(0)
     assert free0 - free1 < 64 << 20, "the refused fits left their draws on the device"   # the model itself is a few MB
     assert abs(free2 - free0) < 16 << 20, "Model.close() was deferred by a fit that was never handed out"
+
+
+# ---- identify_outliers() -- both passes -- over several devices and over several ranks (R/methods.R:268-342 with the reference's
+# ---- chains spread over `cores`, R/utilities.R:1500-1501) -------------------------------------------------------------------
+def _two_pass_frame():
+    """A reduced cfg5: synthetic genes with injected outliers, two groups, pfp = 5, the first K genes checked."""
+    import pandas as pd
+    from ppcseq_amd.synth import synth
+    d = synth(400, 24, seed=20255)
+    K = 20
+    G, S = d["counts"].shape
+    rows = []
+    for g in range(G):
+        for s_ in range(S):
+            rows.append((f"s{s_:02d}", f"g{g:04d}", int(d["counts"][g, s_]), "B" if d["X"][s_, 1] else "A", g < K, 0.5 if g < K else 0.9 + 1e-6 * g))
+    return pd.DataFrame(rows, columns=["sample", "symbol", "value", "Label", "is_significant", "PValue"]), K
+
+
+_TWO_PASS_KW = dict(formula="~ Label", sample="sample", transcript="symbol", abundance="value", significance="PValue", do_check="is_significant",
+                    percent_false_positive_genes=5, how_many_negative_controls=380, approximate_posterior_inference=False,
+                    approximate_posterior_analysis=False, cores=4, seed=77, launch=LAUNCH)
+
+
+def _summary(out):
+    sw = out["sample_wise_data"]
+    return (out["ppc_samples_failed"].tolist(), out["tot_deleterious_outliers"].tolist(),
+            np.stack([f[".upper"].to_numpy() for f in sw]), np.stack([f["slope_after_outlier_filtering"].to_numpy()[0:1] for f in sw]))
+
+
+def _two_pass_rank_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from ppcseq_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data, _ = _two_pass_frame()
+        kw = {k: v for k, v in _TWO_PASS_KW.items() if k != "launch"}
+        out = D.identify_outliers(data, device=0, coll_device="cpu", launch=LAUNCH, **kw)
+        q.put((rank, "ok") + _summary(out))
+    except Exception as e:                      # noqa: BLE001
+        q.put((rank, "crash: " + repr(e), None, None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_identify_outliers_over_two_devices_and_over_two_ranks_equals_the_single_device():
+    """Both passes of identify_outliers with the chains dealt (a) to two devices of this process (devices=[0, 0]: two host
+    threads) and (b) to two ranks of a torch.distributed job (gloo here, one GPU shared): global chain ids and pinned lanes per
+    gene make the pooled chains those of the one-device run, so the frames coincide -- the same flagged cells, the same interval
+    ends and slopes, bit for bit."""
+    from ppcseq_amd import _lib
+    from ppcseq_amd.methods import identify_outliers
+    if _lib.device_count() < 1:
+        pytest.fail("no HIP device visible: the product has no CPU fallback")
+    data, K = _two_pass_frame()
+    one = _summary(identify_outliers(data, device=0, **_TWO_PASS_KW))
+    two = _summary(identify_outliers(data, devices=[0, 0], **_TWO_PASS_KW))
+    assert sum(one[1]) >= 1                                                 # the injected outliers are found
+    assert one[0] == two[0] and one[1] == two[1] and np.array_equal(one[2], two[2]) and np.array_equal(one[3], two[3])
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_pass_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == ["ok", "ok"], [r[1] for r in res]
+    for r in res:
+        assert r[2] == one[0] and r[3] == one[1] and np.array_equal(r[4], one[2]) and np.array_equal(r[5], one[3])

@@ -807,7 +807,7 @@ def test_dot_C_entry_point_matches_handle_api(L):
     excl = np.array([5, 17], np.int32)
     chains, iter_, warmup, seed = 3, 120, 80, 13
     n_draws = chains * (iter_ - warmup)
-    dims = np.array([L.ABI_VERSION, 0, G, S, Cc, K, excl.size, chains, iter_, warmup, 0, 0, 0, 1, 0, 0], np.int32)
+    dims = np.array([L.ABI_VERSION, 0, G, S, Cc, K, excl.size, chains, iter_, warmup, 0, 0, 0, 1, 0, 0] + [0] * 17, np.int32)
     reals = np.array([5.612671, 0.7352941, 0.01, 0.99, float(seed), 0.0])
     ci = np.zeros((K, S, 4)); slope = np.zeros(K); status = np.array([99], np.int32)
     rng = np.zeros((n_draws, K, S), np.int32)
@@ -821,6 +821,17 @@ def test_dot_C_entry_point_matches_handle_api(L):
         slope2 = f.columns(np.arange(3 + G, 3 + G + K)).reshape(-1, K).mean(0)
         f.close()
         assert np.array_equal(ci, ci2) and np.allclose(slope, slope2, rtol=0, atol=1e-14) and np.array_equal(rng, rng2)
+        # the chains dealt to several devices behind the same entry (dims: n_devices, devices[16]; here device 0 three times, one
+        # chain each, three host threads): rstan::sampling's `cores` (R/utilities.R:1500-1501). Chain ids are global and the lanes
+        # per gene those of one fit of all the chains, so the result is the single device's, bit for bit.
+        dims_nd = dims.copy(); dims_nd[16] = 3
+        ci_nd = np.zeros((K, S, 4)); slope_nd = np.zeros(K); rng_nd = np.zeros((n_draws, K, S), np.int32)
+        msg = _dot_C(lib, dims_nd, counts, X, expo, excl, reals, ci_nd, slope_nd, rng_nd, status)
+        assert status[0] == 0 and msg == ""
+        assert np.array_equal(ci_nd, ci2) and np.allclose(slope_nd, slope2, rtol=0, atol=1e-14) and np.array_equal(rng_nd, rng2)
+        dims_nd[16] = 2; dims_nd[17:19] = [0, 7]                        # a device that does not exist: status and message
+        msg = _dot_C(lib, dims_nd, counts, X, expo, excl, reals, ci_nd, slope_nd, rng_nd, status)
+        assert status[0] == -1 and "device 7" in msg
         # the reference's default mode: ADVI (approximate_posterior_inference = TRUE), approximated analysis
         dims_vb = dims.copy(); dims_vb[10:16] = [700, 1, 1, 0, 400, 0]
         msg = _dot_C(lib, dims_vb, counts, X, expo, excl, reals, ci, slope, None, status)
@@ -836,8 +847,11 @@ def test_dot_C_entry_point_matches_handle_api(L):
     dims_bad = dims.copy(); dims_bad[2] = 0
     msg = _dot_C(lib, dims_bad, counts, X, expo, excl, reals, ci, slope, rng, status)
     assert status[0] == -1 and "G>=1" in msg
-    # a shim written for the previous argument layout (device first, 15 entries) is refused before anything is read
+    # a shim written for a previous argument layout (device first; version 300's 16 entries) is refused before anything is read
     msg = _dot_C(lib, np.ascontiguousarray(dims[1:]), counts, X, expo, excl, reals, ci, slope, rng, status)
+    assert status[0] == -1 and "ABI version" in msg
+    old = dims[:16].copy(); old[0] = 300
+    msg = _dot_C(lib, old, counts, X, expo, excl, reals, ci, slope, rng, status)
     assert status[0] == -1 and "ABI version" in msg
     msg = _dot_C(lib, dims, counts, X, expo, excl, reals, ci, slope, None, status)       # save_generated_quantities without a buffer
     assert status[0] == -1 and "counts_rng" in msg
@@ -863,7 +877,7 @@ def test_reference_testthat_cases_through_the_dot_C_entry(L, bundled):
     for approx in (True, False):
         status = np.array([99], np.int32); ci = np.zeros((K, S, 4)); slope = np.zeros(K)
         # pass 1 (discovery): always the full analysis (R/methods.R:273); draws_1 = max(1000, 10 / thr1) = 1000
-        dims = np.array([L.ABI_VERSION, 0, G, S, 2, K, 0, 0, 0, 0, 0, 0, 1, 0, 1000, 0], np.int32)
+        dims = np.array([L.ABI_VERSION, 0, G, S, 2, K, 0, 0, 0, 0, 0, 0, 1, 0, 1000, 0] + [0] * 17, np.int32)
         reals = np.array([5.612671, 1.0, thr1, 1 - thr1, 321.0, 0.0])
         assert _dot_C(lib, dims, counts, Xf, expo, None, reals, ci, slope, None, status) == "" and status[0] == 0
         r1 = _post_process(counts[:K], ci.copy(), slope.copy(), X)
@@ -871,9 +885,9 @@ def test_reference_testthat_cases_through_the_dot_C_entry(L, bundled):
         # pass 2 (test): exclusions, truncation compensation, draws_2 = 10 / thr2 = 10 500
         draws2 = int(max(1000, 10 / thr2))
         if approx:
-            dims2 = np.array([L.ABI_VERSION, 0, G, S, 2, K, excl.size, 0, 0, 0, draws2, 1, 1, 0, 1000, 0], np.int32)
+            dims2 = np.array([L.ABI_VERSION, 0, G, S, 2, K, excl.size, 0, 0, 0, draws2, 1, 1, 0, 1000, 0] + [0] * 17, np.int32)
         else:
-            dims2 = np.array([L.ABI_VERSION, 0, G, S, 2, K, excl.size, 0, 0, 0, 0, 0, 1, 0, draws2, 0], np.int32)
+            dims2 = np.array([L.ABI_VERSION, 0, G, S, 2, K, excl.size, 0, 0, 0, 0, 0, 1, 0, draws2, 0] + [0] * 17, np.int32)
         reals2 = np.array([5.612671, 0.7352941, thr2, 1 - thr2, 321.0, 0.0])
         assert _dot_C(lib, dims2, counts, Xf, expo, excl if excl.size else None, reals2, ci, slope, None, status) == ""
         assert status[0] == 0
