@@ -40,7 +40,7 @@ void* ppcf_model_create(int G, int S, int C, int K, const int32_t* counts, const
   m->d.x0_is_one = x0;
   int x1b = (C >= 2);
   for (size_t i = (size_t)S; i < (size_t)S * C && x1b; ++i) if (X[i] != 0.0 && X[i] != 1.0) x1b = 0;
-  m->d.x1_binary = x1b;
+  m->d.x1_binary = x1b; m->d.raw_consts = (!x0 || (C >= 2 && K > 0 && !x1b)) ? 1 : 0;
   m->Sy.assign(G, 0); m->SyE.assign(G, 0); m->SyX.assign((size_t)C * G, 0); m->SX.assign((size_t)C * G, 0); m->ncell.assign(G, 0); m->Lg1.assign(G, 0);
   m->gflags.assign(G, 0); m->disp.assign((size_t)G * kDispGeneDoubles, 0.0);
   DispFit fit; disp_fit_init(fit);

@@ -360,6 +360,7 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   if (g_test.force_generic) x1b = 0;
 #endif
   m->d.x1_binary = x1b;
+  m->d.raw_consts = (!x0 || (C >= 2 && K > 0 && !x1b)) ? 1 : 0;
   // the two tuning knobs of a fit's round structure, read from the environment HERE and nowhere else
   if (const char* e = getenv("PPCX_PIPELINE")) if (atoi(e) == 0) m->opt_pipelined = 0;
   if (const char* e = getenv("PPCX_STREAM_GROUPS")) { const int v = atoi(e); if (v >= 1) m->opt_stream_groups = v; }
@@ -425,9 +426,9 @@ extern "C" int ppcx_model_set_rounds(ppcx_model* m, int pipelined, int stream_gr
   return PPCX_OK;
 }
 static bool model_pipelines(const ppcx_model* m) {
-  // the pipelined round needs a model whose cells read the anticipated constants only: X[,1] = 1 and slopes only on
-  // indicator columns (no per-cell linear predictor)
-  return m->opt_pipelined != 0 && m->ls_wgs_per_cu >= 1 && m->d.x0_is_one && (m->d.C < 2 || m->d.K == 0 || m->d.x1_binary);
+  // the pipelined round needs cells that read the anticipated constants only: every design since round 5 (a per-cell linear
+  // predictor reads the coefficients kept among the constants: Dims::raw_consts)
+  return m->opt_pipelined != 0 && m->ls_wgs_per_cu >= 1;
 }
 extern "C" int ppcx_model_set_progress(ppcx_model* m, ppcx_progress_fn fn, void* user, double every_seconds) {
   if (!m || !(every_seconds >= 0)) return fail(PPCX_ERR_ARG, "bad arguments");
@@ -1212,8 +1213,8 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
     if (!xg->connected) return fail(PPCX_ERR_ARG, "the exchange group is not connected");
     if (xg->device != m->device) return fail(PPCX_ERR_ARG, "the exchange group lives on another device than the shard");
     if (cfg->chains > xg->max_chains) return fail(PPCX_ERR_ARG, "more chains than the exchange group was created for");
-    if (!piped) return fail(PPCX_ERR_LIMIT, "the direct exchange runs inside pipelined rounds, which this model (a per-cell linear predictor) "
-                                             "or ppcx_model_set_rounds rules out: use ppcx_fit_nuts_comm");
+    if (!piped) return fail(PPCX_ERR_LIMIT, "the direct exchange runs inside pipelined rounds, which ppcx_model_set_rounds (or a model too large for "
+                                             "the merged launch's LDS) rules out: use ppcx_fit_nuts_comm");
     xg->epoch += 1;                             // every rank counts the fits of the group: sequence numbers of earlier fits never match
     xchg_fill(xg, &xa);
     xa_live = xg->nranks > 1;

@@ -31,6 +31,10 @@ PPCX_HD void coord_consts(const Dims& d, const VecRef& v, int i, double q) {
     v.at(V_C0, i) = fast_exp(-q); v.at(V_C2, i) = q;         // 1/phi: the reader takes fast_rcp(phi) itself (V_C1, V_C3 are unused)
   } else if (i >= d.off_intercept && i < d.off_sigma_raw) {
     v.at(V_C0, i) = fast_exp(q);
+    // a per-cell linear predictor (generic_cells) needs the coefficients themselves: kept beside exp(q), so that such a model's
+    // cells too read constants only and its rounds can be pipelined (round 5; before, they read the trajectory's end and the
+    // model ran the three-launch round)
+    if (d.raw_consts) v.at(V_C2, i) = q;
   }
 }
 
@@ -203,10 +207,11 @@ PPCX_HD void generic_cells(const Dims& d, const Cmd& c, const VecRef& v, int g, 
                            const double* sExpo, const double* sX, int sub, GeneParams<CM>& gp, const double* tab,
                            CellAcc<CM>& acc) {
   const int S = d.S, C = d.C;
-  gp.sigma_raw = v.at(V_Q0 + 3 * c.dir, d.off_sigma_raw + g);
-  gp.coef[0] = v.at(V_Q0 + 3 * c.dir, d.off_intercept + g);
+  // the position being evaluated, from the coordinates' constants (coord_consts; gp.sigma_raw is set by the caller from them)
+  gp.coef[0] = v.at(V_C2, d.off_intercept + g);
 #pragma unroll
-  for (int cc = 1; cc < CM; ++cc) gp.coef[cc] = (has_slopes && cc < C) ? v.at(V_Q0 + 3 * c.dir, coef_index(d, cc, g)) : 0.0;
+  for (int cc = 1; cc < CM; ++cc) gp.coef[cc] = (has_slopes && cc < C) ? v.at(V_C2, coef_index(d, cc, g)) : 0.0;
+  (void)c;
   for (int s = sub; s < S; s += L) {
     const int y = row[s];
     if (y >= 0) {

@@ -730,8 +730,8 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
 // r >> 3 the chain's column, and the workgroups with equal r & 7 land on one XCD. In the first n_srun runs position 7 is not
 // a range block but a state machine (of chain run * columns + column, if there is such a chain): state machines take the
 // slot of a log-likelihood workgroup each, all on one XCD, and every workgroup of the launch is resident from its start.
-template <int CM>
-__global__ __launch_bounds__(256, PPCX_LOGLIK_OCC_FAST) void ppcx_ls_kernel(LoglikArgs a, StepArgs sa, int n_srun, int n_chains_total, int spec) {
+template <int CM, bool GEN>
+__global__ __launch_bounds__(256, GEN ? PPCX_LOGLIK_OCC : PPCX_LOGLIK_OCC_FAST) void ppcx_ls_kernel(LoglikArgs a, StepArgs sa, int n_srun, int n_chains_total, int spec) {
   extern __shared__ double lds[];
   const int nch = a.nchains;
   const int lin = blockIdx.x, run = lin / (8 * nch), r = lin - run * (8 * nch);
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256, PPCX_LOGLIK_OCC_FAST) void ppcx_ls_kernel(Logl
     return;
   }
   const int jb = run < n_srun ? run * 7 + pos : n_srun * 7 + (run - n_srun) * 8 + pos;
-  loglik_role<CM, false, true>(a, jb, col, lds);
+  loglik_role<CM, GEN, true>(a, jb, col, lds);
 }
 
 // One gene's part of a pipelined round, for the lane that owns gene g (g >= G: a lane without a gene, which only takes part
@@ -1437,22 +1437,24 @@ hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int ncha
   else hipLaunchKernelGGL((ppcx_close_kernel<8>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
-static const void* ls_kernel_ptr(int CM) {
-  if (CM <= 2) return (const void*)ppcx_ls_kernel<2>;
-  if (CM <= 4) return (const void*)ppcx_ls_kernel<4>;
-  return (const void*)ppcx_ls_kernel<8>;
+static bool loglik_generic_possible(const Dims& d);
+static const void* ls_kernel_ptr(int CM, bool gen) {
+  if (CM <= 2) return gen ? (const void*)ppcx_ls_kernel<2, true> : (const void*)ppcx_ls_kernel<2, false>;
+  if (CM <= 4) return gen ? (const void*)ppcx_ls_kernel<4, true> : (const void*)ppcx_ls_kernel<4, false>;
+  return gen ? (const void*)ppcx_ls_kernel<8, true> : (const void*)ppcx_ls_kernel<8, false>;
 }
 static size_t ls_lds_bytes(int S, int C) { const size_t a = loglik_lds_bytes(S, C); return a > sizeof(StepShared) ? a : sizeof(StepShared); }
 int ls_resident_workgroups_per_cu(int CM, const Dims& d) {
   int n = 0;
   const size_t lds_bytes = ls_lds_bytes(d.S, d.C);
+  const bool gen = loglik_generic_possible(d);
   if (lds_bytes > 64u * 1024u) {
-    if (hipFuncSetAttribute(ls_kernel_ptr(CM), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipFuncSetAttribute(ls_kernel_ptr(CM, gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
   }
   hipError_t e;
-  if (CM <= 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<2>, 256, lds_bytes);
-  else if (CM <= 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<4>, 256, lds_bytes);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<8>, 256, lds_bytes);
+  if (CM <= 2) e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<2, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<2, false>, 256, lds_bytes);
+  else if (CM <= 4) e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<4, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<4, false>, 256, lds_bytes);
+  else e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<8, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<8, false>, 256, lds_bytes);
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
 }
@@ -1464,7 +1466,7 @@ hipError_t launch_ls_kernel(int CM, const LoglikArgs& a, const StepArgs& sa, int
   const dim3 grid((unsigned)runs * 8u * (unsigned)a.nchains);
   LoglikArgs args = a; StepArgs sargs = sa;
   void* params[] = {&args, &sargs, &n_srun, &n_chains_total, &spec};
-  return hipLaunchKernel(ls_kernel_ptr(CM), grid, dim3(256), params, lds_bytes, st);
+  return hipLaunchKernel(ls_kernel_ptr(CM, loglik_generic_possible(a.d)), grid, dim3(256), params, lds_bytes, st);
 }
 hipError_t launch_gene_kernel(int CM, const GeneArgs& a, int nblocks, int nchains, hipStream_t st) {
   const dim3 grid(nblocks, nchains);

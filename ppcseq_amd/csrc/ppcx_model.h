@@ -41,6 +41,8 @@ struct Dims {
   int x1_binary;                // C >= 2 and every slope column of X in {0, 1} (model.matrix of factors: `~ Label`, a multi-level
                                 // factor, `~ a + b`): e^t of a gene with slopes is E_s A_g times exp(slope_c) of the sample's
                                 // columns -- no per-cell exp for the checked genes either (C == 2: A_g or A1_g by the group)
+  int raw_consts;               // the model has genes whose linear predictor is formed per cell (a continuous covariate, or
+                                // X[,1] != 1): the position itself is kept among a coordinate's constants too (coord_consts)
   int Gt, Kt, g0, k0;           // gene shard: totals of the whole problem and this shard's first gene / checked gene
   int gstride;                  // ... and the distance of its consecutive genes in the whole problem: 1 = a contiguous range;
                                 // N = every N-th gene (the reference deals genes to its shards round-robin, R/utilities.R:125-136)
@@ -56,7 +58,7 @@ PPCX_HD Dims make_dims(int G, int S, int C, int K, double lambda_mu_mu) {
   d.off_sigma_raw = d.off_alpha2 + (C > 2 ? C - 2 : 0) * K;
   d.off_tail = d.off_sigma_raw + G;
   d.D = d.off_tail + 3;
-  d.x0_is_one = 1; d.x1_binary = 0; d.lambda_mu_mu = lambda_mu_mu;
+  d.x0_is_one = 1; d.x1_binary = 0; d.raw_consts = 0; d.lambda_mu_mu = lambda_mu_mu;
   d.Gt = G; d.Kt = K; d.g0 = 0; d.k0 = 0; d.gstride = 1;
   return d;
 }

@@ -467,16 +467,17 @@ def test_do_inference_with_the_genes_sharded_over_two_ranks():
 
 def test_a_refused_exchange_fit_leaves_nothing_on_the_device():
     """ppcx_fit_nuts_xchg looks at its exchange group before it allocates anything: the direct exchange needs pipelined rounds,
-    which a model with a continuous covariate does not run -- a documented, expected refusal (PPCX_ERR_LIMIT: use
-    ppcx_fit_nuts_comm) -- and a refused call must leave no draws buffer behind and no reference that would keep the model's
-    count matrix on the device after Model.close()."""
+    which ppcx_model_set_rounds can rule out -- a documented, expected refusal (PPCX_ERR_LIMIT: use ppcx_fit_nuts_comm) -- and a
+    refused call must leave no draws buffer behind and no reference that would keep the model's count matrix on the device after
+    Model.close()."""
     from ppcseq_amd import _lib as L
     if L.device_count() < 1:
         pytest.fail("no HIP device visible: the product has no CPU fallback")
     d = ind.synth(300, 40, K=20, seed=31, C=2)
-    X = d["X"].copy(); X[:, 1] = np.linspace(-1.0, 1.0, 40)                 # a continuous covariate: per-cell linear predictor
+    X = d["X"].copy()
     free0, _ = L.device_memory(0)
     m = L.Model(d["counts"], X, d["exposure"], 20)
+    m.set_rounds(pipelined=0)                                               # the three-launch round: no direct exchange
     xg = L.Xchg(1, 0, 4)
     try:
         for _ in range(3):

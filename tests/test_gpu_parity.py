@@ -126,11 +126,33 @@ def test_factor_designs_factorise_and_pipeline(L, oracle, levels, G, S, K, seed)
                 assert np.allclose(dg["stepsize"][:, :6], r.stepsize[:, :6], rtol=1e-9, atol=0), pipe
     finally:
         m.close()
+    # a continuous covariate beside the factor (`~ group + age`, R/utilities.R:887-900): the checked genes' cells form eta per
+    # cell (an exp each) from the coefficients kept among the coordinates' constants, and the model pipelines like every other
+    # (round 5; before, it ran the three-launch round): density and gradient against the oracle, both round structures on the
+    # oracle's sampler
     Xc = d["X"].copy()
-    Xc[:, -1] = np.linspace(-1, 1, S)                                      # a continuous covariate: per-cell exp, three launches
-    m = L.Model(counts, Xc, d["exposure"], K)
+    Xc[:, -1] = np.linspace(-1, 1, S)
+    moc = oracle.model(counts, Xc, d["exposure"], K, excl=excl)
+    refc = [oracle.log_prob_grad(moc, u[i]) for i in range(2)]
+    m = L.Model(counts, Xc, d["exposure"], K, excl=excl)
     try:
-        assert m.get_rounds(3)[0] is False
+        assert m.get_rounds(3)[0] is True
+        for lanes in (0, 8, 64):
+            m.set_launch(lanes, 0)
+            lp, g = m.log_prob_grad(u)
+            for i in range(2):
+                assert abs(lp[i] - refc[i][0]) <= 1e-11 * abs(refc[i][0]), (lanes, i)
+                assert np.max(np.abs(g[i] - refc[i][1]) / (1 + np.abs(refc[i][1]))) < 1e-10, (lanes, i)
+        if G <= 70:
+            m.set_launch(0, 0)
+            r = oracle.nuts_model(moc, oracle.cfg(chains=2, iter=14, warmup=10, seed=5))
+            for pipe in (-1, 0):
+                m.set_rounds(pipelined=pipe)
+                f = m.fit_nuts(chains=2, iter=14, warmup=10, seed=5)
+                dg = f.diagnostics()
+                f.close()
+                assert np.array_equal(dg["n_leapfrog"][:, :6], r.n_leapfrog[:, :6]), pipe
+                assert np.allclose(dg["stepsize"][:, :6], r.stepsize[:, :6], rtol=1e-9, atol=0), pipe
     finally:
         m.close()
 
