@@ -381,7 +381,7 @@ def kernel_sources_sha16():
     """Hash of the HIP sources the log-likelihood kernel is built from (recorded in profiles/rNN_loglik_issue.json)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("ppcx_math.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h", "ppcx_kernels.h", "ppcx_kernels.hip"):
+    for f in ("ppcx_math.h", "ppcx_disp.h", "ppcx_model.h", "ppcx_nuts.h", "ppcx_gene.h", "ppcx_kernels.h", "ppcx_kernels.hip"):
         with open(os.path.join(ROOT, "ppcseq_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

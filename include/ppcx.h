@@ -124,6 +124,10 @@ PPCX_API int ppcx_fit_get_columns(ppcx_fit* f, int n_cols, const int32_t* cols, 
 /* lp: [chains][n_keep]; the rest [chains][iter] (warmup included); any pointer may be NULL */
 PPCX_API int ppcx_fit_get_diagnostics(ppcx_fit* f, double* lp, double* stepsize, int32_t* treedepth,
                              int32_t* n_leapfrog, int32_t* divergent, double* accept);
+/* [chains][D]: the diagonal of the inverse metric every chain ended its warm-up with, in the order of the unconstrained vector
+ * (what rstan::get_adaptation_info(fit) prints as "Diagonal elements of inverse mass matrix"; the adapted step sizes are the
+ * last column of ppcx_fit_get_diagnostics' stepsize). NUTS fits only.                                                        */
+PPCX_API int ppcx_fit_get_inv_metric(ppcx_fit* f, double* inv_metric);
 /* wall seconds of the sampling loop, gradient evaluations summed over chains, and the mean duration
  * (ms) / count of the HIP-event-timed log-likelihood-kernel launches with the chain-launches they covered    */
 PPCX_API int ppcx_fit_get_timing(ppcx_fit* f, double* seconds, long long* grad_evals, double* gene_kernel_ms_mean,

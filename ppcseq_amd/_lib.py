@@ -23,7 +23,7 @@ EXPORTS = [
     "ppcx_fit_nuts_comm", "ppcx_advi_config_default", "ppcx_fit_advi", "ppcx_fit_advi_info", "ppcx_fit_advi_iterative",
     "ppcx_guard_decision", "ppcx_device_memory", "ppcx_fit_get_ppc_timing",
     "ppcx_xchg_create", "ppcx_xchg_handle", "ppcx_xchg_connect", "ppcx_xchg_connect_local", "ppcx_xchg_set_timeout", "ppcx_xchg_destroy",
-    "ppcx_fit_nuts_xchg", "ppcx_fit_get_xchg_timing",
+    "ppcx_fit_nuts_xchg", "ppcx_fit_get_xchg_timing", "ppcx_fit_get_inv_metric",
 ]
 ABI_VERSION = 400           # include/ppcx.h PPCX_VERSION this binding was written for
 
@@ -95,6 +95,7 @@ def load() -> C.CDLL:
     lib.ppcx_fit_get_diagnostics.argtypes = [C.c_void_p, dp, dp, ip, ip, ip, dp]
     lib.ppcx_fit_get_timing.argtypes = [C.c_void_p, dp, C.POINTER(C.c_longlong), dp, C.POINTER(C.c_longlong), dp]
     lib.ppcx_fit_get_kernel_times.argtypes = [C.c_void_p, dp, dp, dp, C.POINTER(C.c_longlong)]
+    lib.ppcx_fit_get_inv_metric.argtypes = [C.c_void_p, dp]
     lib.ppcx_fit_ppc.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_ulonglong, C.c_int, C.c_int, dp, ip]
     lib.ppcx_fit_free.argtypes = [C.c_void_p]
     lib.ppcx_model_set_rounds.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -445,6 +446,12 @@ class Fit:
         _check(load().ppcx_fit_get_diagnostics(self._h, _p(lp, C.c_double), _p(ss, C.c_double), _p(td, C.c_int32),
                                                 _p(nl, C.c_int32), _p(dv, C.c_int32), _p(acc, C.c_double)))
         return dict(lp=lp, stepsize=ss, treedepth=td, n_leapfrog=nl, divergent=dv, accept=acc)
+
+    def inv_metric(self):
+        """[chains, D] diagonal of the adapted inverse metric (rstan::get_adaptation_info)."""
+        out = np.zeros((self.chains, self.D))
+        _check(load().ppcx_fit_get_inv_metric(self._h, _p(out, C.c_double)))
+        return out
 
     def timing(self) -> Timing:
         s, ms, cl = C.c_double(), C.c_double(), C.c_double()

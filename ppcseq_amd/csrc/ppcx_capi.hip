@@ -94,6 +94,7 @@ struct ppcx_fit {
   double advi_elbo = 0, advi_eta = 0; int advi_converged = 0;
   double ppc_ms = 0; long long ppc_draws = 0;  // last ppcx_fit_ppc: kernel time (HIP events) and NB draws generated
   long long xchg_ticks = 0, xchg_count = 0;    // direct exchange: 100 MHz ticks the chains' state machines waited for peers, exchanges
+  std::vector<double> inv_metric;              // [chains][D] diagonal of the adapted inverse metric (host; ppcx_fit_get_inv_metric)
 };
 
 extern "C" int ppcx_version(void) { return PPCX_VERSION; }
@@ -1229,6 +1230,7 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
   };
   f = new ppcx_fit();
   fit_attach(f, m); f->chains = nch; f->n_keep = n_keep; f->iter = iter;
+  f->inv_metric.assign((size_t)nch * D, 1.0);
   NutsConfig nc;
   nc.chains = nch; nc.iter = iter; nc.warmup = cfg->warmup; nc.seed = cfg->seed; nc.adapt_delta = cfg->adapt_delta;
   nc.max_treedepth = cfg->max_treedepth; nc.init_radius = cfg->init_radius; nc.stepsize0 = cfg->stepsize0;
@@ -1304,6 +1306,15 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
       G->rc = PPCX_ERR_HIP; G->err = "reading back the chain states failed"; return;
     }
     for (int c = 0; c < G->n; ++c) { G->leap += states[c].sc.total_leapfrogs; G->xticks += states[c].xc.ticks; G->xcount += states[c].xc.count; }
+    // the adapted inverse metric (what rstan::get_adaptation_info prints): the genes' coordinates, then the six hyper-parameters
+    std::vector<double> hq((size_t)G->n * V_COUNT * 8);
+    bool ok = hipMemcpy(hq.data(), current_hyper(G->w), sizeof(double) * hq.size(), hipMemcpyDeviceToHost) == hipSuccess;
+    for (int c = 0; c < G->n && ok; ++c) {
+      double* dst = f->inv_metric.data() + (size_t)(G->c0 + c) * D;
+      ok = hipMemcpy(dst, G->w.vecs + ((size_t)c * V_COUNT + V_MINV) * G->w.Dpad, sizeof(double) * D, hipMemcpyDeviceToHost) == hipSuccess;
+      for (int k = 0; k < 6; ++k) dst[hyper_index(m->d, k)] = hq[((size_t)c * V_COUNT + V_MINV) * 8 + k];
+    }
+    if (!ok) { G->rc = PPCX_ERR_HIP; G->err = "reading back the inverse metric failed"; }
   };
   {
     std::vector<std::thread> th;
@@ -1727,6 +1738,12 @@ extern "C" int ppcx_fit_get_diagnostics(ppcx_fit* f, double* lp, double* stepsiz
   if (n_leapfrog && f->d_nleap) HIPCHK(hipMemcpy(n_leapfrog, f->d_nleap, sizeof(int) * ni, hipMemcpyDeviceToHost));
   if (divergent && f->d_div) HIPCHK(hipMemcpy(divergent, f->d_div, sizeof(int) * ni, hipMemcpyDeviceToHost));
   if (accept && f->d_accept) HIPCHK(hipMemcpy(accept, f->d_accept, sizeof(double) * ni, hipMemcpyDeviceToHost));
+  return PPCX_OK;
+}
+extern "C" int ppcx_fit_get_inv_metric(ppcx_fit* f, double* out) {
+  if (!f || !out) return fail(PPCX_ERR_ARG, "bad arguments");
+  if (f->inv_metric.empty()) return fail(PPCX_ERR_ARG, "this fit has no adapted metric (not a NUTS fit)");
+  memcpy(out, f->inv_metric.data(), sizeof(double) * f->inv_metric.size());
   return PPCX_OK;
 }
 extern "C" int ppcx_fit_get_kernel_times(ppcx_fit* f, double* loglik_ms, double* close_ms, double* update_ms,
