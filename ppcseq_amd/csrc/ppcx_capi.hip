@@ -137,7 +137,12 @@ static double pass_cost(const ppcx_model* m, int L, int p, int n) {
 #ifdef PPCX_TESTING
   if (g_test.slope_cost_permille > 0) slope_w = 1e-3 * g_test.slope_cost_permille;
 #endif
-  const double sweep = (double)((S + L - 1) / L) * (!m->d.x0_is_one || (slope && !m->d.x1_binary) ? 2.5 : (slope ? slope_w : 1.0));
+  // ... and with an exp per cell (a continuous covariate: sweep_cells MODE 3; without the column of ones: generic_cells)
+  double lin_w = 2.5;
+#ifdef PPCX_TESTING
+  if (g_test.slope_cost_permille > 0) lin_w = 1e-3 * g_test.slope_cost_permille;
+#endif
+  const double sweep = (double)((S + L - 1) / L) * (!m->d.x0_is_one ? 2.5 : (slope && !m->d.x1_binary ? lin_w : (slope ? slope_w : 1.0)));
   return 5.8 + sweep;
 }
 // reserve: workgroups of the same launch that are not log-likelihood workgroups (the state machines of a pipelined
@@ -302,6 +307,32 @@ static int upload_counts(ppcx_model* m, int n_excl, const int32_t* excl) {
       if (sa != sb) return sa;
       return gflags[a] > gflags[b];
     });
+    // ... and the genes with slopes are dealt over the whole order in blocks of kOrderBlock positions (whole passes for every L
+    // >= 4), evenly spaced among the plain genes' blocks: a wavefront's range is a contiguous piece of the order, a workgroup's
+    // four wavefronts hold neighbouring ranges and a CU four workgroups in dispatch order, so with the slope genes at the front
+    // a few CUs ran nothing but the dearer passes -- `~ group + age` at BASELINE size: 61 us per 8-chain launch whatever weight
+    // the plan gave those passes, 46 us dealt out, against 40 us for the sum of the work; the order does not enter a gene's sums.
+    // Only where those passes are much dearer (an exp per cell): with indicator columns they cost 1.15 x a plain one, and dealing
+    // them out makes a chain group's launch of three chains 5 % slower (17.6 -> 18.6 us: shorter runs of alike passes).
+    {
+      int ns = 0;
+      while (ns < G && ord[ns] < K && C >= 2) ++ns;         // genes with slopes: the first ns positions
+      constexpr int kOrderBlock = 16;
+      const int nbs = (ns + kOrderBlock - 1) / kOrderBlock, nb = (G + kOrderBlock - 1) / kOrderBlock;
+      const bool dear_slopes = m->d.x0_is_one && !m->d.x1_binary;      // an exp per cell (sweep_cells MODE 3): 2.4 x a plain pass
+      if (ns > 0 && ns < G && nbs < nb && dear_slopes) {
+        std::vector<int> mixed; mixed.reserve(G);
+        int is = 0, ip = ns, sb = 0;                       // next slope gene, next plain gene, slope blocks placed
+        for (int b = 0; b < nb; ++b) {
+          const bool slope_block = sb < nbs && b == (int)((long long)sb * nb / nbs);
+          if (slope_block && is < ns) { for (int k = 0; k < kOrderBlock && is < ns; ++k) mixed.push_back(ord[is++]); ++sb; }
+          else { for (int k = 0; k < kOrderBlock && ip < G; ++k) mixed.push_back(ord[ip++]); }
+        }
+        while (is < ns) mixed.push_back(ord[is++]);
+        while (ip < G) mixed.push_back(ord[ip++]);
+        ord.swap(mixed);
+      }
+    }
     HIPCHK(hipMemcpy(m->d_order, ord.data(), sizeof(int) * (size_t)G, hipMemcpyHostToDevice));
     m->pos_slope.resize(G);
     for (int p = 0; p < G; ++p) m->pos_slope[p] = ord[p] < K && C >= 2;

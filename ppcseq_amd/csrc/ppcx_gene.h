@@ -126,7 +126,10 @@ template <int L> struct DispDeal {
 
 // MODE 0: plain gene (e^t = E_s A); 1: two-group design (A or A1 by the sample's group, sX1 = the group column);
 // 2: more indicator columns (C > 2; sX1 = column 1 of X in LDS, column c at sX1 + (c - 1) S; ec[c] = exp(slope_c)):
-// A times the ec of the sample's columns
+// A times the ec of the sample's columns; 3: slope columns of any values (a continuous covariate: `~ group + age`,
+// R/utilities.R:887-900): ec[c] = slope_c itself, e^t = E_s A exp(sum_c X_sc slope_c) -- one exp per cell on top of the
+// factorised E_s A, in the same four-cell trips with their counts requested a trip ahead (the general cell: such a gene's w
+// have no common window that the slopes' constants would give away)
 // WIN: the windowed cell (ppcx_model.h GeneWindow): A, A1 arrive scaled by 2^-k, one = 2^-k, tab = the window table; else the
 // general cell: one = 1 (not used), tab = the mantissa table
 template <int CM, int L, int MODE, bool MASKED, bool WIN>
@@ -148,6 +151,13 @@ PPCX_HD void sweep_cells(int S, const int* row, const double* sE, const double* 
       double a_ = (XB) != 0.0 ? A1 : A; double xk_[CM];                                         \
       _Pragma("unroll") for (int cc = 2; cc < CM; ++cc) { xk_[cc] = cc < C ? qx[(cc - 1) * S + (OFF)] : 0.0; a_ = xk_[cc] != 0.0 ? a_ * ec[cc] : a_; } \
       const double rho_ = WIN ? cell_eval_win<CM, true>(Y, E, a_, one, gp, tab, acc) : cell_eval<CM, true>(Y, E, a_, gp, tab, acc); \
+      acc.Tx[1] = fma(XB, rho_, acc.Tx[1]);                                                     \
+      _Pragma("unroll") for (int cc = 2; cc < CM; ++cc) acc.Tx[cc] = fma(xk_[cc], rho_, acc.Tx[cc]); \
+    }                                                                                           \
+    else if (MODE == 3) {                                                                       \
+      double t_ = (XB) * ec[1]; double xk_[CM];                                                 \
+      _Pragma("unroll") for (int cc = 2; cc < CM; ++cc) { xk_[cc] = cc < C ? qx[(cc - 1) * S + (OFF)] : 0.0; t_ = fma(xk_[cc], ec[cc], t_); } \
+      const double rho_ = cell_eval<CM, true>(Y, E, A * fast_exp(t_), gp, tab, acc);           \
       acc.Tx[1] = fma(XB, rho_, acc.Tx[1]);                                                     \
       _Pragma("unroll") for (int cc = 2; cc < CM; ++cc) acc.Tx[cc] = fma(xk_[cc], rho_, acc.Tx[cc]); \
     }                                                                                           \
@@ -227,9 +237,11 @@ PPCX_HD void generic_cells(const Dims& d, const Cmd& c, const VecRef& v, int g, 
 }
 
 // one lane's share of gene g: the hand-over sums before the L-lane reduction
-// GEN = false: a model in which every gene factorises (X[,1] == 1 and slopes only on indicator columns) -- the
-// per-cell-eta path is not compiled in, which leaves the registers to the sweep
-template <int CM, int L, bool GEN = true>
+// GEN: which routes with an exp per cell are compiled in -- bit 0: slopes on columns of any values (a continuous covariate;
+// sweep_cells MODE 3), bit 1: a design without the column of ones (generic_cells). 0: a model in which every gene factorises
+// (X[,1] == 1 and slopes only on indicator columns), which leaves the registers to the sweep; the kernels have one instantiation
+// per value (0, 1, 2), the host-side emulation compiles both routes (3)
+template <int CM, int L, int GEN = 3>
 PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const CellData& m, int g, const GenePre& pre, int sub,
                             const double* sE, const double* sExpo, const double* sX, const double* tab, const double* wtab,
                             GeneSumsV<CM>& o
@@ -245,7 +257,10 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   const int S = d.S;
   const bool has_slopes = g < d.K && d.C >= 2;
   const bool two = has_slopes && d.x0_is_one && d.x1_binary;
-  const bool generic = GEN && (!d.x0_is_one || (has_slopes && !two));
+  // slopes on columns of any values: the sweep with an exp per cell (MODE 3); only a design without the column of ones still
+  // forms the whole linear predictor per cell (generic_cells)
+  const bool lin = (GEN & 1) && d.x0_is_one && has_slopes && !two;
+  const bool generic = (GEN & 2) && !d.x0_is_one;
   GeneParams<CM> gp;
   gp.phi = pre.phi;
   const double sigma = pre.sigma;
@@ -274,14 +289,14 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   }
   CellAcc<CM> acc; acc.zero();
   PPCX_GSTAMP(5);
-  if (GEN) {
+  if (GEN & 2) {
     if (PPCX_WAVE_ANY(generic)) {
       if (generic) generic_cells<CM, L>(d, c, v, g, has_slopes, row, sExpo, sX, sub, gp, tab, acc);
     }
   }
   GeneWindow gw; gw.k = 0; gw.ok = false; gw.scale = 1.0;
   bool win = false;
-  if (!GEN || PPCX_WAVE_ANY(!generic)) {
+  if (!(GEN & 2) || PPCX_WAVE_ANY(!generic)) {
     if (!generic) {
       const bool any_masked = PPCX_WAVE_ANY(masked);
       // the pass runs the windowed cell if every gene of it has a window (and none has excluded cells: those passes are few,
@@ -292,7 +307,14 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
       if (any_masked) sweep_cells<CM, L, MODE, true, false>(S, row, sE, X1_, sub, A_, A1_, 1.0, gp, tab, acc, ##__VA_ARGS__);   \
       else if (win) sweep_cells<CM, L, MODE, false, true>(S, row, sE, X1_, sub, (A_) * gw.scale, (A1_) * gw.scale, gw.scale, gp, wtab, acc, ##__VA_ARGS__); \
       else sweep_cells<CM, L, MODE, false, false>(S, row, sE, X1_, sub, A_, A1_, 1.0, gp, tab, acc, ##__VA_ARGS__);
-      if (CM > 2 && d.C > 2 && PPCX_WAVE_ANY(two)) {       // indicator columns, C > 2 (factor designs): e^t = E_s A times the
+      if ((GEN & 1) && PPCX_WAVE_ANY(lin)) {                     // a continuous covariate among the slope columns: exp(X_s . slopes) per
+        double be[CM];                                     // cell; a plain gene of the same pass (the host puts genes with slopes
+        be[0] = 0.0;                                       // first) runs it with slopes 0
+#pragma unroll
+        for (int cc = 1; cc < CM; ++cc) be[cc] = (lin && cc < d.C) ? v.at(V_C2, coef_index(d, cc, g)) : 0.0;
+        if (any_masked) sweep_cells<CM, L, 3, true, false>(S, row, sE, sX + S, sub, A, A, 1.0, gp, tab, acc, be, d.C);
+        else sweep_cells<CM, L, 3, false, false>(S, row, sE, sX + S, sub, A, A, 1.0, gp, tab, acc, be, d.C);
+      } else if (CM > 2 && d.C > 2 && PPCX_WAVE_ANY(two)) {       // indicator columns, C > 2 (factor designs): e^t = E_s A times the
         double ec[CM];                                     // exp(slope_c) of the sample's columns; a plain gene of the same
         ec[0] = 1.0;                                       // pass (the host puts genes with slopes first) runs it with ec = 1
         double a_lo = A, a_hi = A;
@@ -315,6 +337,7 @@ PPCX_HD void lane_gene_sums(const Dims& d, const Cmd& c, const VecRef& v, const 
   PPCX_GSTAMP(6);
   if (!win) gw.scale = 1.0;
   cell_acc_close<CM>(gp, acc, gw.scale, &o);
+  if ((GEN & 1) && lin) o.Tx[0] = o.Sr;                           // X[,1] == 1: sum X_s1 rho is sum rho
   if (win && sub == 0 && gw.k != 0) {                       // the cells' logarithms were those of 2^-k w: k ln 2 per cell, once per gene
     const double kd = (double)gw.k;
     const double klog2 = fma(kd, 6.93147180369123816490e-01, kd * 1.90821492927058770002e-10);

@@ -37,7 +37,7 @@ typedef double2 __attribute__((may_alias)) dpair_t;
 // (+ sum X_sc rho for genes with slopes).
 // -----------------------------------------------------------------------------------------------------
 #ifndef PPCX_LOGLIK_OCC
-#define PPCX_LOGLIK_OCC 4
+#define PPCX_LOGLIK_OCC 2
 #endif
 #ifndef PPCX_LOGLIK_OCC_FAST
 #define PPCX_LOGLIK_OCC_FAST 4                   // wavefronts per SIMD of the instantiation without the per-cell-eta path
@@ -74,7 +74,7 @@ __device__ __forceinline__ double group_sum(double v) {
 // chosen on the host so that all ranges cost the same, and walks it 64 / L genes at a time. All wavefronts start
 // together and finish together: no partly filled last round of workgroups, one LDS fill per resident workgroup.
 // Wavefronts are independent after the LDS fill (no barrier, no atomic), and a gene's sums depend on L only.
-template <int CM, int LG, bool GEN>
+template <int CM, int LG, int GEN>
 __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c, const VecRef& v, double* sums, int p0, int p1,
                                               const double* stab, const double* swin, const double* sE, const double* sExpo, const double* sX,
                                               int lane, bool any_generic) {
@@ -123,7 +123,7 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
       // (its accumulators carry two slope sums, not CM: the registers the wider one needs cost the row sweep spills), and
       // the three sums of a plain gene
       GeneSumsV<2> o2;
-      lane_gene_sums<2, L, false>(d, c, v, a.cd, g, pre, sub, sE, sExpo, sX, stab, swin, o2);
+      lane_gene_sums<2, L, 0>(d, c, v, a.cd, g, pre, sub, sE, sExpo, sX, stab, swin, o2);
       o2.lik = group_sum<L>(o2.lik); o2.dph = group_sum<L>(o2.dph); o2.Sr = group_sum<L>(o2.Sr);
       if (act && sub == 0) { const long G = d.G; sums[0 * G + g] = o2.lik; sums[1 * G + g] = o2.dph; sums[2 * G + g] = o2.Sr; }
       continue;
@@ -165,7 +165,7 @@ __device__ __forceinline__ void loglik_passes(const LoglikArgs& a, const Cmd& c,
 // the body of a log-likelihood workgroup: range block jb of the chain in column `col` of the launch.
 // PIPE: part of a pipelined round's merged launch (ppcx_ls_kernel) -- the command in a.cmds is then the chain's command
 // BEFORE the state machine that runs beside this workgroup has looked at it.
-template <int CM, bool GEN, bool PIPE>
+template <int CM, int GEN, bool PIPE>
 __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col, double* lds) {
   if (jb >= a.nbpc) return;
   constexpr int NS = GeneSums<CM>::N;
@@ -190,7 +190,7 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
   if (evenS) { if (tid < S / 2) f_e = reinterpret_cast<const dpair_t*>(a.sampleE)[tid]; }
   else if (tid < S) f_e.x = a.sampleE[tid];
   double f_x = 0.0;
-  if (!GEN && any_generic && tid < S) f_x = a.X[S + tid];      // the two-group path reads the group column only (C > 2: below)
+  if (GEN != 2 && any_generic && tid < S) f_x = a.X[S + tid];      // the two-group path reads the group column only (C > 2: below)
   const int chain = a.active ? a.active[col] : col;
   const Cmd& c = a.cmds[chain];
   if (c.type == CMD_DONE || c.type == CMD_FLUSH) return;
@@ -220,7 +220,7 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
     for (int i = tid + 256; i < S; i += 256) sE[i] = a.sampleE[i];
   }
   if (any_generic) {
-    if (GEN) {
+    if (GEN == 2) {
       for (int i = tid; i < S; i += 256) sExpo[i] = a.exposure[i];
       for (int i = tid; i < S * C; i += 256) sX[i] = a.X[i];
     } else {
@@ -242,7 +242,7 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
   }
 }
 
-template <int CM, bool GEN>
+template <int CM, int GEN>
 __global__ __launch_bounds__(256, GEN ? PPCX_LOGLIK_OCC : PPCX_LOGLIK_OCC_FAST) void ppcx_loglik_kernel(LoglikArgs a) {
   extern __shared__ double lds[];
   // workgroups are dealt to the 8 XCDs round-robin in dispatch order: ids chain * 8 + (jb & 7) inside every run of
@@ -730,7 +730,7 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
 // r >> 3 the chain's column, and the workgroups with equal r & 7 land on one XCD. In the first n_srun runs position 7 is not
 // a range block but a state machine (of chain run * columns + column, if there is such a chain): state machines take the
 // slot of a log-likelihood workgroup each, all on one XCD, and every workgroup of the launch is resident from its start.
-template <int CM, bool GEN>
+template <int CM, int GEN>
 __global__ __launch_bounds__(256, GEN ? PPCX_LOGLIK_OCC : PPCX_LOGLIK_OCC_FAST) void ppcx_ls_kernel(LoglikArgs a, StepArgs sa, int n_srun, int n_chains_total, int spec) {
   extern __shared__ double lds[];
   const int nch = a.nchains;
@@ -1401,25 +1401,30 @@ __global__ void ppcx_fill_kernel(double* p, long n, double val) {
 // launch helpers (host)
 // -----------------------------------------------------------------------------------------------------
 size_t loglik_lds_bytes(int S, int C) { return sizeof(double) * (2 * kLogTabSize + 2 * kWinTabSize + (size_t)S * (2 + C) + 2 * kLdsPad); }
-// the instantiation a model runs: CM design columns (2, 4 or 8) and whether any gene can need the per-cell-eta path
-static const void* loglik_kernel_ptr(int CM, bool gen) {
-  if (CM <= 2) return gen ? (const void*)ppcx_loglik_kernel<2, true> : (const void*)ppcx_loglik_kernel<2, false>;
-  if (CM <= 4) return gen ? (const void*)ppcx_loglik_kernel<4, true> : (const void*)ppcx_loglik_kernel<4, false>;
-  return gen ? (const void*)ppcx_loglik_kernel<8, true> : (const void*)ppcx_loglik_kernel<8, false>;
+// the instantiation a model runs: CM design columns (2, 4 or 8) and which route with an exp per cell its genes can need
+// (lane_gene_sums: 0 none, 1 slopes on columns of any values, 2 no column of ones)
+#define PPCX_BY_CM_GEN(KERNEL, CM, GEN, EXPR)                                                                     \
+  do {                                                                                                            \
+    if ((CM) <= 2) { if ((GEN) == 0) { auto k_ = KERNEL<2, 0>; EXPR; } else if ((GEN) == 1) { auto k_ = KERNEL<2, 1>; EXPR; } else { auto k_ = KERNEL<2, 2>; EXPR; } } \
+    else if ((CM) <= 4) { if ((GEN) == 0) { auto k_ = KERNEL<4, 0>; EXPR; } else if ((GEN) == 1) { auto k_ = KERNEL<4, 1>; EXPR; } else { auto k_ = KERNEL<4, 2>; EXPR; } } \
+    else { if ((GEN) == 0) { auto k_ = KERNEL<8, 0>; EXPR; } else if ((GEN) == 1) { auto k_ = KERNEL<8, 1>; EXPR; } else { auto k_ = KERNEL<8, 2>; EXPR; } } \
+  } while (0)
+static const void* loglik_kernel_ptr(int CM, int gen) {
+  const void* f = nullptr;
+  PPCX_BY_CM_GEN(ppcx_loglik_kernel, CM, gen, f = (const void*)k_);
+  return f;
 }
-static bool loglik_generic_possible(const Dims& d) { return !d.x0_is_one || (d.C >= 2 && d.K > 0 && !d.x1_binary); }
+static int loglik_generic_possible(const Dims& d) { return !d.x0_is_one ? 2 : ((d.C >= 2 && d.K > 0 && !d.x1_binary) ? 1 : 0); }
 int loglik_resident_workgroups_per_cu(int CM, const Dims& d) {
   int n = 0;
   const size_t lds_bytes = loglik_lds_bytes(d.S, d.C);
-  const bool gen = loglik_generic_possible(d);
+  const int gen = loglik_generic_possible(d);
   const void* f = loglik_kernel_ptr(CM, gen);
   if (lds_bytes > 64u * 1024u) {               // more than the default limit of dynamic LDS: ask for it once
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
   }
-  hipError_t e;
-  if (CM <= 2) e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<2, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<2, false>, 256, lds_bytes);
-  else if (CM <= 4) e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<4, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<4, false>, 256, lds_bytes);
-  else e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<8, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_loglik_kernel<8, false>, 256, lds_bytes);
+  hipError_t e = hipSuccess;
+  PPCX_BY_CM_GEN(ppcx_loglik_kernel, CM, gen, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_, 256, lds_bytes));
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
 }
@@ -1437,24 +1442,21 @@ hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int ncha
   else hipLaunchKernelGGL((ppcx_close_kernel<8>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
-static bool loglik_generic_possible(const Dims& d);
-static const void* ls_kernel_ptr(int CM, bool gen) {
-  if (CM <= 2) return gen ? (const void*)ppcx_ls_kernel<2, true> : (const void*)ppcx_ls_kernel<2, false>;
-  if (CM <= 4) return gen ? (const void*)ppcx_ls_kernel<4, true> : (const void*)ppcx_ls_kernel<4, false>;
-  return gen ? (const void*)ppcx_ls_kernel<8, true> : (const void*)ppcx_ls_kernel<8, false>;
+static const void* ls_kernel_ptr(int CM, int gen) {
+  const void* f = nullptr;
+  PPCX_BY_CM_GEN(ppcx_ls_kernel, CM, gen, f = (const void*)k_);
+  return f;
 }
 static size_t ls_lds_bytes(int S, int C) { const size_t a = loglik_lds_bytes(S, C); return a > sizeof(StepShared) ? a : sizeof(StepShared); }
 int ls_resident_workgroups_per_cu(int CM, const Dims& d) {
   int n = 0;
   const size_t lds_bytes = ls_lds_bytes(d.S, d.C);
-  const bool gen = loglik_generic_possible(d);
+  const int gen = loglik_generic_possible(d);
   if (lds_bytes > 64u * 1024u) {
     if (hipFuncSetAttribute(ls_kernel_ptr(CM, gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
   }
-  hipError_t e;
-  if (CM <= 2) e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<2, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<2, false>, 256, lds_bytes);
-  else if (CM <= 4) e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<4, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<4, false>, 256, lds_bytes);
-  else e = gen ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<8, true>, 256, lds_bytes) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ppcx_ls_kernel<8, false>, 256, lds_bytes);
+  hipError_t e = hipSuccess;
+  PPCX_BY_CM_GEN(ppcx_ls_kernel, CM, gen, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_, 256, lds_bytes));
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
 }

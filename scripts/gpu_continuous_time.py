@@ -33,5 +33,6 @@ for tag, X, pipe in (("group_age_three_launch", X3, 0), ("group_age_pipelined", 
     m.close()
 a, b = out["group_age_pipelined"]["loglik_launch_us_8_chains"], out["two_group_pipelined"]["loglik_launch_us_8_chains"]
 out["launch_ratio_group_age_over_two_group"] = round(a / b, 3)
-json.dump(out, open(os.path.join(ROOT, "profiles", "r05_continuous_design.json"), "w"), indent=1)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r05_continuous_design.json"), "w"), indent=1)   # merged back by gpurun; copied to profiles/
 print("ratio", out["launch_ratio_group_age_over_two_group"])
