@@ -189,31 +189,39 @@ static int workgroups_per_chain(const ppcx_model* m, int L, int nch, int n_res, 
 }
 // chain groups on their own streams (ppcx_fit_nuts): the default for a fit of `nch` chains
 static int default_stream_groups(int nch) { return nch >= 8 ? 3 : (nch >= 4 ? 2 : 1); }
+// chains in a launch of a fit of `nch` chains: the fit runs them in groups on their own streams (ppcx_model_set_rounds, default
+// default_stream_groups), every launch holds one group. A function of the fit's chain count and the model's setting only, so that a
+// chain's lanes per gene -- hence its draws -- do not depend on anything else.
+static int fit_launch_chains(const ppcx_model* m, int nch) {
+  int g = default_stream_groups(nch);
+  if (m->opt_stream_groups >= 1) g = m->opt_stream_groups < nch ? m->opt_stream_groups : nch;
+  return (nch + g - 1) / g;
+}
 static void choose_launch(ppcx_model* m, int nchains) {
   const int G = m->d.G, S = m->d.S;
-  // lanes per gene: passes of the busiest wavefront x pass cost, smallest first -- among the choices that leave no wavefront
-  // slot of the chip without a pass (fill >= 1.2 passes per slot). Without that condition few large passes look cheapest
-  // for small numbers of chains (one pass of 32 genes per wavefront at 5 chains: 157 of 204 workgroups per chain with work,
-  // and L = 2 reads four times the cache lines per request), measured at cfg3, whole fits: 1 chain 30.0 -> 28.5 us per round
-  // (L = 8 -> 16), 2 chains 44.2 -> 35.3 (4 -> 16), 3 chains 45.9 -> 43.2 (4 -> 8), 5 chains 76.8 -> 59.4 (2 -> 4),
-  // 6 chains 81.2 -> 62.9 (2 -> 4); 4, 7 and 8 chains keep L = 8.
-  // (Choosing L for the chain groups a fit runs in -- launches of a third of the chains, whose idle slots other groups fill:
-  // L = 4 at 7 and 8 chains, one pass of 16 genes per wavefront -- made regular 8-chain fits 9 % faster, 2.75 -> 2.50 s, but of
-  // 61 seeds two ended warm-up with a chain at tree depth 10 (13.5 and 4.8 s; none of 233 fits with L = 8 did; Fisher p = 0.04):
-  // the means over all fits tried are 2.72 and 2.75 s. Not adopted; DESIGN section 3. Round 4, with the groups' launches trimmed to
-  // whole passes: L = 4 gains nothing any more -- 2.40-2.47 s against 2.35 s over the driver's seeds for all 8 ranks, one of 200 stuck.)
-  const double slots = 4.0 * (double)resident_workgroups(m, 0);
-  int bestL = 64, bestL_any = 64; double best = 1e300, best_any = 1e300;
-  for (int L = 1; L <= 64; L <<= 1) {
+  // lanes per gene for launches of `nchains` chains: passes of the busiest wavefront x pass cost, smallest first. A pass costs
+  // what its sweep costs plus 8 cell iterations' worth of loading and closing its genes (round 5: SQ_INSTS_VALU of a wavefront
+  // = 22 per cell iteration + 165 per pass; rounds 2-4, with a cell of 41 instructions: 5.8).
+  // Round 5 dropped two things. (a) The condition that a choice leave no wavefront slot of the chip without a pass (>= 1.2 passes
+  // per slot), which kept few large passes from looking cheapest at small numbers of chains: with the cheaper cell the pass
+  // overhead decides, and the measured order is the model's -- cfg3, kernel level, one chain: L = 8 9.4 us (2500 wavefronts of one
+  // pass), 4 10.9, 16 11.4, 32 13.5; two chains: L = 4 13.5, 8 15.9, 16 17.6, 32 20.5; three: L = 4 15.8, 8 17.6; eight: L = 8
+  // 38.6, 4 39.0. (b) Choosing L for all the chains of a fit when the fit runs them in groups (callers pass the chains of a
+  // group's launch, fit_launch_chains): whole cfg3 fits by L = 4 / 8 / 16 (scripts/gpu_lanes_fits.py): 1 chain 0.920 / 0.918 /
+  // 0.950 s, 2 chains 1.008 / 1.081 / 1.114, 3 chains 1.152 / 1.272 / 1.495, 4 chains (two groups) 1.256 / 1.281 / 1.358, 8 chains
+  // (three groups) 1.634 / 1.756 / 1.978. (Round 3 had measured the same 9 % at 8 chains and not taken them: two of 61 fits with
+  // L = 4 ended warm-up with a chain at tree depth 10, none of 233 with L = 8. Round 5 found where such chains come from --
+  // log(-sigma_slope) wandering through its flat tail during the one adaptation window, DESIGN.md section 4 -- and lanes per gene
+  // have no part in it beyond changing every chain's rounding, like a seed.)
+  int bestL = 64; double best = 1e300;
+  for (int L = 64; L >= 1; L >>= 1) {                      // (ties go to the larger L: shorter dependent chains per lane)
     const int gpw = 64 / L;
     // (L = 1, 2: a lane's four counts of a trip lie 4 L bytes apart, every request touches 64 / L times the lines: +20 %)
-    const double npass = ceil((double)G / gpw), c_pass = (5.8 + (double)((S + L - 1) / L)) * (L <= 2 ? 1.2 : 1.0);
+    const double npass = ceil((double)G / gpw), c_pass = (8.0 + (double)((S + L - 1) / L)) * (L <= 2 ? 1.2 : 1.0);
     const int wpc = 4 * workgroups_per_chain(m, L, nchains, resident_workgroups(m, 0));
     const double t = ceil(npass / wpc) * c_pass;           // passes of the busiest wavefront x pass cost
-    if (t < best_any) { best_any = t; bestL_any = L; }
-    if (npass * nchains >= 1.2 * slots && t < best) { best = t; bestL = L; }
+    if (t < best) { best = t; bestL = L; }
   }
-  if (best >= 1e300) bestL = bestL_any;         // a small model: no choice fills the chip
   const int L = m->L_override > 0 ? m->L_override : bestL;
   if (L != m->L) {
     std::lock_guard<std::mutex> lk(m->plan_mutex);
@@ -362,9 +370,6 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   if (G < 1 || S < 1 || C < 1 || K < 0 || K > G) return fail(PPCX_ERR_ARG, "need G>=1, S>=1, C>=1, 0<=K<=G");
   if (C > kMaxC) return fail(PPCX_ERR_LIMIT, "C exceeds the 8 design columns this build supports");
   if ((long long)G * S > 2000000000LL) return fail(PPCX_ERR_LIMIT, "G*S exceeds int32 cell ids");
-  // the log-likelihood kernel stages the log table and the per-sample constants (exp(exposure), exposure, X) in LDS
-  if (loglik_lds_bytes(S, C) > 160u * 1024u)
-    return fail(PPCX_ERR_LIMIT, "S * (2 + C) doubles of per-sample constants do not fit the 160 KB of LDS of a compute unit");
   if (!counts || !X || !exposure || (n_excl > 0 && !excl)) return fail(PPCX_ERR_ARG, "NULL input buffer");
   for (long long i = 0; i < (long long)G * S; ++i) if (counts[i] < 0) return fail(PPCX_ERR_ARG, "negative count");
   int ndev = 0;
@@ -396,6 +401,12 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   // the two tuning knobs of a fit's round structure, read from the environment HERE and nowhere else
   if (const char* e = getenv("PPCX_PIPELINE")) if (atoi(e) == 0) m->opt_pipelined = 0;
   if (const char* e = getenv("PPCX_STREAM_GROUPS")) { const int v = atoi(e); if (v >= 1) m->opt_stream_groups = v; }
+  // the log-likelihood kernel stages its tables (20 KB) and the per-sample constants in LDS: exp(exposure) and the design's slope
+  // columns -- S * C doubles; S * (2 + C) without the column of ones
+  if (loglik_lds_bytes(m->d) > 160u * 1024u) {
+    delete m;
+    return fail(PPCX_ERR_LIMIT, "the per-sample constants (S * C doubles; S * (2 + C) for a design without a column of ones) do not fit the 160 KB of LDS of a compute unit beside the 20 KB of tables");
+  }
   m->wgs_per_cu = loglik_resident_workgroups_per_cu(m->CM, m->d);      // of the instantiation this model runs
   if (m->wgs_per_cu < 1) { delete m; return fail(PPCX_ERR_LIMIT, "the log-likelihood kernel cannot be resident with S * (2 + C) doubles of per-sample constants in LDS"); }
   m->ls_wgs_per_cu = ls_resident_workgroups_per_cu(m->CM, m->d);
@@ -1227,7 +1238,7 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
   if (cfg->max_treedepth < 1 || cfg->max_treedepth > kMaxDepth) return fail(PPCX_ERR_LIMIT, "max_treedepth must be in 1..10");
   HIPCHK(hipSetDevice(m->device));
   const int nch = cfg->chains, D = m->d.D, iter = cfg->iter, n_keep = cfg->iter - cfg->warmup;
-  choose_launch(m, nch);
+  choose_launch(m, (xg && xg->nranks > 1) ? nch : fit_launch_chains(m, nch));   // (between ranks: one group, below)
   // Round structure. Pipelined (default where it applies): two launches per leapfrog, the state machine beside the
   // log-likelihood workgroups (ppcx_kernels.hip, "Pipelined rounds"). It needs a model whose cells read the anticipated
   // constants only (no per-cell linear predictor). The choice must not depend on the number of chains: the two round
@@ -1905,7 +1916,7 @@ static int nuts_over_devices(const int* devs, int ndev, int G, int S, int C, int
     ppcx_model* m = nullptr; ppcx_fit* f = nullptr;
     int rc = ppcx_model_create(devs[r], G, S, C, K, counts, X, exposure, lmm, n_excl, excl, &m);
     if (rc == PPCX_OK) {
-      choose_launch(m, chains);                  // the geometry of ONE fit of all the chains
+      choose_launch(m, fit_launch_chains(m, chains));   // the geometry of ONE fit of all the chains
       m->L_override = m->L;
       ppcx_nuts_config cfg = cfg0; cfg.chains = n; cfg.chain_id_offset = cfg0.chain_id_offset + c0;
       rc = ppcx_fit_nuts(m, &cfg, &f);

@@ -137,7 +137,7 @@ struct PpcArgs {
 
 hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, hipStream_t st);
 int loglik_resident_workgroups_per_cu(int CM, const Dims& d);   // 0: the kernel cannot be launched with this much LDS
-size_t loglik_lds_bytes(int S, int C);
+size_t loglik_lds_bytes(const Dims& d);
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st);
 // pipelined rounds: the merged launch (the state machines take position 7 of the first n_srun runs of 8 x chains
 // workgroups, log-likelihood range blocks everything else) and the gene kernel

@@ -203,8 +203,10 @@ __device__ __forceinline__ void loglik_role(const LoglikArgs& a, int jb, int col
   double* stab = lds;                          // log table: 256 x 1/c then 256 x log c (4 KB)
   double* swin = lds + 2 * kLogTabSize;        // window table: 1024 x 1/c then 1024 x log c (16 KB)
   double* sE = swin + 2 * kWinTabSize;         // exp(exposure_s), readable kLdsPad entries past S (sweep_cells)
-  double* sExpo = sE + S + kLdsPad;
-  double* sX = sExpo + S;                      // S x C column-major, readable kLdsPad entries past its end
+  // a design without the column of ones (GEN == 2) keeps the exposures and the whole of X; every other instantiation reads the
+  // columns 1 .. C - 1 only: column c at sX + c S, column 0 and the exposures are not staged (the space of column 0 is sE's)
+  double* sExpo = GEN == 2 ? sE + S + kLdsPad : nullptr;
+  double* sX = GEN == 2 ? sExpo + S : sE + kLdsPad;      // S x C column-major, readable kLdsPad entries past its end
   const VecRef v{a.vecs + (long)chain * V_COUNT * a.Dpad, a.Dpad};
   double* sums = a.sums + (long)chain * NS * d.G;
   // the fill: every workgroup of the launch reads the same few KB at the same time, so as few requests as possible -- 16 bytes
@@ -1400,7 +1402,14 @@ __global__ void ppcx_fill_kernel(double* p, long n, double val) {
 // -----------------------------------------------------------------------------------------------------
 // launch helpers (host)
 // -----------------------------------------------------------------------------------------------------
-size_t loglik_lds_bytes(int S, int C) { return sizeof(double) * (2 * kLogTabSize + 2 * kWinTabSize + (size_t)S * (2 + C) + 2 * kLdsPad); }
+static int loglik_generic_possible(const Dims& d) { return !d.x0_is_one ? 2 : ((d.C >= 2 && d.K > 0 && !d.x1_binary) ? 1 : 0); }
+// LDS of a log-likelihood workgroup: the two tables, exp(exposure_s), and the design columns its genes read -- columns 1 .. C - 1
+// where X[,1] == 1 (sweep_cells: S * C doubles in all; 8 960 samples fit at C = 2), the exposures and the whole of X for a design
+// without the column of ones (generic_cells: S * (2 + C))
+size_t loglik_lds_bytes(const Dims& d) {
+  const size_t per_sample = loglik_generic_possible(d) == 2 ? (size_t)(2 + d.C) : (size_t)(d.C < 1 ? 1 : d.C);
+  return sizeof(double) * (2 * kLogTabSize + 2 * kWinTabSize + (size_t)d.S * per_sample + 2 * kLdsPad);
+}
 // the instantiation a model runs: CM design columns (2, 4 or 8) and which route with an exp per cell its genes can need
 // (lane_gene_sums: 0 none, 1 slopes on columns of any values, 2 no column of ones)
 #define PPCX_BY_CM_GEN(KERNEL, CM, GEN, EXPR)                                                                     \
@@ -1414,10 +1423,9 @@ static const void* loglik_kernel_ptr(int CM, int gen) {
   PPCX_BY_CM_GEN(ppcx_loglik_kernel, CM, gen, f = (const void*)k_);
   return f;
 }
-static int loglik_generic_possible(const Dims& d) { return !d.x0_is_one ? 2 : ((d.C >= 2 && d.K > 0 && !d.x1_binary) ? 1 : 0); }
 int loglik_resident_workgroups_per_cu(int CM, const Dims& d) {
   int n = 0;
-  const size_t lds_bytes = loglik_lds_bytes(d.S, d.C);
+  const size_t lds_bytes = loglik_lds_bytes(d);
   const int gen = loglik_generic_possible(d);
   const void* f = loglik_kernel_ptr(CM, gen);
   if (lds_bytes > 64u * 1024u) {               // more than the default limit of dynamic LDS: ask for it once
@@ -1429,7 +1437,7 @@ int loglik_resident_workgroups_per_cu(int CM, const Dims& d) {
   return n;
 }
 hipError_t launch_loglik_kernel(int CM, const LoglikArgs& a, hipStream_t st) {
-  const size_t lds_bytes = loglik_lds_bytes(a.d.S, a.d.C);
+  const size_t lds_bytes = loglik_lds_bytes(a.d);
   const dim3 grid((unsigned)((a.nbpc + 7) / 8 * 8) * (unsigned)a.nchains);
   LoglikArgs args = a;
   void* params[] = {&args};
@@ -1447,10 +1455,10 @@ static const void* ls_kernel_ptr(int CM, int gen) {
   PPCX_BY_CM_GEN(ppcx_ls_kernel, CM, gen, f = (const void*)k_);
   return f;
 }
-static size_t ls_lds_bytes(int S, int C) { const size_t a = loglik_lds_bytes(S, C); return a > sizeof(StepShared) ? a : sizeof(StepShared); }
+static size_t ls_lds_bytes(const Dims& d) { const size_t a = loglik_lds_bytes(d); return a > sizeof(StepShared) ? a : sizeof(StepShared); }
 int ls_resident_workgroups_per_cu(int CM, const Dims& d) {
   int n = 0;
-  const size_t lds_bytes = ls_lds_bytes(d.S, d.C);
+  const size_t lds_bytes = ls_lds_bytes(d);
   const int gen = loglik_generic_possible(d);
   if (lds_bytes > 64u * 1024u) {
     if (hipFuncSetAttribute(ls_kernel_ptr(CM, gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -1461,7 +1469,7 @@ int ls_resident_workgroups_per_cu(int CM, const Dims& d) {
   return n;
 }
 hipError_t launch_ls_kernel(int CM, const LoglikArgs& a, const StepArgs& sa, int n_srun, int n_chains_total, int spec, hipStream_t st) {
-  const size_t lds_bytes = ls_lds_bytes(a.d.S, a.d.C);
+  const size_t lds_bytes = ls_lds_bytes(a.d);
   // runs: the first n_srun hold 7 range blocks (and a state machine) per chain, the others 8
   int runs = n_srun;
   if (a.nbpc > 7 * n_srun) runs += (a.nbpc - 7 * n_srun + 7) / 8;

@@ -982,3 +982,57 @@ def test_posterior_and_intervals_match_cpu_path_within_monte_carlo_error(L, orac
     for (gi, si) in d["injected"]:
         if flag_c[gi, si]:
             assert flag_g[gi, si]
+
+
+@pytest.mark.parametrize("C", [2, 3])
+def test_thousands_of_samples_in_the_lds_layout(L, oracle, C):
+    """The reference has no limit on the number of samples (inst/stan/negBinomial_MPI.stan:142-173). A log-likelihood workgroup
+    stages exp(exposure) and the design's slope columns in LDS -- S * C doubles beside 20 KB of tables since round 5 (S * (2 + C)
+    before: 5 300 samples at C = 2) -- so 8 000 samples of a two-group design and 5 000 of a three-column one still run, with one
+    or two workgroups resident per compute unit; beyond the 160 KB the model is refused with a status, not a fault."""
+    S = 8000 if C == 2 else 5000
+    G, K = 24, 5
+    d = ind.synth(G, S, K=K, seed=41, C=C)
+    rng = np.random.default_rng(41)
+    u = rng.uniform(-1, 1, (2, oracle.dim(G, C, K)))
+    u[:, 3:3 + G] += 5
+    excl = np.array([3, S + 7, 5 * S - 1], dtype=np.int32)
+    mo = oracle.model(d["counts"], d["X"], d["exposure"], K, excl=excl)
+    m = L.Model(d["counts"], d["X"], d["exposure"], K, excl=excl)
+    try:
+        for lanes in (0, 8, 64):
+            m.set_launch(lanes, 0)
+            lp, g = m.log_prob_grad(u)
+            for i in range(2):
+                lpo, go = oracle.log_prob_grad(mo, u[i])
+                assert abs(lp[i] - lpo) <= 1e-11 * max(1.0, abs(lpo)), (lanes, lp[i], lpo)
+                assert np.max(np.abs(g[i] - go) / (1 + np.abs(go))) <= 1e-10, lanes
+        f = m.fit_nuts(chains=2, iter=12, warmup=8, seed=3)              # the merged launch of a pipelined round with that much LDS
+        assert np.isfinite(f.diagnostics()["lp"]).all()
+        f.close()
+    finally:
+        m.close()
+    big = ind.synth(4, 11000, K=1, seed=2, C=2)
+    with pytest.raises(L.PpcxError, match="ppcx error -6"):              # PPCX_ERR_LIMIT
+        L.Model(big["counts"], big["X"], big["exposure"], 1)
+
+
+def test_adapted_inverse_metric_is_reported(L):
+    """ppcx_fit_get_inv_metric: the diagonal inverse metric a chain ended warm-up with (rstan::get_adaptation_info) -- Stan's
+    regularised variance of the draws of the slow window ((n / (n + 5)) var + 1e-3 * 5 / (n + 5)), so every entry is at least the
+    regulariser's floor; ones without a warm-up."""
+    d = ind.synth(60, 10, K=6, seed=9)
+    m = L.Model(d["counts"], d["X"], d["exposure"], 6)
+    try:
+        f = m.fit_nuts(chains=3, iter=170, warmup=150, seed=4)
+        im = f.inv_metric()
+        assert im.shape == (3, m.D) and np.isfinite(im).all()
+        n = 25.0
+        assert (im >= 1e-3 * 5 / (n + 5) * (1 - 1e-12)).all() and (im != 1.0).all()
+        assert len({tuple(r) for r in im.round(12).tolist()}) == 3        # every chain its own
+        f.close()
+        f = m.fit_nuts(chains=2, iter=12, warmup=0, seed=4)              # no warm-up: the unit metric
+        assert np.array_equal(f.inv_metric(), np.ones((2, m.D)))
+        f.close()
+    finally:
+        m.close()
