@@ -30,7 +30,7 @@ struct FastModel {
 extern "C" __attribute__((visibility("default")))
 void* ppcf_model_create(int G, int S, int C, int K, const int32_t* counts, const double* X, const double* expo, double lmm) {
   FastModel* m = new FastModel();
-  m->d = make_dims(G, S, C, K, lmm); m->CM = C <= 2 ? 2 : (C <= 4 ? 4 : 8);
+  m->d = make_dims(G, S, C, K, lmm); m->CM = C <= 2 ? 2 : (C <= 4 ? 4 : (C <= 8 ? 8 : 16));
   m->counts.assign(counts, counts + (size_t)G * S); m->counts.resize((size_t)G * S + 64, 0);
   m->X.assign(X, X + (size_t)S * C); m->X.resize((size_t)S * C + 64, 0.0); m->expo.assign(expo, expo + S); m->E.assign(S + 64, 0.0);
   int x0 = 1;
@@ -102,7 +102,8 @@ double ppcf_log_prob_grad(void* h, const double* u, double* grad, int threads) {
   if (threads < 1) threads = 1;
   if (m.CM == 2) return eval<2>(m, u, grad, threads);
   if (m.CM == 4) return eval<4>(m, u, grad, threads);
-  return eval<8>(m, u, grad, threads);
+  if (m.CM == 8) return eval<8>(m, u, grad, threads);
+  return eval<16>(m, u, grad, threads);
 }
 
 // The same evaluation as a callback fn(ctx, u, grad) for the oracle's NUTS driver (ppco_nuts_chain_fn): ctx is the model,

@@ -65,7 +65,33 @@ def build_testing(force: bool = False, verbose: bool = False) -> str:
     return TESTING_LIB
 
 
+def build_all(force: bool = False, verbose: bool = False):
+    """The product and the testing build side by side (four hipcc processes: the kernels' translation unit takes minutes)."""
+    import threading
+    jobs = []
+    if force or _stale(LIB):
+        jobs.append((LIB, []))
+    if force or _stale(TESTING_LIB):
+        jobs.append((TESTING_LIB, ["-DPPCX_TESTING"]))
+    errs = []
+
+    def run(lib, extra):
+        try:
+            _compile(lib, extra, verbose)
+        except Exception as e:                   # noqa: BLE001 -- reported below
+            errs.append(e)
+    th = [threading.Thread(target=run, args=j) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    return LIB, TESTING_LIB
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
     if "--testing" in sys.argv:
-        print(build_testing(force="--force" in sys.argv, verbose=True))
+        print(*build_all(force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -368,7 +368,7 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   if (!out) return fail(PPCX_ERR_ARG, "out is NULL");
   *out = nullptr;
   if (G < 1 || S < 1 || C < 1 || K < 0 || K > G) return fail(PPCX_ERR_ARG, "need G>=1, S>=1, C>=1, 0<=K<=G");
-  if (C > kMaxC) return fail(PPCX_ERR_LIMIT, "C exceeds the 8 design columns this build supports");
+  if (C > kMaxC) return fail(PPCX_ERR_LIMIT, "C exceeds the 16 design columns this build supports");
   if ((long long)G * S > 2000000000LL) return fail(PPCX_ERR_LIMIT, "G*S exceeds int32 cell ids");
   if (!counts || !X || !exposure || (n_excl > 0 && !excl)) return fail(PPCX_ERR_ARG, "NULL input buffer");
   for (long long i = 0; i < (long long)G * S; ++i) if (counts[i] < 0) return fail(PPCX_ERR_ARG, "negative count");
@@ -379,7 +379,7 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
   ppcx_model* m = new ppcx_model();
   m->device = device;
   m->d = make_dims(G, S, C, K, lambda_mu_mu);
-  m->CM = C <= 2 ? 2 : (C <= 4 ? 4 : 8);
+  m->CM = C <= 2 ? 2 : (C <= 4 ? 4 : (C <= 8 ? 8 : 16));
   {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -398,6 +398,13 @@ extern "C" int ppcx_model_create(int device, int G, int S, int C, int K, const i
 #endif
   m->d.x1_binary = x1b;
   m->d.raw_consts = (!x0 || (C >= 2 && K > 0 && !x1b)) ? 1 : 0;
+  // more than 8 design columns: the instantiation for factor designs only (a twelve-level factor, `~ a + b + c` of factors:
+  // model.matrix columns that are all indicators, R/utilities.R:887-900); a continuous covariate among more than 8 columns,
+  // or such a design without the column of ones, has no instantiation in this build
+  if (C > 8 && (!x0 || (K > 0 && !x1b))) {
+    delete m;
+    return fail(PPCX_ERR_LIMIT, "more than 8 design columns are supported for designs of a column of ones and 0 / 1 indicator columns only");
+  }
   // the two tuning knobs of a fit's round structure, read from the environment HERE and nowhere else
   if (const char* e = getenv("PPCX_PIPELINE")) if (atoi(e) == 0) m->opt_pipelined = 0;
   if (const char* e = getenv("PPCX_STREAM_GROUPS")) { const int v = atoi(e); if (v >= 1) m->opt_stream_groups = v; }

@@ -1416,7 +1416,8 @@ size_t loglik_lds_bytes(const Dims& d) {
   do {                                                                                                            \
     if ((CM) <= 2) { if ((GEN) == 0) { auto k_ = KERNEL<2, 0>; EXPR; } else if ((GEN) == 1) { auto k_ = KERNEL<2, 1>; EXPR; } else { auto k_ = KERNEL<2, 2>; EXPR; } } \
     else if ((CM) <= 4) { if ((GEN) == 0) { auto k_ = KERNEL<4, 0>; EXPR; } else if ((GEN) == 1) { auto k_ = KERNEL<4, 1>; EXPR; } else { auto k_ = KERNEL<4, 2>; EXPR; } } \
-    else { if ((GEN) == 0) { auto k_ = KERNEL<8, 0>; EXPR; } else if ((GEN) == 1) { auto k_ = KERNEL<8, 1>; EXPR; } else { auto k_ = KERNEL<8, 2>; EXPR; } } \
+    else if ((CM) <= 8) { if ((GEN) == 0) { auto k_ = KERNEL<8, 0>; EXPR; } else if ((GEN) == 1) { auto k_ = KERNEL<8, 1>; EXPR; } else { auto k_ = KERNEL<8, 2>; EXPR; } } \
+    else { auto k_ = KERNEL<16, 0>; EXPR; }   /* 9 .. 16 columns: indicator designs only (ppcx_model_create refuses the others) */ \
   } while (0)
 static const void* loglik_kernel_ptr(int CM, int gen) {
   const void* f = nullptr;
@@ -1447,7 +1448,8 @@ hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int ncha
   const dim3 grid(nblocks, nchains);
   if (CM <= 2) hipLaunchKernelGGL((ppcx_close_kernel<2>), grid, dim3(256), 0, st, a);
   else if (CM <= 4) hipLaunchKernelGGL((ppcx_close_kernel<4>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((ppcx_close_kernel<8>), grid, dim3(256), 0, st, a);
+  else if (CM <= 8) hipLaunchKernelGGL((ppcx_close_kernel<8>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((ppcx_close_kernel<16>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 static const void* ls_kernel_ptr(int CM, int gen) {
@@ -1482,7 +1484,8 @@ hipError_t launch_gene_kernel(int CM, const GeneArgs& a, int nblocks, int nchain
   const dim3 grid(nblocks, nchains);
   if (CM <= 2) hipLaunchKernelGGL((ppcx_gene_kernel<2>), grid, dim3(256), 0, st, a);
   else if (CM <= 4) hipLaunchKernelGGL((ppcx_gene_kernel<4>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((ppcx_gene_kernel<8>), grid, dim3(256), 0, st, a);
+  else if (CM <= 8) hipLaunchKernelGGL((ppcx_gene_kernel<8>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((ppcx_gene_kernel<16>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_step_kernel(const StepArgs& a, int nblocks, int nchains, hipStream_t st) {

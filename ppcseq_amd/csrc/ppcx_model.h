@@ -32,7 +32,7 @@
 
 namespace ppcx {
 
-constexpr int kMaxC = 8;        // design-matrix columns supported by the kernels
+constexpr int kMaxC = 16;       // design-matrix columns supported by the kernels (instantiations for up to 2, 4, 8 and 16)
 
 struct Dims {
   int G, S, C, K, D;

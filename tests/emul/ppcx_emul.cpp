@@ -21,7 +21,7 @@ struct EmulModel {
 
 static EmulModel make_model(int G, int S, int C, int K, const int32_t* counts, const double* X, const double* expo,
                             double lmm, int n_excl, const int32_t* excl) {
-  EmulModel m; m.d = make_dims(G, S, C, K, lmm); m.CM = C <= 2 ? 2 : (C <= 4 ? 4 : 8);
+  EmulModel m; m.d = make_dims(G, S, C, K, lmm); m.CM = C <= 2 ? 2 : (C <= 4 ? 4 : (C <= 8 ? 8 : 16));
   m.counts.assign(counts, counts + (size_t)G * S);
   m.counts.resize((size_t)G * S + 64, 0);      // the row sweep requests counts up to two trips of 4 lanes past the end
   for (int e = 0; e < n_excl; ++e) m.counts[excl[e]] = -1;
@@ -75,7 +75,8 @@ static void gene_pass(const EmulModel& m, const Cmd& c, const VecRef& v, double*
 static void gene_pass_dispatch(const EmulModel& m, const Cmd& c, const VecRef& v, double* red) {
   if (m.CM == 2) gene_pass<2>(m, c, v, red);
   else if (m.CM == 4) gene_pass<4>(m, c, v, red);
-  else gene_pass<8>(m, c, v, red);
+  else if (m.CM == 8) gene_pass<8>(m, c, v, red);
+  else gene_pass<16>(m, c, v, red);
 }
 // kernel B: state machine, then the per-coordinate operations of the new command; returns T0 of the gene coordinates
 static double update_pass(const EmulModel& m, ChainState& st, const Cmd& ex, const double* red, double T0_prev,
@@ -242,7 +243,8 @@ int emul_fit_nuts_pipelined(int G, int S, int C, int K, const int32_t* counts, c
     int r;
     if (m.CM == 2) r = pipelined_chain<2>(m, nc, ch, io, spec != 0, ls_first_s != 0, rounds + ch, carried + ch);
     else if (m.CM == 4) r = pipelined_chain<4>(m, nc, ch, io, spec != 0, ls_first_s != 0, rounds + ch, carried + ch);
-    else r = pipelined_chain<8>(m, nc, ch, io, spec != 0, ls_first_s != 0, rounds + ch, carried + ch);
+    else if (m.CM == 8) r = pipelined_chain<8>(m, nc, ch, io, spec != 0, ls_first_s != 0, rounds + ch, carried + ch);
+    else r = pipelined_chain<16>(m, nc, ch, io, spec != 0, ls_first_s != 0, rounds + ch, carried + ch);
     if (r != 0) rc = r;
   }
   return rc;

@@ -27,7 +27,8 @@ def test_density_and_gradient(oracle, emul, G, S, C, K, seed):
     assert np.max(np.abs(g - g2) / (1 + np.abs(g))) < 1e-10
 
 
-@pytest.mark.parametrize("levels,G,S,K,seed", [((3,), 30, 14, 6, 1), ((2, 2), 24, 11, 24, 2), ((4,), 18, 9, 5, 3), ((3, 2), 20, 13, 7, 4)])
+@pytest.mark.parametrize("levels,G,S,K,seed", [((3,), 30, 14, 6, 1), ((2, 2), 24, 11, 24, 2), ((4,), 18, 9, 5, 3), ((3, 2), 20, 13, 7, 4),
+                                               ((12,), 26, 40, 7, 5)])
 def test_factor_designs_take_the_factorised_cells(oracle, emul, levels, G, S, K, seed):
     """Designs whose slope columns are all 0 / 1 indicators -- a multi-level factor, `~ a + b` of factors (model.matrix,
     R/utilities.R:887-900) -- with C = 3, 3 and 4, 4: e^t = E_s A_g prod exp(slope_c), no exp per cell (ppcx_gene.h

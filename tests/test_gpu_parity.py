@@ -90,10 +90,12 @@ def test_continuous_covariate_and_two_group_designs(L, oracle):
         assert np.max(np.abs(res[0] - res[1]) / np.abs(res[0])) < 1e-13
 
 
-@pytest.mark.parametrize("levels,G,S,K,seed", [((3,), 70, 19, 9, 1), ((2, 2), 40, 21, 40, 2), ((4,), 33, 200, 6, 3), ((3, 2), 300, 50, 15, 4)])
+@pytest.mark.parametrize("levels,G,S,K,seed", [((3,), 70, 19, 9, 1), ((2, 2), 40, 21, 40, 2), ((4,), 33, 200, 6, 3), ((3, 2), 300, 50, 15, 4),
+                                               ((12,), 60, 48, 9, 5), ((5, 4), 45, 40, 11, 6)])
 def test_factor_designs_factorise_and_pipeline(L, oracle, levels, G, S, K, seed):
     """Designs beyond two groups whose slope columns are all indicators -- model.matrix of a multi-level factor or of
-    `~ a + b` (R/utilities.R:887-900): C = 3 and 4. The checked genes' cells use E_s A_g prod exp(slope_c) (no exp per cell:
+    `~ a + b` (R/utilities.R:887-900): C = 3 and 4; a twelve-level factor (C = 12: the instantiation for up to 16 columns -- the
+    reference has no limit, inst/stan/negBinomial_MPI.stan:160,189-190) and C = 8. The checked genes' cells use E_s A_g prod exp(slope_c) (no exp per cell:
     ppcx_gene.h indicator_cells), the model runs pipelined rounds, and both round structures follow the oracle's sampler."""
     d = ind.synth_factor(G, S, K, levels, seed)
     counts = d["counts"].copy()
@@ -130,6 +132,8 @@ def test_factor_designs_factorise_and_pipeline(L, oracle, levels, G, S, K, seed)
     # cell (an exp each) from the coefficients kept among the coordinates' constants, and the model pipelines like every other
     # (round 5; before, it ran the three-launch round): density and gradient against the oracle, both round structures on the
     # oracle's sampler
+    if C > 8:                                   # (more than 8 columns: indicator designs only, test_more_than_eight_columns_...)
+        return
     Xc = d["X"].copy()
     Xc[:, -1] = np.linspace(-1, 1, S)
     moc = oracle.model(counts, Xc, d["exposure"], K, excl=excl)
@@ -1036,3 +1040,16 @@ def test_adapted_inverse_metric_is_reported(L):
         f.close()
     finally:
         m.close()
+
+
+def test_more_than_eight_columns_only_for_indicator_designs(L):
+    """More than 8 design columns run the instantiation for factor designs; a continuous covariate among them is refused with a
+    status (PPCX_ERR_LIMIT), as are more than 16 columns."""
+    d = ind.synth_factor(20, 30, 4, (10,), 1)
+    X = d["X"].copy()
+    X[:, 3] = np.linspace(-1, 1, 30)
+    with pytest.raises(L.PpcxError, match="ppcx error -6"):
+        L.Model(d["counts"], X, d["exposure"], 4)
+    d17 = ind.synth_factor(20, 40, 4, (17,), 1)
+    with pytest.raises(L.PpcxError, match="ppcx error -6"):
+        L.Model(d17["counts"], d17["X"], d17["exposure"], 4)
