@@ -484,10 +484,11 @@ def test_launch_plan_invariants(L, G, S, K):
         m.close()
 
 
-def test_lanes_per_gene_leave_no_wavefront_slot_without_a_pass(L):
-    """The automatic lanes per gene at cfg3 size for 1..8 chains: every choice hands out at least 1.2 passes per wavefront
-    slot of the chip (4 x 4 x 256), none is below 4 lanes (whose requests touch 16+ times the cache lines), and the choices are
-    the ones measured fastest per number of chains (16, 16, 8, 8, 4, 4, 8, 8)."""
+def test_lanes_per_gene_are_chosen_for_the_chains_of_a_launch(L):
+    """The automatic lanes per gene at cfg3 size for launches of 1..8 chains (round 5: passes of the busiest wavefront x (8 + cell
+    iterations of a lane), ppcx_capi.hip choose_launch): none below 4 lanes (whose requests touch 16+ times the cache lines), and the
+    choices measured fastest per number of chains (kernel level: 1 chain L = 8, 2 and 3 chains L = 4, 8 chains L = 8). A fit chooses
+    for the chains of ONE launch -- its chain groups' (three groups from eight chains on) -- not for all of its chains."""
     G, S = CONFIGS["cfg3"][0], CONFIGS["cfg3"][1]
     d = ind.synth(G, S, seed=CONFIGS["cfg3"][2])
     m = L.Model(d["counts"], d["X"], d["exposure"], d["K"])
@@ -496,10 +497,16 @@ def test_lanes_per_gene_leave_no_wavefront_slot_without_a_pass(L):
         for nch in range(1, 9):
             lanes, nb, b = m.get_plan(nch)
             chosen.append(lanes)
-            npass = -(-G // (64 // lanes))
-            assert lanes >= 4 and npass * nch >= 1.2 * 4 * 4 * 256, (nch, lanes)
-            assert nb * nch <= 4 * 256
-        assert chosen == [16, 16, 8, 8, 4, 4, 8, 8], chosen
+            assert lanes >= 4 and nb * nch <= 4 * 256, (nch, lanes, nb)
+        assert chosen == [8, 4, 4, 8, 4, 4, 8, 8], chosen
+        kw = dict(iter=3, warmup=2, seed=1)
+        m.fit_nuts(chains=8, **kw).close()                               # groups of 3, 3 and 2 chains
+        assert m.get_launch()[0] == 4
+        m.fit_nuts(chains=1, **kw).close()
+        assert m.get_launch()[0] == 8
+        m.set_rounds(stream_groups=1)                                    # all eight chains in every launch
+        m.fit_nuts(chains=8, **kw).close()
+        assert m.get_launch()[0] == 8
     finally:
         m.close()
 

@@ -557,7 +557,7 @@ def _check_readme_result(res):
         bad = sw[sw["deleterious_outliers"]]
         assert len(bad) == 1
         y, lo, up = float(bad["value"].iloc[0]), float(bad[".lower"].iloc[0]), float(bad[".upper"].iloc[0])
-        assert (y > up and y < 2 * up) or (y < lo and 2 * y + 1 >= lo), (g, y, lo, up)
+        assert (y > up and y < 1.5 * up) or (y < lo and y + 1 >= lo), (g, y, lo, up)
     return extras
 
 

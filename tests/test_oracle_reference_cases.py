@@ -115,7 +115,8 @@ def check_readme_calls(names, counts, samples, r2):
         assert tot[i] == 1
         s = int(np.flatnonzero(r2.deleterious_outliers[i])[0])
         y, lo, up = float(counts[i, s]), float(r2.lower[i, s]), float(r2.upper[i, s])
-        assert (y > up and y < 2 * up) or (y < lo and 2 * y + 1 >= lo), (g, y, lo, up)      # just outside the interval
+        assert (y > up and y < 1.5 * up) or (y < lo and y + 1 >= lo), (g, y, lo, up)      # just outside the interval: profiles/r05_readme_margins.json --
+        # MMP8's 219 against an upper end of 163-255 over seeds and modes, CCNA1's 0 against a lower end of 0 or 1
     return extras
 
 
