@@ -535,7 +535,11 @@ def test_extreme_sample_counts(L, oracle, G, S, C, K):
 
 
 def test_too_many_samples_for_lds_is_refused(L):
+    """S * C doubles of per-sample constants beside 20 KB of tables (round 5; S * (2 + C) before): 5 300 samples of a two-group
+    design now run (tests/test_gpu_parity.py goes to 8 000), 9 500 do not fit the 160 KB and are refused with a status."""
     d = ind.synth(4, 5300, K=0, seed=2)
+    L.Model(d["counts"], d["X"], d["exposure"], 0).close()
+    d = ind.synth(4, 9500, K=0, seed=2)
     with pytest.raises(L.PpcxError, match="LDS"):
         L.Model(d["counts"], d["X"], d["exposure"], 0)
 

@@ -282,7 +282,7 @@ def test_error_reporting(L):
     with pytest.raises(L.PpcxError):
         L.Model(np.zeros((3, 4), np.int32) - 1, np.ones((4, 1)), np.zeros(4), 0)      # negative count
     with pytest.raises(L.PpcxError):
-        L.Model(np.ones((3, 4), np.int32), np.ones((4, 9)), np.zeros(4), 0)           # C > 8
+        L.Model(np.ones((3, 4), np.int32), np.ones((4, 17)), np.zeros(4), 0)          # C > 16
     m = L.Model(np.ones((3, 4), np.int32), np.ones((4, 1)), np.zeros(4), 1)
     try:
         with pytest.raises(L.PpcxError):
