@@ -1036,6 +1036,18 @@ extern "C" int ppcx_testing_set_nccl_provider(const char* path) {
 // Kernel-level timing: mean duration (ms) of `reps` back-to-back launches of one kernel (`which`, ppcx_testing.h) of the
 // three-launch round on the command the chains hold after `warm_rounds` rounds of a real run. n_merge >= 0 overrides the
 // tree position of that command (number of subtree merges the leaf closes), so every variant is timed on the same work.
+static std::mutex g_sm_mutex; static long long g_sm_ticks[6] = {0, 0, 0, 0, 0, 0}; static long long g_sm_rounds = 0;
+// mean microseconds per round a chain's state machine (the workgroup beside the log-likelihood workgroups of a pipelined round)
+// spent in its phases, over the fits since the last call: [0] until state, command, hyper vectors and slab have arrived,
+// [1] folding the slab and staging in LDS, [2] the exchange between ranks, [3] chain_step, [4] after it; out[5] = rounds counted
+extern "C" int ppcx_testing_sm_trace(double* out6) {
+  std::lock_guard<std::mutex> lk(g_sm_mutex);
+  for (int k = 0; k < 5; ++k) out6[k] = g_sm_rounds ? 1e-2 * (double)g_sm_ticks[k] / (double)g_sm_rounds : 0.0;
+  out6[5] = (double)g_sm_rounds;
+  for (int k = 0; k < 6; ++k) g_sm_ticks[k] = 0;
+  g_sm_rounds = 0;
+  return PPCX_OK;
+}
 extern "C" int ppcx_testing_bench_kernel(ppcx_model* m, int which, int nchains, int warm_rounds, int reps, int n_merge,
                                          double* ms_per_launch, int* cmd_type) {
   if (!m || nchains < 1 || reps < 1 || !ms_per_launch || which < 0 || which > PPCX_BENCH_GENE_NEW_TRANSITION) return fail(PPCX_ERR_ARG, "bad arguments");
@@ -1355,6 +1367,9 @@ static int fit_nuts_impl(ppcx_model* m, const ppcx_nuts_config* cfg, ppcx_xchg* 
       G->rc = PPCX_ERR_HIP; G->err = "reading back the chain states failed"; return;
     }
     for (int c = 0; c < G->n; ++c) { G->leap += states[c].sc.total_leapfrogs; G->xticks += states[c].xc.ticks; G->xcount += states[c].xc.count; }
+#ifdef PPCX_TESTING
+    { std::lock_guard<std::mutex> lk(g_sm_mutex); for (int c = 0; c < G->n; ++c) { for (int k = 0; k < 6; ++k) g_sm_ticks[k] += states[c].tr.t[k]; g_sm_rounds += states[c].tr.n; } }
+#endif
     // the adapted inverse metric (what rstan::get_adaptation_info prints): the genes' coordinates, then the six hyper-parameters
     std::vector<double> hq((size_t)G->n * V_COUNT * 8);
     bool ok = hipMemcpy(hq.data(), current_hyper(G->w), sizeof(double) * hq.size(), hipMemcpyDeviceToHost) == hipSuccess;

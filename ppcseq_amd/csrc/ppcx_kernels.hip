@@ -633,6 +633,13 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
   constexpr int NST = (int)(sizeof(ChainState) / sizeof(int)), NCMD = (int)(sizeof(Cmd) / sizeof(int)), NHV = V_COUNT * 8;
   static_assert(NST <= 4 * 256 && NCMD <= 256 && NHV <= 3 * 256 && PT_COUNT <= 96, "step role staging sizes");
   const int tid = threadIdx.x;
+#ifdef PPCX_TESTING
+  long long tr_t[7] = {0, 0, 0, 0, 0, 0, 0};
+#define PPCX_SM_STAMP(k) do { tr_t[k] = (long long)wall_clock64(); } while (0)
+#else
+#define PPCX_SM_STAMP(k) ((void)0)
+#endif
+  PPCX_SM_STAMP(0);
   const ChainState* st_in = a.states_in + chain;
   const bool done = st_in->sc.phase == PH_DONE;
   int r_st[4], r_cmd = 0; double r_hv[3];
@@ -661,6 +668,7 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
     const Cmd& exg = a.cmds_in[chain];
     const int np = (done || exg.type == CMD_DONE || exg.type == CMD_FLUSH) ? 0 : parts_used(exg);   // uniform
     s.sm[0][ch][c] = c < np ? s0 : 0.0; s.sm[1][ch][c] = c + 32 < np ? s1 : 0.0; s.sm[2][ch][c] = c + 64 < np ? s2 : 0.0;
+    PPCX_SM_STAMP(1);                          // the state, the command, the hyper vectors and the slab have arrived
     __syncthreads();
     if (tid < PT_COUNT) {
       double t = 0.0;
@@ -687,6 +695,7 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
     for (int k = 0; k < 3; ++k) if (tid + 256 * k < NHV) s.hv[tid + 256 * k] = r_hv[k];
   }
   __syncthreads();
+  PPCX_SM_STAMP(2);                            // sums folded, everything staged in LDS
   // gene shards, one per rank: the other ranks' sums. Every rank's copy of this chain reaches this point the same number of times.
   bool x_ok = true;
   const bool x_on = a.x.nranks > 1;
@@ -711,7 +720,9 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
     io.out.divergent = a.out_divergent ? a.out_divergent + (long)chain * a.iter : nullptr;
     io.out.accept = a.out_accept ? a.out_accept + (long)chain * a.iter : nullptr;
     Cmd nc;
+    PPCX_SM_STAMP(3);
     (void)chain_step_pipelined(WaveLanes{tid}, a.d, st, s.st.ta, s.ex, s.red, VecRef{s.hv, 8}, io, s.rd, nc, spec);
+    PPCX_SM_STAMP(4);
     if (tid == 0) {
       s.st.sc = st;
       s.nc = nc;
@@ -719,6 +730,14 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
     }
     }
   }
+#ifdef PPCX_TESTING
+  if (tid == 0) {                              // phases: loads + slab, fold + staging, (exchange), state machine, and the write-out of the previous round's
+    PPCX_SM_STAMP(5);
+    SmTrace& tr = s.st.tr;
+    tr.t[0] += tr_t[1] - tr_t[0]; tr.t[1] += tr_t[2] - tr_t[1]; tr.t[2] += tr_t[3] - tr_t[2]; tr.t[3] += tr_t[4] - tr_t[3]; tr.t[4] += tr_t[5] - tr_t[4];
+    tr.n += 1;
+  }
+#endif
   __syncthreads();
   double* hvo = a.hyper_out + (long)chain * NHV;
   for (int i = tid; i < NHV; i += 256) hvo[i] = s.hv[i];

@@ -303,7 +303,13 @@ struct XchgCount { unsigned count; unsigned pad_; long long ticks; };
 
 // per-level log weights / potentials of the parked left subtrees (indexed at run time: kept in LDS)
 struct TreeArrays { double Llsw[kLev + 1], LV[kLev + 1]; };
+#ifdef PPCX_TESTING
+// testing build: 100 MHz ticks the chain's state machine (step_role_pipelined) has spent in its phases, and the rounds counted
+struct SmTrace { long long t[6]; long long n; };
+struct ChainState { ChainScalars sc; TreeArrays ta; XchgCount xc; SmTrace tr; };
+#else
 struct ChainState { ChainScalars sc; TreeArrays ta; XchgCount xc; };
+#endif
 
 struct Reduced {
   double lp_genes, hsum[6], T0, T1, nonfinite;

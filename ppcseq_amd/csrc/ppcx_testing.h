@@ -27,6 +27,8 @@ enum { PPCX_BENCH_LOGLIK = 0, PPCX_BENCH_CLOSE = 1, PPCX_BENCH_LOGLIK_CLOSE = 2,
        PPCX_BENCH_GENE_NEW_TRANSITION = 12 };  /* the first leaf of a transition: fresh momenta for every coordinate */
 PPCX_API int ppcx_testing_bench_kernel(ppcx_model* m, int which, int nchains, int warm_rounds, int reps, int n_merge,
                                        double* ms_per_launch, int* cmd_type);
+/* mean microseconds per round of a chain's state machine by phase since the last call (ppcx_capi.hip) */
+PPCX_API int ppcx_testing_sm_trace(double* out6);
 #ifdef __cplusplus
 }
 #endif
