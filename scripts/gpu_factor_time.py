@@ -2,7 +2,7 @@
 R/utilities.R:887-900), K = 1000 checked genes. Times the log-likelihood launch (8 chains, kernel-level) and whole fits
 (8 chains, 150 + 250) on (a) the per-cell-exp path with the three-launch round -- what every C >= 3 design ran before round 4,
 forced here through the testing build -- and (b) the factorised indicator path with pipelined rounds (the product's choice),
-and the two-group design of cfg3 beside them. Writes profiles/r04_factor_design_c3.json (run on the GPU box)."""
+and the two-group design of cfg3 beside them. Writes gpurun_out/factor_design_c3.json (kept as profiles/rNN_factor_design_c3.json) (run on the GPU box)."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,4 +29,5 @@ for tag, d, force in (("c3_generic_three_launch", d3, 1), ("c3_indicator_pipelin
     print(tag, out[tag], flush=True)
     m.close()
 L.testing_set("force_generic", 0)
-json.dump(out, open(os.path.join(ROOT, "profiles", "r04_factor_design_c3.json"), "w"), indent=1)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "factor_design_c3.json"), "w"), indent=1)     # merged back by gpurun; copied to profiles/rNN_factor_design_c3.json
