@@ -701,12 +701,19 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
   const bool x_on = a.x.nranks > 1;
   if (x_on) x_ok = xchg_sums(a.x, chain, s.st.xc.count + 1u, s);
   if (tid < 8) {
-    ChainScalars st = s.st.sc;
+    // The chain's scalars and the new command stay where they are staged, in LDS (round 5; before, lane 0's register copy was
+    // written back after the step). Under the merged launch's 128-register bound that copy lived in scratch: copying it in and
+    // out and reloading spilled scalars cost 3-5 of the state machine's 12-16 us per round, which bounds the launches of one and
+    // two chains (profiles/r05_sm_phase_trace.txt). The eight lanes run the scalar logic redundantly on identical values, so
+    // their stores to the shared copy agree -- as they always have for the tree arrays beside it. Same arithmetic: with
+    // -ffp-contract=on the chains are bit for bit those of the register copy; with the default contraction the backend fuses
+    // multiply-adds across statements differently when an operand passes through LDS, and a chain's rounding changes like
+    // under another seed.
+    ChainScalars& st = s.st.sc;
     if (x_on && tid == 0) { s.st.xc.count += 1u; s.st.xc.ticks += s.x_wait; }
     if (!x_ok) {                               // a peer has left the fit or did not arrive: this chain ends with an error
       if (tid == 0) {
         st.error = 4; st.phase = PH_DONE;
-        s.st.sc = st;
         s.nc = s.ex; s.nc.type = CMD_DONE;
         a.done[chain] = 1 + st.error;
       }
@@ -719,15 +726,11 @@ __device__ __forceinline__ void step_role_pipelined(const StepArgs& a, int chain
     io.out.n_leapfrog = a.out_n_leapfrog ? a.out_n_leapfrog + (long)chain * a.iter : nullptr;
     io.out.divergent = a.out_divergent ? a.out_divergent + (long)chain * a.iter : nullptr;
     io.out.accept = a.out_accept ? a.out_accept + (long)chain * a.iter : nullptr;
-    Cmd nc;
+    Cmd& nc = s.nc;
     PPCX_SM_STAMP(3);
     (void)chain_step_pipelined(WaveLanes{tid}, a.d, st, s.st.ta, s.ex, s.red, VecRef{s.hv, 8}, io, s.rd, nc, spec);
     PPCX_SM_STAMP(4);
-    if (tid == 0) {
-      s.st.sc = st;
-      s.nc = nc;
-      if (st.phase == PH_DONE) a.done[chain] = 1 + st.error;
-    }
+    if (tid == 0 && st.phase == PH_DONE) a.done[chain] = 1 + st.error;
     }
   }
 #ifdef PPCX_TESTING
