@@ -685,7 +685,7 @@ static void close_args(ppcx_model* m, Work& w, CloseArgs* o);
 // pipelined round, first launch: the state machines that digest the previous gene kernel's sums beside the log-likelihood
 // workgroups of this round (the command buffer the log-likelihood part reads is the one the state machines read, not
 // the one they write)
-static int launch_ls(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
+static int launch_ls(ppcx_model* m, Work& w, int nchains, const RunIO& io, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   const int nact = w.n_active > 0 ? w.n_active : nchains;
   const int n_srun = step_runs(nchains, nact);
   LoglikArgs la;
@@ -693,7 +693,7 @@ static int launch_ls(ppcx_model* m, Work& w, int nchains, const RunIO& io) {
   if (rc != PPCX_OK) return rc;
   StepArgs sa;
   step_args(m, w, io, STEP_REDUCE | STEP_ADVANCE, false, &sa);
-  hipError_t e = launch_ls_kernel(m->CM, la, sa, n_srun, nchains, 1, w.stream);
+  hipError_t e = launch_ls_kernel(m->CM, la, sa, n_srun, nchains, 1, w.stream, ev_start, ev_stop);
   if (e != hipSuccess) return fail(PPCX_ERR_HIP, std::string("merged log-likelihood / step kernel: ") + hipGetErrorString(e));
   w.launches++;
   return PPCX_OK;
@@ -850,10 +850,12 @@ static int pump(std::vector<Shard>& sh, int nchains, ppcx_comm* comm, long long 
     bool sampled = false;
     for (int i = 0; i < batch; ++i, ++pairs) {
       const bool smp = time_kernels && !sampled && (pairs / batch) % sample_every == 0 && i == batch / 2 && local_rc == PPCX_OK;
-      if (smp) PUMP_HIP(hipEventRecord(ev0, st));
+      if (smp && !piped) PUMP_HIP(hipEventRecord(ev0, st));
       if (piped) {
-        PUMP_TRY(launch_ls(sh[0].m, w0, nchains, sh[0].io));
-        if (smp) { PUMP_HIP(hipEventRecord(ev1, st)); sampled = true; }
+        // a sampled merged launch carries its own start / stop events (hipExtLaunchKernel): the kernel's duration as the
+        // profiler's kernel trace sees it; a hipEventRecord on either side adds its marker packets (3-4 us on a 38 us launch)
+        PUMP_TRY(launch_ls(sh[0].m, w0, nchains, sh[0].io, smp ? ev0 : nullptr, smp ? ev1 : nullptr));
+        if (smp) sampled = true;
         PUMP_TRY(launch_gene_round(sh[0].m, w0, nchains, sh[0].io));
         if (smp) { PUMP_HIP(hipEventRecord(ev2, st)); PUMP_HIP(hipEventRecord(ev3, st)); }
         continue;

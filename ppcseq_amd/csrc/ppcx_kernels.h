@@ -141,7 +141,10 @@ size_t loglik_lds_bytes(const Dims& d);
 hipError_t launch_close_kernel(int CM, const CloseArgs& a, int nblocks, int nchains, hipStream_t st);
 // pipelined rounds: the merged launch (the state machines take position 7 of the first n_srun runs of 8 x chains
 // workgroups, log-likelihood range blocks everything else) and the gene kernel
-hipError_t launch_ls_kernel(int CM, const LoglikArgs& a, const StepArgs& sa, int n_srun, int n_chains_total, int spec, hipStream_t st);
+// ev_start / ev_stop (both or neither): events attached to the dispatch itself (hipExtLaunchKernel) -- their elapsed time is the
+// kernel's own duration, without the marker packets of a hipEventRecord on either side of the launch
+hipError_t launch_ls_kernel(int CM, const LoglikArgs& a, const StepArgs& sa, int n_srun, int n_chains_total, int spec, hipStream_t st,
+                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int ls_resident_workgroups_per_cu(int CM, const Dims& d);
 hipError_t launch_gene_kernel(int CM, const GeneArgs& a, int nblocks, int nchains, hipStream_t st);
 hipError_t launch_step_kernel(const StepArgs& a, int nblocks, int nchains, hipStream_t st);

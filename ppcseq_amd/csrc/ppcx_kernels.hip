@@ -19,6 +19,7 @@
 // Per-block partial sums of the close kernel go to a slab that the step kernel reduces in a fixed order, so results are
 // bitwise reproducible for a fixed number of lanes per gene.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "ppcx_gene.h"
 #include "ppcx_kernels.h"
 
@@ -1492,7 +1493,8 @@ int ls_resident_workgroups_per_cu(int CM, const Dims& d) {
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
 }
-hipError_t launch_ls_kernel(int CM, const LoglikArgs& a, const StepArgs& sa, int n_srun, int n_chains_total, int spec, hipStream_t st) {
+hipError_t launch_ls_kernel(int CM, const LoglikArgs& a, const StepArgs& sa, int n_srun, int n_chains_total, int spec, hipStream_t st,
+                            hipEvent_t ev_start, hipEvent_t ev_stop) {
   const size_t lds_bytes = ls_lds_bytes(a.d);
   // runs: the first n_srun hold 7 range blocks (and a state machine) per chain, the others 8
   int runs = n_srun;
@@ -1500,6 +1502,8 @@ hipError_t launch_ls_kernel(int CM, const LoglikArgs& a, const StepArgs& sa, int
   const dim3 grid((unsigned)runs * 8u * (unsigned)a.nchains);
   LoglikArgs args = a; StepArgs sargs = sa;
   void* params[] = {&args, &sargs, &n_srun, &n_chains_total, &spec};
+  if (ev_start && ev_stop)
+    return hipExtLaunchKernel(ls_kernel_ptr(CM, loglik_generic_possible(a.d)), grid, dim3(256), params, lds_bytes, st, ev_start, ev_stop, 0);
   return hipLaunchKernel(ls_kernel_ptr(CM, loglik_generic_possible(a.d)), grid, dim3(256), params, lds_bytes, st);
 }
 hipError_t launch_gene_kernel(int CM, const GeneArgs& a, int nblocks, int nchains, hipStream_t st) {

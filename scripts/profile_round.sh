@@ -13,6 +13,19 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --as-named-steps 0 --stream-groups 1 --single-stream-steps 1 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || true
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv || true
+# the merged launch's durations in that trace: the statistics' mean contains the partly empty launches after chains have finished; the
+# median is a launch with every chain active -- what bench.py's roofline sample (events attached to such dispatches) must agree with
+python3 - $OUT <<'PY' || true
+import csv, glob, json, sys
+import numpy as np
+out = sys.argv[1]
+f = glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True)[0]
+d = np.array([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if "ppcx_ls_kernel" in r["Kernel_Name"]], float) * 1e-3
+bench = json.load(open(out + "/bench_under_rocprof.json"))
+json.dump({"kernel": "ppcx_ls_kernel", "dispatches": int(d.size), "mean_us": round(float(d.mean()), 2), "median_us": round(float(np.median(d)), 2),
+           "p25_us": round(float(np.percentile(d, 25)), 2), "p75_us": round(float(np.percentile(d, 75)), 2),
+           "bench_roofline_avg_launch_us_same_run": round(1e3 * bench["roofline"]["avg_launch_ms"], 2)}, open(out + "/ls_kernel_durations.json", "w"), indent=1)
+PY
 rm -rf $OUT/trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --as-named-steps 0 --single-stream-steps 0 --no-ppc > $OUT/bench_default_groups_under_rocprof.json 2> $OUT/trace2.err || true
 find $OUT/trace2 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_default_groups.csv || true
