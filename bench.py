@@ -8,7 +8,8 @@ HBM. `value` = sum over steps of the pooled bulk-ESS (min over the six hyper-par
 by the summed wall time (barrier + device synchronise on both sides, max over ranks). Chains are the
 sharded unit (weak scaling: chains/GPU fixed); there is no collective on the data path. The timed fits run the
 library's defaults (pipelined rounds, three chain groups on their own streams); the `roofline` sample comes from one
-more fit on a single in-order stream, where HIP events around a launch time that launch alone.
+more fit on a single in-order stream, from HIP events attached to the merged launch's dispatches (hipExtLaunchKernel: the
+kernel's own duration, as a kernel trace sees it).
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -228,8 +229,8 @@ def main():
         as_named = {"chains_per_gpu": 1, "chains_total": world, "value": round(ess_an / t_an, 3), "unit": "ESS/s",
                     "ms_per_step": round(1e3 * t_an / args.as_named_steps, 2), "steps": args.as_named_steps}
 
-    # The same fit on ONE in-order stream: HIP events around a launch then time that launch alone, which is what the
-    # roofline object needs (with chain groups on several streams another group's kernels run inside the bracket).
+    # The same fit on ONE in-order stream: the merged launch's own start / stop events then time that launch alone, which is what
+    # the roofline object needs (with chain groups on several streams another group's kernels share the chip with it).
     single = None
     if args.mode == "chains" and args.single_stream_steps > 0:
         model.set_rounds(stream_groups=1)
@@ -279,6 +280,7 @@ def main():
                     "from_committed_profiles": {"traffic": "profiles/rNN_pmc.json (rocprofv3 --pmc passes of the same command: counters need their own runs)",
                                                 "fp64_issue": "profiles/rNN_loglik_issue.json (SQ counters; `stale` says whether the kernel sources have changed since)"},
                     "sampled_in": "a fit on one in-order stream (stream_groups = 1) after the timed fits" if args.mode == "chains" else "the timed fits",
+                    "timed_by": "HIP events attached to the dispatch of sampled launches with every chain active (hipExtLaunchKernel start / stop events)",
                     "note": "achieved = algorithmic bytes (SURVEY 8d: count matrix + coordinates, per chain gradient) x chains per "
                             "launch / launch time: an effective-throughput figure. ppcx_ls_kernel is the merged launch of a "
                             "pipelined round: the log-likelihood workgroups of every chain beside the chains' state machines. "
