@@ -2,7 +2,11 @@
 //
 //   ppcx_loglik_kernel<CM,GEN>  streams the int32 count matrix once per gradient evaluation and reduces it to a handful
 //                           of sums per gene. Replaces lp_reduce + map_rect + X*alpha of
-//                           inst/stan/negBinomial_MPI.stan:58-120,:205,:226-240.
+//                           inst/stan/negBinomial_MPI.stan:58-120,:205,:226-240. CM = design columns (2, 4, 8, 16), GEN = the
+//                           route with an exp per cell that is compiled in (0 none, 1 continuous covariate, 2 no column of ones).
+//   ppcx_ls_kernel<CM,GEN>  the merged launch of a pipelined round: those workgroups beside the chains' state machines.
+//   ppcx_gene_kernel<CM>    the other launch of a pipelined round: everything per gene (command, close, anticipated constants).
+//   ppcx_disp_build_kernel  the genes' dispersion tables (ppcx_disp.h), once per model and per change of the exclusions.
 //   ppcx_close_kernel<CM>   per gene: priors (.stan:219-223), gradient, second half kick of the leapfrog, NUTS tree
 //                           bookkeeping of the gene's coordinates, block partial sums.
 //   ppcx_step_kernel        reduction of the close kernel's block partials, hyper-parameters, NUTS / adaptation state

@@ -5,27 +5,25 @@
 //   transforms :183-197,:203      priors :210-223      likelihood lp_reduce :58-120 via map_rect :226-240
 //   coefficient assembly merge_coefficients :122-139 and X*alpha :205 (fused away: eta is formed per cell)
 //
-// How it is computed (the MI355X-first part, see DESIGN.md "log-likelihood kernel"). With log phi = -sigma_raw exactly,
-// t = eta + sigma_raw, u = exp(t), w = 1 + u, x = y + phi, xf = x/phi = 1 + y/phi and rho = xf/w = x/(phi w):
-//   * Stirling at x AND at phi, leading terms cancelled analytically (dlt, dps = the "Stirling excess" of phi,
-//     ppcx_math.h):
-//       NB2log(y|eta,phi) + lgamma(y+1) = y eta - y + (y + phi) ln rho - 1/2 ln xf + lg_tail(1/x) - dlt
-//       d/deta = y - x u/w = phi (rho - 1)
-//       d/dphi = psi(x) - psi(phi) - ln w + 1 - x/(phi w) = ln rho - dg_tail(1/x) + dps + 1 - rho
-//     so a cell needs ONE logarithm (ln rho), one reciprocal (of w xf: it yields 1/w and 1/xf) and the two tails;
-//     sum_s ln xf is the logarithm of a running product (one multiply per cell, renormalised every few cells);
-//     the tails are degree-4 polynomials in 1/x^2 valid for every x >= 8 (ppcx_math.h stirling_tails);
-//   * sum_s y eta, sum_s y are per-gene SUFFICIENT STATISTICS (SyE, SyX, Sy) precomputed once, so the large
-//     cancelling terms never go through the per-cell loop; sum_s lgamma(y+1) is a per-gene constant of the data (Lg1);
-//   * cells with y <= 7 do not use Stirling at x: lgamma(y + phi) - lgamma(phi) = sum_{k<y} ln(phi + k) depends on the
-//     count and on phi only, so the gene adds it once per k = 0..6, weighted by the number M_k of such cells with y > k
-//     (counted at upload); per cell only - (y + phi) ln w and rho remain: one reciprocal, one logarithm;
-//   * for genes without slope terms (g >= K, X[,1] == 1) exp(t) factorises into E_s * A_g with
-//     E_s = exp(exposure_s) staged in LDS and A_g = exp(intercept_g + sigma_raw_g): no per-cell exp;
-//   * the row sweep evaluates only the cells with y >= 8 (then x >= 8 whatever phi is: one regime, no test); the cells
-//     with 0 <= y <= 7 are kept in a per-gene list built at upload and evaluated by a second, short loop;
-//   * excluded cells (to_exclude, R/utilities.R:321-359, subtracted at .stan:105-115) are stored as count = -1, are in
-//     neither loop, and are left out of the sufficient statistics.
+// How it is computed (the MI355X-first part). With log phi = -sigma_raw exactly, t = eta + sigma_raw,
+// w = 1 + exp(t), q = 1/w, l = ln w:
+//       NB2log(y|eta,phi) + lgamma(y+1) = y eta - y - (y + phi) l + [lgamma(y+phi) - lgamma(phi) + y sigma_raw + y]
+//       d/deta = y - (y + phi)(1 - q) = phi (rho - 1),   rho = (1 + y/phi) q
+//       d/dphi = - l + 1 - rho + [psi(y+phi) - psi(phi)]
+//   * the brackets depend on the count and the dispersion only: summed over a gene's cells they are two functions of sigma_raw
+//     per gene, tabulated at upload (ppcx_disp.h, round 5; rounds 2-4 evaluated them per cell with Stirling tails at y + phi and
+//     at phi, leading terms cancelled analytically -- that cell, ppcx_disp.h disp_cell, now runs at the table nodes and outside
+//     the tables' range only);
+//   * a cell needs ONE reciprocal (v_rcp_f64 + a Newton step) and ONE logarithm (table-driven) and four accumulations
+//     (sum q, sum y q, sum l, sum y l); sum rho is formed once per gene;
+//   * sum_s y eta, sum_s y are per-gene SUFFICIENT STATISTICS (SyE, SyX, Sy) precomputed once, so the large cancelling terms
+//     never go through the per-cell loop; sum_s lgamma(y+1) is a per-gene constant of the data (Lg1);
+//   * exp(t) factorises into E_s * A_g with E_s = exp(exposure_s) staged in LDS and A_g = exp(intercept_g + sigma_raw_g), times
+//     exp(slope_c) for the sample's indicator columns of a gene with slopes: no per-cell exp; a continuous covariate costs one
+//     exp(X_s . slopes) per cell on top of it (ppcx_gene.h sweep_cells MODE 3);
+//   * the cells of a gene whose w lie within four binades are evaluated on 2^-k w in [1, 16) (the windowed cell below);
+//   * excluded cells (to_exclude, R/utilities.R:321-359, subtracted at .stan:105-115) are stored as count = -1, skipped by
+//     the sweep, and left out of the sufficient statistics and the tables.
 #pragma once
 #include "ppcx_math.h"
 #include "ppcx_disp.h"
