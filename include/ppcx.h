@@ -210,7 +210,9 @@ PPCX_API int ppcx_comm_create(int device, int nranks, int rank, const char* id12
 PPCX_API void ppcx_comm_destroy(ppcx_comm* c);
 PPCX_API int ppcx_fit_nuts_comm(ppcx_model* shard, const ppcx_nuts_config* cfg, ppcx_comm* comm, ppcx_fit** out);
 
-/* --- gene shards with a DIRECT exchange (the default between GPUs): no collective library call per leapfrog. Every rank's
+/* --- gene shards with a DIRECT exchange (the default between GPUs; exercised so far between processes that share one GPU and
+ * between host threads -- no multi-GPU box was available to any round -- so the host layer, distributed.do_inference_shards, falls
+ * back to ppcx_fit_nuts_comm on ALL ranks when its set-up fails on any): no collective library call per leapfrog. Every rank's
  * receive buffer (uncached device memory) is mapped into every rank -- hipIpc handles between processes -- and the chains'
  * state machines, which run inside the merged launch of a pipelined round beside the log-likelihood workgroups, store their
  * <= 76 partial sums into the peers' buffers over xGMI, then a sequence number, and wait for the peers' (rank-order sum:

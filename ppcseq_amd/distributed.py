@@ -81,6 +81,11 @@ def raise_if_any_rank_failed(err: BaseException | None, device="cpu", what="a ra
         raise RuntimeError(f"{what}: rank {world - int(worst)} failed; this rank leaves with it")
 
 
+def any_rank_failed(err: BaseException | None, device="cpu") -> bool:
+    """Collective: whether any rank passed an exception (nobody raises -- the caller has a way on for all ranks together)."""
+    return max_over_ranks(1.0 if err is not None else 0.0, device=device) > 0.0
+
+
 def do_inference(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_device="cpu", chains=None, cores=None,
                  approximate_posterior_analysis=False, lambda_mu_mu=5.612671, adj_prob_theshold=0.05,
                  how_many_posterior_draws=1000, to_exclude=None, truncation_compensation=1.0, seed=1, launch=None):
@@ -145,7 +150,8 @@ def do_inference(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_
 
 def do_inference_shards(counts, X, exposure_rate, how_many_to_check, *, device=0, coll_device="cpu", chains=None, cores=None,
                         approximate_posterior_analysis=False, lambda_mu_mu=5.612671, adj_prob_theshold=0.05,
-                        how_many_posterior_draws=1000, to_exclude=None, truncation_compensation=1.0, seed=1, launch=None):
+                        how_many_posterior_draws=1000, to_exclude=None, truncation_compensation=1.0, seed=1, launch=None,
+                        exchange="direct"):
     """One inference pass with the GENES partitioned over the ranks (the reference's map_rect over gene shards,
     inst/stan/negBinomial_MPI.stan:226-240; BASELINE cfg4): every rank holds every world-th gene (the reference's round-robin deal,
     R/utilities.R:125-136: an equal share of the checked genes and of the work on every rank) and runs ALL the chains on them, the six hyper-parameters and the chains' state machines are replicated, and the ranks' partial sums meet every leapfrog
@@ -153,10 +159,18 @@ def do_inference_shards(counts, X, exposure_rate, how_many_to_check, *, device=0
     are then gathered on rank 0, which computes the credible intervals from them exactly as the chains path does
     (pooled_summary), and the result is broadcast (with the sampler's diagnostics, which are the same on every rank: the state
     machines are replicated). Needs a design that runs pipelined rounds (factor designs, `~ 1`). `launch` = (lanes_per_gene,
-    workgroups) pins the log-likelihood launch as in do_inference."""
+    workgroups) pins the log-likelihood launch as in do_inference.
+    `exchange` = "direct" (default) or "rccl" (an RCCL all-reduce per leapfrog between the launches of the three-launch round,
+    ppcx_fit_nuts_comm; needs one GPU per rank). The direct exchange has run between processes that share one GPU and between
+    host threads, never yet between GPUs (no multi-GPU box was available to any round): if its set-up fails on ANY rank -- the
+    allocation of uncached memory, an IPC handle that a peer cannot open, peer access -- ALL ranks fall back to the RCCL path
+    together, with a warning; a failure of that path is raised on every rank."""
     import math
+    import warnings
     from . import _lib
     from .inference import _to_cell_ids, find_optimal_number_of_chains, pooled_summary
+    if exchange not in ("direct", "rccl"):
+        raise ValueError("exchange must be 'direct' or 'rccl'")
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
     counts = np.asarray(counts)
@@ -180,26 +194,55 @@ def do_inference_shards(counts, X, exposure_rate, how_many_to_check, *, device=0
         keep = (eg % world) == rank
         excl = ((eg[keep] // world) * S + es[keep]).astype(np.int32)
     part, err, diag = None, None, None
-    m = xg = None
+    m = xg = comm = None
     try:
         m = _lib.Model(counts[mine], X, exposure_rate, 0, lambda_mu_mu=lambda_mu_mu, excl=excl, device=device, shard=(G, K, rank, None, world))
-        xg = _lib.Xchg(world, rank, chains, device=device)
-        handle = xg.handle()
-    except Exception as e:                          # noqa: BLE001
-        err, handle = e, b""
-    raise_if_any_rank_failed(err, device=coll_device, what="gene shards (set-up)")
-    handles = [None] * world
-    dist.all_gather_object(handles, handle)
-    try:
-        if world > 1:
-            xg.connect(handles)
     except Exception as e:                          # noqa: BLE001
         err = e
-    raise_if_any_rank_failed(err, device=coll_device, what="gene shards (exchange)")      # also the barrier before anybody publishes
+    raise_if_any_rank_failed(err, device=coll_device, what="gene shards (model)")
+    if exchange == "direct":
+        xerr, handle = None, b""
+        try:
+            xg = _lib.Xchg(world, rank, chains, device=device)
+            handle = xg.handle()
+        except Exception as e:                      # noqa: BLE001
+            xerr = e
+        handles = [None] * world
+        dist.all_gather_object(handles, handle)
+        if xerr is None:
+            try:
+                if world > 1:
+                    xg.connect(handles)
+            except Exception as e:                  # noqa: BLE001
+                xerr = e
+        if any_rank_failed(xerr, device=coll_device):      # also the barrier before anybody publishes
+            if xg is not None:
+                xg.close()
+                xg = None
+            warnings.warn("gene shards: the direct exchange could not be set up on every rank"
+                          + (f" (this rank: {xerr})" if xerr is not None else "") + "; all ranks use the RCCL path", RuntimeWarning)
+            exchange = "rccl"
+    if exchange == "rccl":
+        uid = [None]
+        try:
+            if rank == 0:
+                uid[0] = _lib.Comm.unique_id()
+        except Exception as e:                      # noqa: BLE001
+            err = e
+        raise_if_any_rank_failed(err, device=coll_device, what="gene shards (RCCL id)")
+        dist.broadcast_object_list(uid, src=0)
+        try:
+            comm = _lib.Comm(world, rank, uid[0], device=device)
+        except Exception as e:                      # noqa: BLE001
+            err = e
+        raise_if_any_rank_failed(err, device=coll_device, what="gene shards (RCCL communicator)")
     try:
         if launch is not None:
             m.set_launch(*launch)
-        f = m.fit_nuts_xchg(xg, chains=chains, iter=n_iter, warmup=150, seed=seed)
+        if comm is not None:
+            f = m.fit_nuts_comm(comm, chains=chains, iter=n_iter, warmup=150, seed=seed)
+        else:
+            f = m.fit_nuts_xchg(xg, chains=chains, iter=n_iter, warmup=150, seed=seed)
         try:
             diag = f.diagnostics()
             Gl, Kl = len(mine), m.K                 # this shard's genes and checked genes (local unconstrained vector, Stan order)
@@ -217,6 +260,8 @@ def do_inference_shards(counts, X, exposure_rate, how_many_to_check, *, device=0
             m.close()
         if xg is not None:
             xg.close()
+        if comm is not None:
+            comm.close()
     raise_if_any_rank_failed(err, device=coll_device, what="gene shards (fit)")
     parts = [None] * world
     dist.all_gather_object(parts, part)

@@ -465,6 +465,59 @@ def test_do_inference_with_the_genes_sharded_over_two_ranks():
     assert int(div[:, 150:].sum()) <= 40 and int(one.diagnostics["divergent"][:, 150:].sum()) <= 40
 
 
+def _shards_fallback_worker(rank, world, port, q):
+    import warnings
+    import torch.distributed as dist
+    from ppcseq_amd import _lib as L, distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L.use_library(_testing_lib())
+        L.testing_set_nccl_provider(_loopback_lib())      # RCCL refuses two ranks on one device: the stand-in over shared memory
+        if rank == 1:                                     # this rank cannot map its peer's buffer
+            def broken_connect(self, handles):
+                raise L.PpcxError("ppcx error -3: injected: hipIpcOpenMemHandle failed")
+            L.Xchg.connect = broken_connect
+        d = ind.synth_factor(90, 12, 7, (3,), 5)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            r = D.do_inference_shards(d["counts"], d["X"], d["exposure"], 7, device=0, coll_device="cpu", chains=4,
+                                      to_exclude=np.array([3, 14], np.int32), launch=LAUNCH, **KW)
+        q.put((rank, "ok", r.deleterious_outliers, r.diagnostics["n_leapfrog"], [str(x.message) for x in w]))
+    except Exception as e:                      # noqa: BLE001
+        q.put((rank, "crash: " + repr(e), None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_do_inference_falls_back_to_the_collective_when_the_direct_exchange_cannot_be_set_up():
+    """The direct exchange has never run between GPUs (no multi-GPU box was available to any round): when its set-up fails on
+    ANY rank -- here rank 1 cannot map its peer's buffer -- ALL ranks of distributed.do_inference_shards take the RCCL path
+    together (ppcx_fit_nuts_comm; through the loopback stand-in here, two ranks on one device), warn, and deliver the calls of the
+    one-rank pass; nobody is left waiting in a collective."""
+    from ppcseq_amd.inference import do_inference
+    _loopback_lib(); _testing_lib()
+    d = ind.synth_factor(90, 12, 7, (3,), 5)
+    one = do_inference(d["counts"], d["X"], d["exposure"], 7, chains=4, to_exclude=np.array([3, 14], np.int32), launch=LAUNCH, **KW)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shards_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == ["ok", "ok"], [r[1] for r in res]
+    for r in res:
+        assert any("all ranks use the RCCL path" in m for m in r[4]), r[4]
+    assert "injected" in " ".join(res[1][4]) and "injected" not in " ".join(res[0][4])          # the failing rank says why
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][2], one.deleterious_outliers)
+    assert np.array_equal(res[0][3][:, :10], one.diagnostics["n_leapfrog"][:, :10])              # the unsharded chains' first trees
+
+
 def test_a_refused_exchange_fit_leaves_nothing_on_the_device():
     """ppcx_fit_nuts_xchg looks at its exchange group before it allocates anything: the direct exchange needs pipelined rounds,
     which ppcx_model_set_rounds can rule out -- a documented, expected refusal (PPCX_ERR_LIMIT: use ppcx_fit_nuts_comm) -- and a
